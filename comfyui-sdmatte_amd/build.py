@@ -1,0 +1,56 @@
+"""Build recipe of the native engine: `hipcc --offload-arch=gfx950` -> csrc/libsdmatte_hip.so (in-tree, so the
+built library travels to the GPU box with the repo snapshot).  gfx950 only; no other backend is compiled."""
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(CSRC, "libsdmatte_hip.so")
+SOURCES = ["sdm_engine.cpp"]
+HEADERS = ["sdm_common.h", "k_conv.h", "k_norm.h", "k_attn.h", "k_misc.h", os.path.join("..", "..", "include", "sdmatte.h")]
+FLAGS = ["-x", "hip", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
+         "-Wno-unused-result", "-Wno-unused-value", "-DNDEBUG"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: the SDMatte engine needs the ROCm toolchain (gfx950)")
+
+
+def _stamp():
+    h = hashlib.sha256()
+    for f in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build_all(verbose=False, force=False, extra_flags=()):
+    stamp_file = LIB + ".stamp"
+    stamp = _stamp()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+        if verbose:
+            print(f"[sdmatte] {LIB} is up to date")
+        return LIB
+    cmd = [_hipcc()] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    if verbose:
+        print("[sdmatte] " + " ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("hipcc failed building libsdmatte_hip.so")
+    if verbose and r.stderr.strip():
+        print(r.stderr[-4000:])
+    with open(stamp_file, "w") as f:
+        f.write(stamp)
+    return LIB
+
+
+if __name__ == "__main__":
+    build_all(verbose=True, force="--force" in sys.argv)

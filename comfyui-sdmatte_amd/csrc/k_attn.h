@@ -1,0 +1,357 @@
+// k_attn.h - flash-style attention for gfx950 (MFMA f16, fp32 online softmax, no L x L buffer).
+//
+// Reference semantics (fp32): probs = softmax(baddbmm(bias, q, k^T, beta=1, alpha=d^-1/2)) ; out = probs @ v
+//   /root/reference/src/utils/replace.py:75-122 (custom_get_attention_scores) driven by diffusers'
+//   AttnProcessor / SlicedAttnProcessor (sdmatte_nodes.py:331-337) for the 32 U-Net attentions, where
+//   `bias` is the per-key additive trimap bias (1-m)*-10000 broadcast over queries and heads
+//   (replace.py:401-403, 56-70), absent for cross-attention; and SDPA for the three single-head d=512
+//   VAE mid-block attentions.
+//
+// Formulation ("swapped" QK^T, cdna_hip_programming.md T12): S^T = K.Q^T so that after the MFMA every
+// lane owns ONE query column (q = lane&31) and 16 of the 32 keys of a key tile; softmax max/sum are
+// in-lane reductions plus one exchange with lane^32; P^T is already in B-operand layout for
+// O^T = V^T.P^T (the k-slot <-> key permutation only has to agree between A and B).  V is consumed
+// through a pre-transposed copy V^T[d][key] so that its A fragments are two 8-byte LDS reads.
+// Logits are computed in fp32 as s*scale*log2e + bias*log2e and exponentiated with v_exp_f32 (2^x).
+#pragma once
+#include "sdm_common.h"
+
+struct AttnParams {
+  const half_t* q; long q_bs; int ldq;                     // q [b][row][head*D + d]
+  const half_t* k; long k_bs; int ldk;                     // k [b][key][head*D + d]
+  const half_t* vt; long vt_bs; long vt_hs; int ldvt;      // vt[b][head][d][key]  (key padded to ldvt, zero filled)
+  const float* bias; long bias_bs;                         // bias[b][key] * log2e, or null
+  half_t* o; long o_bs; int ldo;                           // o [b][row][head*D + d]
+  int Lq, Lk;
+  float scale_log2e;
+};
+
+#define SDM_NEG_BIG (-1.0e30f)
+
+// ------------------------------------------------------------------------------------------------
+// d = 64, any number of heads (grid.y), 4 waves x 32 queries per block, 64-key tiles.
+// ------------------------------------------------------------------------------------------------
+#define ATTN64_PK 144
+#define ATTN64_SMEM (2 * 64 * ATTN64_PK + 256)
+
+__global__ void __launch_bounds__(256) attn_d64_kernel(AttnParams p) {
+  SDM_DYN_SMEM(smem);
+  constexpr int PK = ATTN64_PK;
+  unsigned char* Ks = smem;
+  unsigned char* Vs = smem + 64 * PK;
+  float* Bs = (float*)(smem + 2 * 64 * PK);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+
+  f16x8 qf[4];
+  {
+    int qrow = q0 + l31;
+    if (qrow > p.Lq - 1) qrow = p.Lq - 1;
+    const half_t* qp = p.q + (size_t)b * p.q_bs + (size_t)qrow * p.ldq + head * 64 + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const f16x8*)(qp + ks * 16);
+  }
+  f32x16 o[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.0f;
+  float m_i = SDM_NEG_BIG, l_i = 0.0f;
+
+  const half_t* kbase = p.k + (size_t)b * p.k_bs + head * 64;
+  const half_t* vbase = p.vt + (size_t)b * p.vt_bs + (size_t)head * p.vt_hs;
+  const float* bbase = p.bias ? p.bias + (size_t)b * p.bias_bs : nullptr;
+  const int ntiles = (p.Lk + 63) / 64;
+
+  f16x8 kreg[2], vreg[2];
+  float breg = 0.0f;
+  auto prefetch = [&](int t) {
+    const int k0 = t * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int v = tid + i * 256;
+      const int row = v >> 3, part = v & 7;
+      f16x8 z;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = (half_t)0.0f;
+      kreg[i] = (k0 + row < p.Lk) ? *(const f16x8*)(kbase + (size_t)(k0 + row) * p.ldk + part * 8) : z;
+      vreg[i] = *(const f16x8*)(vbase + (size_t)row * p.ldvt + k0 + part * 8);
+    }
+    if (tid < 64) breg = (k0 + tid < p.Lk) ? (bbase ? bbase[k0 + tid] : 0.0f) : SDM_NEG_BIG;
+  };
+  prefetch(0);
+
+  for (int t = 0; t < ntiles; ++t) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int v = tid + i * 256;
+      const int row = v >> 3, part = v & 7;
+      *(f16x8*)(Ks + row * PK + part * 16) = kreg[i];
+      *(f16x8*)(Vs + row * PK + part * 16) = vreg[i];
+    }
+    if (tid < 64) Bs[tid] = breg;
+    __syncthreads();
+    if (t + 1 < ntiles) prefetch(t + 1);
+
+    // S^T[key][q] for 2 key tiles of 32
+    f32x16 s[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kt][r] = 0.0f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const f16x8 a = *(const f16x8*)(Ks + (kt * 32 + l31) * PK + ks * 32 + hi * 16);
+        s[kt] = SDM_MFMA_32x32x16_F16(a, qf[ks], s[kt]);
+      }
+    }
+    float mx = SDM_NEG_BIG;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 bb = *(const f32x4*)(Bs + kt * 32 + 8 * g + 4 * hi);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x = s[kt][4 * g + e] * p.scale_log2e + bb[e];
+          s[kt][4 * g + e] = x;
+          mx = fmaxf(mx, x);
+        }
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mnew = fmaxf(m_i, mx);
+    const float alpha = sdm_exp2(m_i - mnew);
+    m_i = mnew;
+    float rs = 0.0f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = sdm_exp2(s[kt][r] - mnew);
+        s[kt][r] = pv;
+        rs += pv;
+      }
+    l_i = l_i * alpha + rs;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+
+    // O^T[d][q] += V^T[d][key] . P^T[key][q]
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        f16x8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (half_t)s[kt][8 * u + j];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const unsigned char* vp = Vs + (dt * 32 + l31) * PK + (kt * 32 + 16 * u + 4 * hi) * 2;
+          const f16x4 v0 = *(const f16x4*)vp;
+          const f16x4 v1 = *(const f16x4*)(vp + 16);
+          f16x8 vf;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { vf[e] = v0[e]; vf[4 + e] = v1[e]; }
+          o[dt] = SDM_MFMA_32x32x16_F16(vf, pf, o[dt]);
+        }
+      }
+  }
+
+  l_i += __shfl_xor(l_i, 32);
+  const float inv = 1.0f / l_i;
+  __syncthreads();
+  unsigned char* stg = smem + wave * (32 * PK);
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f16x4 h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) h[e] = (half_t)(o[dt][4 * g + e] * inv);
+      *(f16x4*)(stg + l31 * PK + (dt * 32 + 8 * g + 4 * hi) * 2) = h;
+    }
+  __syncthreads();
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int row = pass * 8 + (lane >> 3), part = lane & 7;
+    const int qg = q0 + row;
+    if (qg < p.Lq)
+      *(f16x8*)(p.o + (size_t)b * p.o_bs + (size_t)qg * p.ldo + head * 64 + part * 8) = *(const f16x8*)(stg + row * PK + part * 16);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// d = 512, single head (VAE mid-block).  8 waves: wave w handles queries 32*(w>>1).. and the d-half
+// (w&1): partial S^T over its 256 d, exchanged with the partner wave through LDS; both then run the
+// same softmax and each accumulates O^T for its own 256 d.  32-key tiles.
+// ------------------------------------------------------------------------------------------------
+#define ATTN512_PKK 1040
+#define ATTN512_PKV 80
+#define ATTN512_KS_BYTES (32 * ATTN512_PKK)
+#define ATTN512_VS_BYTES (512 * ATTN512_PKV)
+#define ATTN512_X_BYTES (8 * 16 * 64 * 4)
+#define ATTN512_SMEM (ATTN512_KS_BYTES + ATTN512_VS_BYTES + ATTN512_X_BYTES)
+
+__global__ void __launch_bounds__(512) attn_d512_kernel(AttnParams p) {
+  SDM_DYN_SMEM(smem);
+  constexpr int PKK = ATTN512_PKK, PKV = ATTN512_PKV;
+  unsigned char* Ks = smem;
+  unsigned char* Vs = smem + ATTN512_KS_BYTES;
+  float* Xs = (float*)(smem + ATTN512_KS_BYTES + ATTN512_VS_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int qgp = wave >> 1, dh = wave & 1;
+  const int b = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + qgp * 32;
+
+  f16x8 qf[16];
+  {
+    int qrow = q0 + l31;
+    if (qrow > p.Lq - 1) qrow = p.Lq - 1;
+    const half_t* qp = p.q + (size_t)b * p.q_bs + (size_t)qrow * p.ldq + dh * 256 + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) qf[ks] = *(const f16x8*)(qp + ks * 16);
+  }
+  f32x16 o[8];
+#pragma unroll
+  for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.0f;
+  float m_i = SDM_NEG_BIG, l_i = 0.0f;
+
+  const half_t* kbase = p.k + (size_t)b * p.k_bs;
+  const half_t* vbase = p.vt + (size_t)b * p.vt_bs;
+  const int ntiles = (p.Lk + 31) / 32;
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int k0 = t * 32;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int v = tid + i * 512;
+      {  // K tile: 32 keys x 64 vectors
+        const int row = v >> 6, part = v & 63;
+        f16x8 z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = (half_t)0.0f;
+        const f16x8 kv = (k0 + row < p.Lk) ? *(const f16x8*)(kbase + (size_t)(k0 + row) * p.ldk + part * 8) : z;
+        *(f16x8*)(Ks + row * PKK + part * 16) = kv;
+      }
+      {  // V^T tile: 512 d x 4 vectors (32 keys)
+        const int row = v >> 2, part = v & 3;
+        *(f16x8*)(Vs + row * PKV + part * 16) = *(const f16x8*)(vbase + (size_t)row * p.ldvt + k0 + part * 8);
+      }
+    }
+    __syncthreads();
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const f16x8 a = *(const f16x8*)(Ks + l31 * PKK + (dh * 256 + ks * 16 + hi * 8) * 2);
+      s = SDM_MFMA_32x32x16_F16(a, qf[ks], s);
+    }
+    float* xme = Xs + wave * (16 * 64);
+    const float* xpt = Xs + (wave ^ 1) * (16 * 64);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xme[r * 64 + lane] = s[r];
+    __syncthreads();
+    float mx = SDM_NEG_BIG;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      float x = (s[r] + xpt[r * 64 + lane]) * p.scale_log2e;
+      if (key >= p.Lk) x = SDM_NEG_BIG;
+      s[r] = x;
+      mx = fmaxf(mx, x);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mnew = fmaxf(m_i, mx);
+    const float alpha = sdm_exp2(m_i - mnew);
+    m_i = mnew;
+    float rs = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pv = sdm_exp2(s[r] - mnew);
+      s[r] = pv;
+      rs += pv;
+    }
+    l_i = l_i * alpha + rs;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      f16x8 pf;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pf[j] = (half_t)s[8 * u + j];
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) {
+        const unsigned char* vp = Vs + (dh * 256 + dt * 32 + l31) * PKV + (16 * u + 4 * hi) * 2;
+        const f16x4 v0 = *(const f16x4*)vp;
+        const f16x4 v1 = *(const f16x4*)(vp + 16);
+        f16x8 vf;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { vf[e] = v0[e]; vf[4 + e] = v1[e]; }
+        o[dt] = SDM_MFMA_32x32x16_F16(vf, pf, o[dt]);
+      }
+    }
+  }
+
+  l_i += __shfl_xor(l_i, 32);
+  const float inv = 1.0f / l_i;
+  // epilogue: two passes of 4 d-tiles (128 d) through per-wave LDS staging [32 q][128 d] fp16, pitch 272
+  constexpr int PS = 272;
+  unsigned char* stg = smem + wave * (32 * PS);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();
+#pragma unroll
+    for (int d4 = 0; d4 < 4; ++d4) {
+      const int dt = half * 4 + d4;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f16x4 h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = (half_t)(o[dt][4 * g + e] * inv);
+        *(f16x4*)(stg + l31 * PS + (d4 * 32 + 8 * g + 4 * hi) * 2) = h;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+      const int row = pass * 4 + (lane >> 4), part = lane & 15;
+      const int qg = q0 + row;
+      if (qg < p.Lq)
+        *(f16x8*)(p.o + (size_t)b * p.o_bs + (size_t)qg * p.ldo + dh * 256 + half * 128 + part * 8) =
+            *(const f16x8*)(stg + row * PS + part * 16);
+    }
+  }
+}
+
+// V [b][key][head*D + d]  ->  V^T [b][head][d][key] (key padded to ldvt with zeros). 64x64 tiles.
+__global__ void __launch_bounds__(256) transpose_v_kernel(const half_t* __restrict__ v, long v_bs, int ldv, half_t* __restrict__ vt,
+                                                          long vt_bs, long vt_hs, int ldvt, int Lk, int D) {
+  SDM_SHARED half_t tile[64][66];
+  const int b = blockIdx.z;
+  const int dblocks = D / 64;
+  const int head = blockIdx.y / dblocks, d0 = (blockIdx.y % dblocks) * 64;
+  const int k0 = blockIdx.x * 64;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 64 * 64; i += 256) {
+    const int key = i >> 6, d = i & 63;
+    half_t x = (half_t)0.0f;
+    if (k0 + key < Lk) x = v[(size_t)b * v_bs + (size_t)(k0 + key) * ldv + head * D + d0 + d];
+    tile[key][d] = x;
+  }
+  __syncthreads();
+  for (int i = tid; i < 64 * 64; i += 256) {
+    const int d = i >> 6, key = i & 63;
+    if (k0 + key < ldvt) vt[(size_t)b * vt_bs + (size_t)head * vt_hs + (size_t)(d0 + d) * ldvt + k0 + key] = tile[key][d];
+  }
+}

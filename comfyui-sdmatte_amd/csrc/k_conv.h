@@ -1,0 +1,297 @@
+// k_conv.h - implicit-GEMM convolution / linear kernel for gfx950 (MFMA f16 -> f32).
+//
+// One kernel template covers every dense contraction of the SDMatte path:
+//   * conv3x3 stride 1/2 of the VAE and U-Net (ResnetBlock2D.conv1/conv2, Down/Upsample2D.conv,
+//     conv_in/conv_out ...; reference call sites meta_arch.py:142,209,216,256 and replace.py:462-544
+//     reaching diffusers blocks).  A 3x3 conv is 9 shifted 1x1 GEMM taps
+//     accumulated into the same MFMA accumulators from ONE LDS halo tile (no im2col in HBM).
+//   * 1x1 conv_shortcut / quant_conv / post_quant_conv and every nn.Linear (proj_in/out, to_q/k/v,
+//     to_out, GEGLU proj, ff.net.2): NTAPS = 1 over a flat [rows, Cin] activation.
+//
+// Layouts: activations NHWC (fp16, or fp32 for the residual stream); weights pre-packed by
+// pack_conv_weight_kernel as fp16 [Cin_pad/16][NTAPS][Cout_pad][16] ("K16" layout, independent of the
+// tile configuration chosen at run time) so that the B tile of one K-chunk is a few contiguous runs;
+// fp32 accumulation.
+// GEMM orientation: M = output pixels (A operand, from the LDS halo tile), N = output channels
+// (B operand), K = KC input channels per tap.  v_mfma_f32_32x32x16_f16; wave tile (MT*32)x(NTL*32).
+// LDS rows are padded to KC*2+16 bytes: with ds_read_b128 the 16-lane groups then hit 16 distinct
+// 16-B slots of the 256-B bank row (conflict-free), see MI355X_MICROARCH.md LDS table.
+//
+// Fused on load : zero padding (symmetric pad 1, or the VAE's asymmetric (0,1,0,1) pad), nearest
+//                 2x upsample (Upsample2D), two-pointer channel concat (U-Net skip `cat`), fp32->fp16.
+// Fused on store: +bias (optionally per-image: the ResBlock time-embedding projection folded into
+//                 conv1's bias), *scale (VAE scaling_factor), +residual, GEGLU u*gelu(g), fp16/fp32,
+//                 channel-offset stores (writes straight into the 8-ch U-Net input tensor).
+#pragma once
+#include "sdm_common.h"
+
+struct ConvParams {
+  const void* in0; const void* in1;     // NHWC sources (channel concat: in0 then in1); in1 may be null
+  int C0, C1;                           // channel counts (row strides) of the sources; (C0+C1) % KC == 0
+  int in_f32;                           // sources are fp32 (1) or fp16 (0)
+  int N, Hin, Win;                      // source dims (before the fused upsample)
+  int up;                               // 1: nearest x2 upsample fused into the load
+  int Hout, Wout;
+  int pad_t, pad_l;
+  long M;                               // NTAPS==1: number of rows (N*H*W)
+  const half_t* w;                      // packed weights, K16 layout
+  const float* bias;                    // [nvariants][Cout_pad]
+  const int* bias_sel;                  // [N] variant per image or null
+  int Cout_pad;                         // GEMM N (multiple of 32)
+  void* out; int out_f32;
+  int Cout_store;                       // row stride (channels) of the output tensor
+  int Cout_valid;                       // number of (post-epilogue) channels actually stored (mult of 4)
+  int out_ch_off;                       // channel offset inside the output row (mult of 4)
+  const void* res; int res_f32; int res_C;
+  int epi;                              // 0: linear, 1: GEGLU (cols come in [u32|g32] groups of 64)
+  float out_scale;
+};
+
+template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN>
+struct ConvCfg {
+  static constexpr int NTHREADS = 64 * WM * WN;
+  static constexpr int BM = TH * TW;
+  static constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 32, NTL = WTN / 32;
+  static constexpr int HPH = (NTAPS == 9) ? (TH - 1) * STRIDE + 3 : TH;
+  static constexpr int HPW = (NTAPS == 9) ? (TW - 1) * STRIDE + 3 : TW;
+  static constexpr int HP = HPH * HPW;
+  static constexpr int PITCH = KC * 2 + 16;
+  static constexpr int KV = KC / 8;
+  static constexpr int A_BYTES = HP * PITCH;
+  static constexpr int B_BYTES = NTAPS * BN * PITCH;
+  static constexpr int STG_BYTES = WM * WN * 32 * WTN * 4;
+  static constexpr int SMEM = (A_BYTES + B_BYTES) > STG_BYTES ? (A_BYTES + B_BYTES) : STG_BYTES;
+  static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of 32x32");
+  static_assert(KC % 16 == 0, "KC multiple of the MFMA K (16)");
+};
+
+template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN>
+__global__ void __launch_bounds__(64 * WM * WN)
+conv_mfma_kernel(ConvParams p) {
+  using C = ConvCfg<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN>;
+  constexpr int NT = C::NTHREADS, MT = C::MT, NTL = C::NTL, PITCH = C::PITCH, KV = C::KV;
+  constexpr int HPW = C::HPW, HP = C::HP, WTM = C::WTM, WTN = C::WTN;
+  SDM_DYN_SMEM(smem);
+  unsigned char* As = smem;
+  unsigned char* Bs = smem + C::A_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int n0 = blockIdx.y * BN;
+  int img = 0, oy0 = 0, ox0 = 0;
+  long m0 = 0;
+  if (NTAPS == 9) {
+    const int npx = (p.Wout + TW - 1) / TW;
+    img = blockIdx.z;
+    oy0 = (blockIdx.x / npx) * TH;
+    ox0 = (blockIdx.x % npx) * TW;
+  } else {
+    m0 = (long)blockIdx.x * C::BM;
+  }
+  const int Cin = p.C0 + p.C1;
+  const int Hl = p.Hin << p.up, Wl = p.Win << p.up;
+
+  f32x16 acc[MT][NTL];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NTL; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  int abase[MT], bbase[NTL];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = wm * WTM + i * 32 + (lane & 31);
+    const int py = m / TW, px = m % TW;
+    abase[i] = ((NTAPS == 9) ? (py * STRIDE * HPW + px * STRIDE) : m) * PITCH + (lane >> 5) * 16;
+  }
+#pragma unroll
+  for (int j = 0; j < NTL; ++j) bbase[j] = (wn * WTN + j * 32 + (lane & 31)) * PITCH + (lane >> 5) * 16;
+
+  for (int c0 = 0; c0 < Cin; c0 += KC) {
+    __syncthreads();
+    // ---- stage A: halo tile [HP pixels][KC channels], zero-filled outside the (upsampled) image ----
+    const void* src = p.in0;
+    int Csrc = p.C0, cc = c0;
+    if (c0 >= p.C0) { src = p.in1; Csrc = p.C1; cc = c0 - p.C0; }
+    for (int v = tid; v < HP * KV; v += NT) {
+      const int hp = v / KV, part = v % KV;
+      f16x8 val;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) val[e] = (half_t)0.0f;
+      if (NTAPS == 9) {
+        const int hy = hp / HPW, hx = hp % HPW;
+        const int iy = oy0 * STRIDE + hy - p.pad_t, ix = ox0 * STRIDE + hx - p.pad_l;
+        if (iy >= 0 && iy < Hl && ix >= 0 && ix < Wl) {
+          const size_t pix = ((size_t)img * p.Hin + (iy >> p.up)) * p.Win + (ix >> p.up);
+          val = sdm_load8_as_f16(src, pix * Csrc + cc + part * 8, p.in_f32);
+        }
+      } else {
+        const long m = m0 + hp;
+        if (m < p.M) val = sdm_load8_as_f16(src, (size_t)m * Csrc + cc + part * 8, p.in_f32);
+      }
+      *(f16x8*)(As + hp * PITCH + part * 16) = val;
+    }
+    // ---- stage B: weights of this K-chunk, all taps: LDS [NTAPS][BN][KC] from the K16-packed tensor ----
+    for (int v = tid; v < NTAPS * BN * KV; v += NT) {
+      const int h = v & 1, co = (v >> 1) % BN, rest = (v >> 1) / BN;
+      const int tap = rest % NTAPS, sc = rest / NTAPS;
+      f16x8 val;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) val[e] = (half_t)0.0f;
+      if (n0 + co < p.Cout_pad)
+        val = *(const f16x8*)(p.w + (((size_t)(c0 / 16 + sc) * NTAPS + tap) * p.Cout_pad + n0 + co) * 16 + h * 8);
+      *(f16x8*)(Bs + (tap * BN + co) * PITCH + (sc * 2 + h) * 16) = val;
+    }
+    __syncthreads();
+    // ---- MFMA over taps and K sub-steps ----
+#pragma unroll
+    for (int tap = 0; tap < NTAPS; ++tap) {
+      const int toff = (NTAPS == 9) ? ((tap / 3) * HPW + (tap % 3)) * PITCH : 0;
+#pragma unroll
+      for (int ks = 0; ks < KC / 16; ++ks) {
+        f16x8 a[MT], b[NTL];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a[i] = *(const f16x8*)(As + abase[i] + toff + ks * 32);
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) b[j] = *(const f16x8*)(Bs + tap * BN * PITCH + bbase[j] + ks * 32);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NTL; ++j) acc[i][j] = SDM_MFMA_32x32x16_F16(a[i], b[j], acc[i][j]);
+      }
+    }
+  }
+
+  // ---- epilogue: per-wave fp32 staging tile (32 x WTN) in LDS -> coalesced row stores ----
+  __syncthreads();
+  float* stg = (float*)smem + wave * (32 * WTN);
+  constexpr int LPR = WTN / 4;   // lanes per output row (4 channels each)
+  constexpr int RPP = 64 / LPR;  // rows per pass
+  const float* bias = p.bias;
+  if (bias && p.bias_sel) bias += (size_t)p.bias_sel[img] * p.Cout_pad;
+  const int colbase = n0 + wn * WTN;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+#pragma unroll
+    for (int j = 0; j < NTL; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        stg[row * WTN + j * 32 + (lane & 31)] = acc[i][j][r];
+      }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 32 / RPP; ++pass) {
+      const int row = pass * RPP + lane / LPR;
+      const int c4 = (lane % LPR) * 4;
+      const int m = wm * WTM + i * 32 + row;
+      long opix;
+      bool valid;
+      if (NTAPS == 9) {
+        const int oy = oy0 + m / TW, ox = ox0 + m % TW;
+        valid = (oy < p.Hout) && (ox < p.Wout);
+        opix = ((long)img * p.Hout + oy) * p.Wout + ox;
+      } else {
+        opix = m0 + m;
+        valid = opix < p.M;
+      }
+      float v[4];
+      int oc;
+      bool colok = true;
+      if (p.epi == 1) {
+        // GEGLU: this wave's 64 columns are [u(32) | g(32)] of the same 32 output channels
+        colok = (c4 & 63) < 32;
+        const int grp = c4 & ~63, c = c4 & 31;
+        const int gcol = colbase + grp + c;                   // GEMM column of u
+        oc = (colbase + grp) / 2 + c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float u = stg[row * WTN + grp + c + e], g = stg[row * WTN + grp + 32 + c + e];
+          if (bias && colok && gcol + 32 + e < p.Cout_pad) { u += bias[gcol + e]; g += bias[gcol + 32 + e]; }
+          v[e] = u * sdm_gelu_erf(g);
+        }
+      } else {
+        oc = colbase + c4;
+        const f32x4 t = *(const f32x4*)(stg + row * WTN + c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = t[e];
+        if (bias && oc < p.Cout_pad) {
+          const f32x4 bb = *(const f32x4*)(bias + oc);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bb[e];
+        }
+      }
+      if (valid && colok && oc < p.Cout_valid) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= p.out_scale;
+        if (p.res) {
+          if (p.res_f32) {
+            const f32x4 rr = *(const f32x4*)((const float*)p.res + (size_t)opix * p.res_C + oc);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += rr[e];
+          } else {
+            const f16x4 rr = *(const f16x4*)((const half_t*)p.res + (size_t)opix * p.res_C + oc);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
+          }
+        }
+        const size_t oidx = (size_t)opix * p.Cout_store + p.out_ch_off + oc;
+        if (p.out_f32) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = v[e];
+          *(f32x4*)((float*)p.out + oidx) = o;
+        } else {
+          f16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
+          *(f16x4*)((half_t*)p.out + oidx) = o;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Pack an OIHW (or [O][I]) fp32 weight into the fp16 K16 layout [Cin_pad/16][ntaps][Cout_pad][16].
+//  * ci_off : the source input channels land at packed channels [ci_off, ci_off+I) (others stay zero)
+//  * co_off : the source rows land at packed rows [co_off, co_off+O) (fused q|k|v GEMMs)
+//  * geglu  : rows are re-ordered so that every 64 GEMM columns hold [u_c..u_c+31 | g_c..g_c+31]
+//             (diffusers GEGLU: proj -> chunk(2) = (u, g); out = u * gelu(g)); O = 2*half rows.
+// Only the rows [co_off, co_off+O) (or all rows for geglu) are written; the arena is zero-initialised.
+SDM_DEV_INLINE int pack_src_row(int co, int O, int co_off, int geglu) {
+  if (geglu) {
+    const int half = O / 2, grp = co / 64, j = co % 64;
+    if (grp * 32 + (j & 31) >= half) return -1;
+    return (j < 32) ? grp * 32 + j : half + grp * 32 + (j - 32);
+  }
+  const int o = co - co_off;
+  return (o >= 0 && o < O) ? o : -1;
+}
+
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, half_t* __restrict__ wp, int O, int I, int ntaps, int Cin_pad,
+                                        int Cout_pad, int ci_off, int co_off, int geglu) {
+  const size_t total = (size_t)Cin_pad * ntaps * Cout_pad;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int k = idx % 16;
+    size_t t = idx / 16;
+    const int co = t % Cout_pad; t /= Cout_pad;
+    const int tap = t % ntaps;
+    const int chunk = t / ntaps;
+    const int ci = chunk * 16 + k - ci_off;
+    const int o = pack_src_row(co, O, co_off, geglu);
+    if (o < 0) continue;
+    float v = 0.0f;
+    if (ci >= 0 && ci < I) v = w[((size_t)o * I + ci) * ntaps + tap];
+    wp[idx] = (half_t)v;
+  }
+}
+
+__global__ void pack_bias_kernel(const float* __restrict__ b, float* __restrict__ bp, int O, int Cout_pad, int co_off, int geglu) {
+  const int co = blockIdx.x * blockDim.x + threadIdx.x;
+  if (co >= Cout_pad) return;
+  const int o = pack_src_row(co, O, co_off, geglu);
+  if (o >= 0) bp[co] = b[o];
+}

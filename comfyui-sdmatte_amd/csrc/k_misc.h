@@ -1,0 +1,147 @@
+// k_misc.h - pre/post-processing and glue kernels of the SDMatte path (all HBM-bound, tiny).
+//
+//  * resize_aa_sample(): torchvision Resize on tensors = F.interpolate(bilinear, align_corners=False,
+//    antialias=True) (sdmatte_nodes.py:204-214,362).  Separable triangle filter with
+//    support = max(scale,1), normalised weights - the ATen `_upsample_bilinear2d_aa` recipe.
+//  * prep_image_kernel / prep_trimap_kernel: sdmatte_nodes.py:339-353 (BHWC -> resize -> (x-0.5)/0.5;
+//    trimap -> resize -> *2-1, `repeat(1,3,1,1)` of meta_arch.py:141) into the engine's NHWC16 fp16 layout.
+//  * mask_bias_kernel: meta_arch.py:200-204 + replace.py:401-403 + replace.py:56-63: level-k additive key
+//    bias = (1 - m[2^k*8 i, 2^k*8 j]) * -10000 (times log2e for the 2^x softmax).
+//  * alpha_out_kernel: meta_arch.py:258-260 (mean over the 3 decoded channels, clip(-1,1), (x+1)/2).
+//  * resize_planes_kernel: sdmatte_nodes.py:362-363 (resize to (H,W), clamp(0,1)).
+#pragma once
+#include "sdm_common.h"
+
+// Weighted antialiased bilinear sample of a single-channel strided plane.
+template <typename F>
+SDM_DEV_INLINE float resize_aa_sample(F fetch, int in_h, int in_w, int out_h, int out_w, int oy, int ox) {
+  const float sy = (float)in_h / (float)out_h, sx = (float)in_w / (float)out_w;
+  const float supy = sy >= 1.0f ? sy : 1.0f, supx = sx >= 1.0f ? sx : 1.0f;
+  const float invy = sy >= 1.0f ? 1.0f / sy : 1.0f, invx = sx >= 1.0f ? 1.0f / sx : 1.0f;
+  const float cy = sy * ((float)oy + 0.5f), cx = sx * ((float)ox + 0.5f);
+  int ymin = (int)(cy - supy + 0.5f); if (ymin < 0) ymin = 0;
+  int ymax = (int)(cy + supy + 0.5f); if (ymax > in_h) ymax = in_h;
+  int xmin = (int)(cx - supx + 0.5f); if (xmin < 0) xmin = 0;
+  int xmax = (int)(cx + supx + 0.5f); if (xmax > in_w) xmax = in_w;
+  float wys = 0.0f, wxs = 0.0f;
+  for (int y = ymin; y < ymax; ++y) { float w = 1.0f - fabsf(((float)y - cy + 0.5f) * invy); wys += w > 0.0f ? w : 0.0f; }
+  for (int x = xmin; x < xmax; ++x) { float w = 1.0f - fabsf(((float)x - cx + 0.5f) * invx); wxs += w > 0.0f ? w : 0.0f; }
+  float acc = 0.0f;
+  for (int y = ymin; y < ymax; ++y) {
+    float wy = 1.0f - fabsf(((float)y - cy + 0.5f) * invy); wy = wy > 0.0f ? wy / wys : 0.0f;
+    float row = 0.0f;
+    for (int x = xmin; x < xmax; ++x) {
+      float wx = 1.0f - fabsf(((float)x - cx + 0.5f) * invx); wx = wx > 0.0f ? wx / wxs : 0.0f;
+      row += wx * fetch(y, x);
+    }
+    acc += wy * row;
+  }
+  return acc;
+}
+
+// image fp32 [B,H,W,3] in [0,1] -> NHWC16 fp16 [B,S,S,16]: ch0..2 = (resize(x)-0.5)/0.5, ch3..15 = 0
+__global__ void prep_image_kernel(const float* __restrict__ img, half_t* __restrict__ out, int B, int H, int W, int S) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * S * S) return;
+  const int ox = i % S, oy = (i / S) % S, b = i / ((long)S * S);
+  float v[3];
+  for (int c = 0; c < 3; ++c) {
+    const float* pl = img + (size_t)b * H * W * 3 + c;
+    float x;
+    if (H == S && W == S) x = pl[((size_t)oy * W + ox) * 3];
+    else x = resize_aa_sample([&](int y, int xx) { return pl[((size_t)y * W + xx) * 3]; }, H, W, S, S, oy, ox);
+    v[c] = (x - 0.5f) / 0.5f;
+  }
+  f16x8 a, z;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { a[e] = (half_t)0.0f; z[e] = (half_t)0.0f; }
+  a[0] = (half_t)v[0]; a[1] = (half_t)v[1]; a[2] = (half_t)v[2];
+  *(f16x8*)(out + (size_t)i * 16) = a;
+  *(f16x8*)(out + (size_t)i * 16 + 8) = z;
+}
+
+// trimap fp32 [B,H,W] in [0,1] -> t = resize(x)*2-1: NHWC16 fp16 (ch0..2 = t) and fp32 plane [B,S,S]
+__global__ void prep_trimap_kernel(const float* __restrict__ tri, half_t* __restrict__ out, float* __restrict__ plane, int B, int H,
+                                   int W, int S) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * S * S) return;
+  const int ox = i % S, oy = (i / S) % S, b = i / ((long)S * S);
+  const float* pl = tri + (size_t)b * H * W;
+  float x;
+  if (H == S && W == S) x = pl[(size_t)oy * W + ox];
+  else x = resize_aa_sample([&](int y, int xx) { return pl[(size_t)y * W + xx]; }, H, W, S, S, oy, ox);
+  const float t = x * 2.0f - 1.0f;
+  plane[i] = t;
+  f16x8 a, z;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { a[e] = (half_t)0.0f; z[e] = (half_t)0.0f; }
+  a[0] = (half_t)t; a[1] = (half_t)t; a[2] = (half_t)t;
+  *(f16x8*)(out + (size_t)i * 16) = a;
+  *(f16x8*)(out + (size_t)i * 16 + 8) = z;
+}
+
+// already pre-processed core-API inputs: image fp32 NCHW [B,3,S,S], trimap fp32 [B,1,S,S] (in [-1,1])
+__global__ void prep_nchw_kernel(const float* __restrict__ img, const float* __restrict__ tri, half_t* __restrict__ out_img,
+                                 half_t* __restrict__ out_tri, float* __restrict__ plane, int B, int S) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long hw = (long)S * S;
+  if (i >= B * hw) return;
+  const long b = i / hw, pq = i % hw;
+  f16x8 a, t, z;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { a[e] = (half_t)0.0f; t[e] = (half_t)0.0f; z[e] = (half_t)0.0f; }
+  for (int c = 0; c < 3; ++c) a[c] = (half_t)img[(b * 3 + c) * hw + pq];
+  const float tv = tri[b * hw + pq];
+  t[0] = (half_t)tv; t[1] = (half_t)tv; t[2] = (half_t)tv;
+  plane[i] = tv;
+  *(f16x8*)(out_img + (size_t)i * 16) = a;
+  *(f16x8*)(out_img + (size_t)i * 16 + 8) = z;
+  *(f16x8*)(out_tri + (size_t)i * 16) = t;
+  *(f16x8*)(out_tri + (size_t)i * 16 + 8) = z;
+}
+
+// bias[level][b][i*lk + j] = (1 - (t[b][8*s*i][8*s*j] + 1)/2) * mask_value * log2e, s = 2^level, lk = l >> level
+__global__ void mask_bias_kernel(const float* __restrict__ plane, float* __restrict__ bias, int B, int S, int level, float mask_value,
+                                 float mult) {
+  const int l = S / 8, lk = l >> level, s = 1 << level;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * lk * lk) return;
+  const int j = i % lk, ii = (i / lk) % lk, b = i / ((long)lk * lk);
+  const float t = plane[((size_t)b * S + (size_t)8 * s * ii) * S + 8 * s * j];
+  const float m = (t + 1.0f) / 2.0f;
+  bias[i] = ((1.0f - m) * mask_value) * mult;
+}
+
+// decoded fp32 [B,S,S,4] (3 real channels) -> alpha fp32 [B,S,S] = (clip(mean3,-1,1)+1)/2
+__global__ void alpha_out_kernel(const float* __restrict__ dec, float* __restrict__ alpha, long npix) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix) return;
+  const f32x4 d = *(const f32x4*)(dec + (size_t)i * 4);
+  float m = (d[0] + d[1] + d[2]) / 3.0f;
+  m = fminf(fmaxf(m, -1.0f), 1.0f);
+  alpha[i] = (m + 1.0f) / 2.0f;
+}
+
+// fp32 planes [P,Hin,Win] -> antialiased bilinear resize to [P,Hout,Wout], optional clamp(0,1)
+// (post-processing of sdmatte_nodes.py:362-363 uses P = B, clamp = 1)
+__global__ void resize_planes_kernel(const float* __restrict__ in, float* __restrict__ out, int P, int Hin, int Win, int Hout,
+                                     int Wout, int clamp01) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)P * Hout * Wout) return;
+  const int ox = i % Wout, oy = (i / Wout) % Hout, b = i / ((long)Hout * Wout);
+  const float* pl = in + (size_t)b * Hin * Win;
+  float x;
+  if (Hin == Hout && Win == Wout) x = pl[(size_t)oy * Win + ox];
+  else x = resize_aa_sample([&](int y, int xx) { return pl[(size_t)y * Win + xx]; }, Hin, Win, Hout, Wout, oy, ox);
+  if (clamp01) x = fminf(fmaxf(x, 0.0f), 1.0f);
+  out[i] = x;
+}
+
+__global__ void scale_copy_kernel(const float* __restrict__ in, float* __restrict__ out, long n, float mult) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i] * mult;
+}
+
+__global__ void fill_zero_kernel(uint32_t* __restrict__ p, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = 0u;
+}

@@ -1,0 +1,149 @@
+// k_norm.h - GroupNorm(32) statistics / apply(+SiLU) and LayerNorm for NHWC tensors (HBM-bound).
+//
+// Reference semantics: F.group_norm(x, 32, gamma, beta, eps) [+ F.silu] inside diffusers
+// ResnetBlock2D / Transformer2DModel / VAE Attention / conv_norm_out (SURVEY.md Appendix A.3,A.5-A.7;
+// eps 1e-6 VAE + Transformer2D, 1e-5 U-Net ResBlocks), and F.layer_norm(eps 1e-5) x3 per
+// BasicTransformerBlock.  Statistics are per (image, group) over (C/32 channels x H*W pixels), biased
+// variance, computed in fp32 per thread, fp32 LDS atomics per block and fp64 global atomics across
+// blocks; the affine transform is applied in fp32 and rounded once to fp16 (the MFMA operand type).
+//
+// Work decomposition (both kernels): a thread owns ONE fixed 8-channel vector (16 B fp16 / 32 B fp32)
+// and strides over pixels, so gamma/beta/scale/shift live in registers and all global accesses are
+// 16-B vectors, consecutive threads -> consecutive channel vectors -> fully coalesced rows.
+#pragma once
+#include "sdm_common.h"
+
+struct GnSrc {
+  const void* in0; const void* in1;  // channel concat (in1 may be null)
+  int C0, C1; int in_f32;
+  int HW;                            // pixels per image
+};
+
+// sums[n][g][2] (double) += {sum x, sum x^2}
+__global__ void __launch_bounds__(512) gn_stats_kernel(GnSrc s, double* __restrict__ sums, int groups, int pix_per_block) {
+  SDM_DYN_SMEM(smem);
+  const int C = s.C0 + s.C1;
+  float* lsum = (float*)smem;      // [C]
+  float* lsq = lsum + C;           // [C]
+  const int CV = C / 8;
+  const int slots = blockDim.x / CV;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 2 * C; i += blockDim.x) lsum[i] = 0.0f;
+  __syncthreads();
+  const int n = blockIdx.y;
+  const int cv = tid % CV, slot = tid / CV;
+  if (slot < slots) {
+    const int c = cv * 8;
+    const void* src = s.in0; int Cs = s.C0, cc = c;
+    if (c >= s.C0) { src = s.in1; Cs = s.C1; cc = c - s.C0; }
+    float a[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a[e] = 0.0f; q[e] = 0.0f; }
+    const int p0 = blockIdx.x * pix_per_block;
+    const int p1 = min(p0 + pix_per_block, s.HW);
+    for (int p = p0 + slot; p < p1; p += slots) {
+      float v[8];
+      sdm_load8_as_f32(src, ((size_t)n * s.HW + p) * Cs + cc, s.in_f32, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { a[e] += v[e]; q[e] += v[e] * v[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { atomicAdd(&lsum[c + e], a[e]); atomicAdd(&lsq[c + e], q[e]); }
+  }
+  __syncthreads();
+  const int cpg = C / groups;
+  if (tid < groups) {
+    double ss = 0.0, qq = 0.0;
+    for (int j = 0; j < cpg; ++j) { ss += (double)lsum[tid * cpg + j]; qq += (double)lsq[tid * cpg + j]; }
+    atomicAdd(&sums[((size_t)n * groups + tid) * 2 + 0], ss);
+    atomicAdd(&sums[((size_t)n * groups + tid) * 2 + 1], qq);
+  }
+}
+
+// scale[n][c] = rstd*gamma, shift[n][c] = beta - mean*rstd*gamma
+__global__ void gn_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift,
+                                   int N, int C, int groups, long count, float eps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * C) return;
+  const int n = i / C, c = i % C, g = c / (C / groups);
+  const double mean = sums[((size_t)n * groups + g) * 2] / (double)count;
+  double var = sums[((size_t)n * groups + g) * 2 + 1] / (double)count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float a = rstd * gamma[c];
+  scale[i] = a;
+  shift[i] = beta[c] - (float)mean * a;
+}
+
+// y = act(x*scale + shift) -> fp16 NHWC with C channels (concat materialised)
+__global__ void __launch_bounds__(512) gn_apply_kernel(GnSrc s, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       half_t* __restrict__ out, int silu, int pix_per_block) {
+  const int C = s.C0 + s.C1;
+  const int CV = C / 8;
+  const int slots = blockDim.x / CV;
+  const int tid = threadIdx.x;
+  const int n = blockIdx.y;
+  const int cv = tid % CV, slot = tid / CV;
+  if (slot >= slots) return;
+  const int c = cv * 8;
+  const void* src = s.in0; int Cs = s.C0, cc = c;
+  if (c >= s.C0) { src = s.in1; Cs = s.C1; cc = c - s.C0; }
+  float a[8], b[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { a[e] = scale[(size_t)n * C + c + e]; b[e] = shift[(size_t)n * C + c + e]; }
+  const int p0 = blockIdx.x * pix_per_block;
+  const int p1 = min(p0 + pix_per_block, s.HW);
+  for (int p = p0 + slot; p < p1; p += slots) {
+    float v[8];
+    sdm_load8_as_f32(src, ((size_t)n * s.HW + p) * Cs + cc, s.in_f32, v);
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float y = v[e] * a[e] + b[e];
+      if (silu) y = sdm_silu(y);
+      o[e] = (half_t)y;
+    }
+    *(f16x8*)(out + ((size_t)n * s.HW + p) * C + c) = o;
+  }
+}
+
+// LayerNorm over the last dim C (multiple of 64, <= 64*LN_MAXV), one wave per row, fp32/fp16 in -> fp16 out.
+#define SDM_LN_MAXV 20
+__global__ void __launch_bounds__(256) layernorm_kernel(const void* __restrict__ x, int in_f32, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, half_t* __restrict__ out, long rows, int C,
+                                                        float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long row = (long)blockIdx.x * (blockDim.x >> 6) + wave;
+  const bool active = row < rows;
+  const long rr = active ? row : rows - 1;     // keep every lane in the shuffles
+  const int nv = C / 64;
+  float v[SDM_LN_MAXV];
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < SDM_LN_MAXV; ++i) {
+    if (i < nv) {
+      const size_t idx = (size_t)rr * C + i * 64 + lane;
+      v[i] = in_f32 ? ((const float*)x)[idx] : (float)((const half_t*)x)[idx];
+      s += v[i];
+    }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+  const float mean = s / (float)C;
+  float q = 0.0f;
+#pragma unroll
+  for (int i = 0; i < SDM_LN_MAXV; ++i)
+    if (i < nv) { const float d = v[i] - mean; q += d * d; }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) q += __shfl_xor(q, m);
+  const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+  if (!active) return;
+#pragma unroll
+  for (int i = 0; i < SDM_LN_MAXV; ++i) {
+    if (i < nv) {
+      const int c = i * 64 + lane;
+      out[(size_t)row * C + c] = (half_t)((v[i] - mean) * rstd * gamma[c] + beta[c]);
+    }
+  }
+}

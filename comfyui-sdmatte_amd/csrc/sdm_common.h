@@ -1,0 +1,80 @@
+// sdm_common.h - shared device/host helpers for the SDMatte gfx950 engine.
+//
+// The product build is `hipcc --offload-arch=gfx950` only.  When SDM_EMU is defined (tests/emu
+// only) the same sources compile for the host against tests/emu/hip_emu.h so that index math can
+// be debugged without a GPU; that build is never shipped or loaded by the package.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#ifdef SDM_EMU
+#include "hip_emu.h"
+#else
+#include <hip/hip_runtime.h>
+#endif
+
+typedef _Float16 half_t;
+typedef half_t f16x8 __attribute__((ext_vector_type(8)));
+typedef half_t f16x4 __attribute__((ext_vector_type(4)));
+typedef half_t f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#ifdef SDM_EMU
+#define SDM_DYN_SMEM(name) unsigned char* name = emu::g_dyn_smem
+#define SDM_SHARED static thread_local
+#define SDM_MFMA_32x32x16_F16(a, b, c) emu_mfma_f32_32x32x16_f16((a), (b), (c))
+#define SDM_LAUNCH(kernel, grid, block, smem, stream, ...) \
+  emu::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); })
+#define SDM_DEV_INLINE static inline
+static inline float sdm_exp2(float x) { return exp2f(x); }
+static inline float sdm_rcp(float x) { return 1.0f / x; }
+#else
+#define SDM_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#define SDM_SHARED __shared__
+#define SDM_MFMA_32x32x16_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+#define SDM_LAUNCH(kernel, grid, block, smem, stream, ...) \
+  hipLaunchKernelGGL(kernel, (grid), (block), (smem), (hipStream_t)(stream), __VA_ARGS__)
+#define SDM_DEV_INLINE __device__ __forceinline__
+__device__ __forceinline__ float sdm_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float sdm_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#endif
+
+#define SDM_LOG2E 1.4426950408889634f
+
+SDM_DEV_INLINE float sdm_silu(float x) {
+  // x * sigmoid(x) = x / (1 + 2^(-x*log2e))
+  return x / (1.0f + sdm_exp2(-x * SDM_LOG2E));
+}
+
+SDM_DEV_INLINE float sdm_gelu_erf(float x) {
+  // exact GELU (diffusers GEGLU uses F.gelu default, approximate='none')
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+}
+
+// 8 consecutive channels from an fp16 or fp32 tensor -> f16x8 (the MFMA operand type)
+SDM_DEV_INLINE f16x8 sdm_load8_as_f16(const void* base, size_t elem_index, int is_f32) {
+  if (is_f32) {
+    const f32x4* p = (const f32x4*)((const float*)base + elem_index);
+    f32x4 a = p[0], b = p[1];
+    f16x8 r;
+    r[0] = (half_t)a[0]; r[1] = (half_t)a[1]; r[2] = (half_t)a[2]; r[3] = (half_t)a[3];
+    r[4] = (half_t)b[0]; r[5] = (half_t)b[1]; r[6] = (half_t)b[2]; r[7] = (half_t)b[3];
+    return r;
+  }
+  return *(const f16x8*)((const half_t*)base + elem_index);
+}
+
+// 8 consecutive channels -> 8 floats
+SDM_DEV_INLINE void sdm_load8_as_f32(const void* base, size_t elem_index, int is_f32, float (&v)[8]) {
+  if (is_f32) {
+    const f32x4* p = (const f32x4*)((const float*)base + elem_index);
+    f32x4 a = p[0], b = p[1];
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+  } else {
+    f16x8 h = *(const f16x8*)((const half_t*)base + elem_index);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)h[i];
+  }
+}
+
+static inline int sdm_cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,304 @@
+"""ctypes binding of the C ABI in include/sdmatte.h (libsdmatte_hip.so, hipcc/gfx950).
+
+This is the only bridge between the Python host code (node, model-load API) and the hand-written HIP
+kernels.  There is NO fallback: if the shared library is missing or no MI355X-class GPU is visible,
+`load_library()` / `Engine()` raise.  PyTorch tensors are used only as device/host memory holders at the
+node boundary (`tensor.data_ptr()`).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from .config import SDMatteConfig
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsdmatte_hip.so")
+
+SDM_PTR_HOST, SDM_PTR_DEVICE = 0, 1
+SDM_F32, SDM_F16, SDM_BF16 = 0, 1, 2
+_DT = {torch.float32: SDM_F32, torch.float16: SDM_F16, torch.bfloat16: SDM_BF16}
+
+
+class SdmConfig(C.Structure):
+    _fields_ = [
+        ("vae_channels", C.c_int32 * 4), ("vae_layers_per_block", C.c_int32),
+        ("unet_channels", C.c_int32 * 4), ("unet_heads", C.c_int32 * 4), ("unet_layers_per_block", C.c_int32),
+        ("cross_attention_dim", C.c_int32), ("unet_in_channels", C.c_int32), ("unet_out_channels", C.c_int32),
+        ("bbox_embeddings_input_dim", C.c_int32), ("groups", C.c_int32),
+        ("vae_eps", C.c_float), ("unet_res_eps", C.c_float), ("unet_tf_gn_eps", C.c_float), ("unet_ln_eps", C.c_float),
+        ("vae_scaling_factor", C.c_float), ("attn_mask_value", C.c_float),
+        ("stream_f32", C.c_int32), ("reserved", C.c_int32 * 7),
+    ]
+
+
+def to_c_config(cfg: SDMatteConfig, stream_f32: bool = True) -> SdmConfig:
+    c = SdmConfig()
+    for i in range(4):
+        c.vae_channels[i] = cfg.vae_channels[i]
+        c.unet_channels[i] = cfg.unet_channels[i]
+        c.unet_heads[i] = cfg.unet_heads[i]
+    c.vae_layers_per_block = cfg.vae_layers_per_block
+    c.unet_layers_per_block = cfg.unet_layers_per_block
+    c.cross_attention_dim = cfg.cross_attention_dim
+    c.unet_in_channels = cfg.unet_in_channels
+    c.unet_out_channels = cfg.unet_out_channels
+    c.bbox_embeddings_input_dim = cfg.bbox_embeddings_input_dim
+    c.groups = cfg.unet_groups
+    c.vae_eps, c.unet_res_eps = cfg.vae_eps, cfg.unet_res_eps
+    c.unet_tf_gn_eps, c.unet_ln_eps = cfg.unet_tf_gn_eps, cfg.unet_ln_eps
+    c.vae_scaling_factor, c.attn_mask_value = cfg.vae_scaling_factor, cfg.attn_mask_value
+    c.stream_f32 = 1 if stream_f32 else 0
+    return c
+
+
+EXPORTS = [
+    "sdm_default_config", "sdm_create", "sdm_destroy", "sdm_last_error", "sdm_load_tensor", "sdm_finalize_weights",
+    "sdm_weight_stats", "sdm_missing_key", "sdm_weight_blob_bytes", "sdm_export_weight_blob", "sdm_import_weight_blob",
+    "sdm_host_blob_bytes", "sdm_export_host_blob", "sdm_import_host_blob", "sdm_forward", "sdm_apply_matte",
+    "sdm_synchronize", "sdm_last_forward_ms", "sdm_profile_enable", "sdm_profile_count", "sdm_profile_get",
+    "sdm_op_conv", "sdm_conv_num_cfgs", "sdm_op_groupnorm", "sdm_op_layernorm", "sdm_op_attention", "sdm_op_resize_aa",
+    "sdm_op_mask_bias",
+]
+
+
+class Bindings:
+    """Typed view of an already dlopen()ed engine library."""
+
+    def __init__(self, cdll):
+        self.dll = cdll
+        vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+        sig = {
+            "sdm_default_config": (None, [C.POINTER(SdmConfig)]),
+            "sdm_create": (i32, [C.POINTER(vp), i32, C.POINTER(SdmConfig)]),
+            "sdm_destroy": (None, [vp]),
+            "sdm_last_error": (C.c_char_p, [vp]),
+            "sdm_load_tensor": (i32, [vp, C.c_char_p, i32, i32, C.POINTER(i64), vp]),
+            "sdm_finalize_weights": (i32, [vp]),
+            "sdm_weight_stats": (i32, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
+            "sdm_missing_key": (C.c_char_p, [vp, i64]),
+            "sdm_weight_blob_bytes": (i64, [vp]),
+            "sdm_export_weight_blob": (i32, [vp, vp]),
+            "sdm_import_weight_blob": (i32, [vp, vp]),
+            "sdm_host_blob_bytes": (i64, [vp]),
+            "sdm_export_host_blob": (i32, [vp, vp]),
+            "sdm_import_host_blob": (i32, [vp, vp]),
+            "sdm_forward": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, i32, vp]),
+            "sdm_apply_matte": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, vp]),
+            "sdm_synchronize": (i32, [vp]),
+            "sdm_last_forward_ms": (f32, [vp]),
+            "sdm_profile_enable": (i32, [vp, i32]),
+            "sdm_profile_count": (i32, [vp]),
+            "sdm_profile_get": (i32, [vp, i32, C.POINTER(C.c_char_p), C.POINTER(f32), C.POINTER(i64), C.POINTER(C.c_double),
+                                      C.POINTER(C.c_double)]),
+            "sdm_op_conv": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, i32,
+                                  f32, i32]),
+            "sdm_conv_num_cfgs": (i32, [i32, i32]),
+            "sdm_op_groupnorm": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, f32, i32, vp]),
+            "sdm_op_layernorm": (i32, [vp, vp, i32, C.c_long, i32, vp, vp, f32, vp]),
+            "sdm_op_attention": (i32, [vp, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32]),
+            "sdm_op_resize_aa": (i32, [vp, vp, i32, i32, i32, vp, i32, i32]),
+            "sdm_op_mask_bias": (i32, [vp, vp, i32, i32, i32, vp]),
+        }
+        for name in EXPORTS:
+            fn = getattr(cdll, name)          # AttributeError = missing export: fail loudly
+            fn.restype, fn.argtypes = sig[name]
+            setattr(self, name, fn)
+
+
+_PRODUCT = None
+
+
+def load_library() -> Bindings:
+    """dlopen the gfx950 engine.  Raises if it has not been built (`python -m ... build` / __graft_entry__.build())."""
+    global _PRODUCT
+    if _PRODUCT is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"SDMatte HIP engine not built: {LIB_PATH} is missing (run __graft_entry__.build()); "
+                               "there is no CPU fallback")
+        _PRODUCT = Bindings(C.CDLL(LIB_PATH))
+    return _PRODUCT
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class Engine:
+    """One engine per GPU (one process per GPU under torch.distributed, or one per device inside ComfyUI)."""
+
+    def __init__(self, cfg: SDMatteConfig = None, device: int = 0, stream_f32: bool = True, _lib: Bindings = None):
+        self.lib = _lib or load_library()
+        self.cfg = cfg or SDMatteConfig.full()
+        self.device = device
+        self._ccfg = to_c_config(self.cfg, stream_f32)
+        h = C.c_void_p()
+        rc = self.lib.sdm_create(C.byref(h), device, C.byref(self._ccfg))
+        if rc != 0:
+            raise RuntimeError(f"sdm_create failed ({rc}): {self.lib.sdm_last_error(None).decode()}")
+        self.h = h
+        self._on_device = _lib is None       # emulator builds (tests) address host memory
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.sdm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise RuntimeError(f"{what} failed ({rc}): {self.lib.sdm_last_error(self.h).decode()}")
+        return rc
+
+    # ---- weights -------------------------------------------------------------------------------
+    def load_state_dict(self, state_dict, strict: bool = False):
+        """Mirror of `load_state_dict(sd, strict=False)` (sdmatte_nodes.py:321): unknown keys are ignored,
+        shape mismatches raise.  Returns (missing_keys, n_ignored)."""
+        for k, t in state_dict.items():
+            if not torch.is_tensor(t):
+                continue
+            t = t.detach()
+            if t.device.type != "cpu":
+                t = t.cpu()
+            if t.dtype not in _DT:
+                t = t.float()
+            t = t.contiguous()
+            shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
+            self._check(self.lib.sdm_load_tensor(self.h, k.encode(), _DT[t.dtype], t.dim(), shape, _ptr(t)), f"load {k}")
+        self._check(self.lib.sdm_finalize_weights(self.h), "finalize")
+        nl, nm, ni = C.c_int64(), C.c_int64(), C.c_int64()
+        self.lib.sdm_weight_stats(self.h, C.byref(nl), C.byref(nm), C.byref(ni))
+        missing = [self.lib.sdm_missing_key(self.h, i).decode() for i in range(nm.value)]
+        if strict and missing:
+            raise RuntimeError(f"missing keys: {missing[:8]}...")
+        return missing, ni.value
+
+    def weight_blob_bytes(self):
+        return int(self.lib.sdm_weight_blob_bytes(self.h))
+
+    def export_weights(self, device_u8: torch.Tensor, host_u8: torch.Tensor):
+        self._check(self.lib.sdm_export_weight_blob(self.h, _ptr(device_u8)), "export blob")
+        self._check(self.lib.sdm_export_host_blob(self.h, _ptr(host_u8)), "export host blob")
+
+    def import_weights(self, device_u8: torch.Tensor, host_u8: torch.Tensor):
+        self._check(self.lib.sdm_import_weight_blob(self.h, _ptr(device_u8)), "import blob")
+        self._check(self.lib.sdm_import_host_blob(self.h, _ptr(host_u8)), "import host blob")
+        self._check(self.lib.sdm_finalize_weights(self.h), "finalize")
+
+    def host_blob_bytes(self):
+        return int(self.lib.sdm_host_blob_bytes(self.h))
+
+    # ---- forward -------------------------------------------------------------------------------
+    def _kind(self, t):
+        return SDM_PTR_DEVICE if (t.device.type == "cuda") else (SDM_PTR_DEVICE if not self._on_device else SDM_PTR_HOST)
+
+    def forward(self, image_b3ss: torch.Tensor, trimap_b1ss: torch.Tensor, is_trans=None, coords=None, out=None, sync=True):
+        """SDMatte.forward(data): image [B,3,S,S] in [-1,1], trimap [B,1,S,S] in [-1,1] -> alpha [B,1,S,S]."""
+        B, _, S, _ = image_b3ss.shape
+        image_b3ss = image_b3ss.float().contiguous()
+        trimap_b1ss = trimap_b1ss.float().contiguous()
+        if out is None:
+            out = torch.empty(B, 1, S, S, dtype=torch.float32, device=image_b3ss.device)
+        it = np.ascontiguousarray(np.zeros(B, np.int32) if is_trans is None else np.asarray(is_trans, np.int32).reshape(B))
+        co = None if coords is None else np.ascontiguousarray(np.asarray(coords, np.float32).reshape(B, 4))
+        self._check(self.lib.sdm_forward(self.h, _ptr(image_b3ss), _ptr(trimap_b1ss), B, S, it.ctypes.data_as(C.c_void_p),
+                                         co.ctypes.data_as(C.c_void_p) if co is not None else None, _ptr(out),
+                                         self._kind(image_b3ss), None), "sdm_forward")
+        if sync:
+            self.synchronize()
+        return out
+
+    def apply_matte(self, image_bhwc: torch.Tensor, trimap_bhw: torch.Tensor, S: int, is_transparent=False, out=None, sync=True):
+        """Device part of SDMatteApply.apply_matte: raw image [B,H,W,3] + trimap [B,H,W] in [0,1] -> alpha [B,H,W]."""
+        B, H, W, _ = image_bhwc.shape
+        image_bhwc = image_bhwc.float().contiguous()
+        trimap_bhw = trimap_bhw.float().contiguous()
+        if out is None:
+            out = torch.empty(B, H, W, dtype=torch.float32, device=image_bhwc.device)
+        self._check(self.lib.sdm_apply_matte(self.h, _ptr(image_bhwc), _ptr(trimap_bhw), B, H, W, int(S), 1 if is_transparent else 0,
+                                             _ptr(out), self._kind(image_bhwc), None), "sdm_apply_matte")
+        if sync:
+            self.synchronize()
+        return out
+
+    def synchronize(self):
+        self._check(self.lib.sdm_synchronize(self.h), "sdm_synchronize")
+
+    def last_forward_ms(self):
+        return float(self.lib.sdm_last_forward_ms(self.h))
+
+    def profile(self, on: bool):
+        self.lib.sdm_profile_enable(self.h, 1 if on else 0)
+
+    def profile_results(self):
+        res = {}
+        for i in range(self.lib.sdm_profile_count(self.h)):
+            name, ms, n, fl, by = C.c_char_p(), C.c_float(), C.c_int64(), C.c_double(), C.c_double()
+            self.lib.sdm_profile_get(self.h, i, C.byref(name), C.byref(ms), C.byref(n), C.byref(fl), C.byref(by))
+            res[name.value.decode()] = {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
+        return res
+
+    # ---- single operators (parity tests) ---------------------------------------------------------
+    def op_conv(self, x0, w, bias=None, x1=None, stride=1, pad_mode=0, up=0, res=None, geglu=False, out_f32=False, out_scale=1.0,
+                tile_cfg=-1):
+        """x0/x1: NHWC fp16|fp32 tensors; w: fp32 OIHW or [O,I]; returns NHWC."""
+        N, H, W_, C0 = x0.shape
+        C1 = x1.shape[-1] if x1 is not None else 0
+        ntaps = 9 if (w.dim() == 4 and w.shape[-1] == 3) else 1
+        O = w.shape[0]
+        Ho, Wo = (H << up), (W_ << up)
+        if stride == 2:
+            Ho, Wo = Ho // 2, Wo // 2
+        Cst = O // 2 if geglu else O
+        out = torch.empty(N, Ho, Wo, Cst, dtype=torch.float32 if out_f32 else torch.float16, device=x0.device)
+        w = w.float().contiguous()
+        b = bias.float().contiguous() if bias is not None else None
+        self._check(self.lib.sdm_op_conv(self.h, _ptr(x0), _ptr(x1), C0, C1, int(x0.dtype == torch.float32), N, H, W_, up, stride,
+                                         pad_mode, ntaps, _ptr(w), _ptr(b), O, _ptr(out), int(out_f32), _ptr(res),
+                                         int(res is not None and res.dtype == torch.float32), int(geglu), float(out_scale), tile_cfg),
+                    "sdm_op_conv")
+        return out
+
+    def op_groupnorm(self, x0, gamma, beta, eps, silu, groups=32, x1=None):
+        N, H, W_, C0 = x0.shape
+        C1 = x1.shape[-1] if x1 is not None else 0
+        out = torch.empty(N, H, W_, C0 + C1, dtype=torch.float16, device=x0.device)
+        self._check(self.lib.sdm_op_groupnorm(self.h, _ptr(x0), _ptr(x1), C0, C1, int(x0.dtype == torch.float32), N, H * W_, groups,
+                                              _ptr(gamma), _ptr(beta), float(eps), int(silu), _ptr(out)), "sdm_op_groupnorm")
+        return out
+
+    def op_layernorm(self, x, gamma, beta, eps):
+        rows, Cc = x.numel() // x.shape[-1], x.shape[-1]
+        out = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+        self._check(self.lib.sdm_op_layernorm(self.h, _ptr(x), int(x.dtype == torch.float32), rows, Cc, _ptr(gamma), _ptr(beta),
+                                              float(eps), _ptr(out)), "sdm_op_layernorm")
+        return out
+
+    def op_attention(self, q, k, v, heads, bias=None):
+        """q [B,Lq,h*D], k/v [B,Lk,h*D] fp16 (may be views with a row stride); bias fp32 [B,Lk] or None."""
+        B, Lq, HD = q.shape
+        Lk = k.shape[1]
+        D = HD // heads
+        out = torch.empty(B, Lq, HD, dtype=torch.float16, device=q.device)
+        self._check(self.lib.sdm_op_attention(self.h, _ptr(q), q.stride(1), _ptr(k), k.stride(1), _ptr(v), v.stride(1), _ptr(bias), B,
+                                              heads, Lq, Lk, D, _ptr(out), HD), "sdm_op_attention")
+        return out
+
+    def op_resize_aa(self, planes, Hout, Wout):
+        P, Hin, Win = planes.shape
+        out = torch.empty(P, Hout, Wout, dtype=torch.float32, device=planes.device)
+        self._check(self.lib.sdm_op_resize_aa(self.h, _ptr(planes), P, Hin, Win, _ptr(out), Hout, Wout), "sdm_op_resize_aa")
+        return out
+
+    def op_mask_bias(self, plane_bss, level):
+        B, S, _ = plane_bss.shape
+        lk = (S // 8) >> level
+        out = torch.empty(B, lk * lk, dtype=torch.float32, device=plane_bss.device)
+        self._check(self.lib.sdm_op_mask_bias(self.h, _ptr(plane_bss), B, S, level, _ptr(out)), "sdm_op_mask_bias")
+        return out

@@ -1,0 +1,152 @@
+/* sdmatte.h - C ABI of the MI355X-native SDMatte engine (libsdmatte_hip.so, gfx950 only).
+ *
+ * The reference (flybirdxx/ComfyUI-SDMatte) is pure Python and has no FFI; this header is the boundary a
+ * maintainer binds with ctypes.  Each entry point names the reference interface it
+ * replaces.  Plain pointers and sizes only - no torch types.  All functions return 0 on success or a
+ * negative sdm_status; sdm_last_error() gives the message (the Python shim raises RuntimeError with it,
+ * mirroring how exceptions propagate to ComfyUI in the reference).  Nothing here ever abort()s.
+ *
+ * Pointer kinds: every data pointer is either a HOST pointer or a DEVICE pointer of the engine's GPU,
+ * selected by the `ptr_kind` argument (SDM_PTR_HOST / SDM_PTR_DEVICE).  Device pointers are what
+ * `tensor.data_ptr()` returns for PyTorch-ROCm tensors at the node boundary.
+ */
+#ifndef SDMATTE_H_
+#define SDMATTE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sdm_ctx sdm_ctx;
+
+enum sdm_status {
+  SDM_OK = 0,
+  SDM_ERR_INVALID = -1,   /* bad argument / shape */
+  SDM_ERR_HIP = -2,       /* HIP runtime error */
+  SDM_ERR_STATE = -3,     /* weights not loaded / finalised */
+  SDM_ERR_NOMEM = -4,
+  SDM_ERR_NODEVICE = -5   /* no gfx950 GPU visible: the product never falls back to the CPU */
+};
+
+enum sdm_ptr_kind { SDM_PTR_HOST = 0, SDM_PTR_DEVICE = 1 };
+enum sdm_dtype { SDM_F32 = 0, SDM_F16 = 1, SDM_BF16 = 2 };
+
+/* Architecture constants.  The reference reads them from stable-diffusion-2-1-base/{unet,vae}/config.json
+ * (sdmatte_nodes.py:20-31, meta_arch.py:95-118) plus in-code defaults (meta_arch.py:107-112). */
+typedef struct sdm_config {
+  int32_t vae_channels[4];
+  int32_t vae_layers_per_block;
+  int32_t unet_channels[4];
+  int32_t unet_heads[4];
+  int32_t unet_layers_per_block;
+  int32_t cross_attention_dim;
+  int32_t unet_in_channels;
+  int32_t unet_out_channels;
+  int32_t bbox_embeddings_input_dim;
+  int32_t groups;
+  float vae_eps;
+  float unet_res_eps;
+  float unet_tf_gn_eps;
+  float unet_ln_eps;
+  float vae_scaling_factor;
+  float attn_mask_value;
+  int32_t stream_f32;      /* 1: residual stream tensors kept in fp32 (default), 0: fp16 */
+  int32_t reserved[7];
+} sdm_config;
+
+/* Fill `cfg` with the SD-2.1-base / SDMatte constants. */
+void sdm_default_config(sdm_config* cfg);
+
+/* Create an engine on GPU `device_id`.  Replaces SDMatte.__init__ / init_submodule (meta_arch.py:31-124)
+ * + `.to(device)` (sdmatte_nodes.py:323).  cfg == NULL selects sdm_default_config. */
+int sdm_create(sdm_ctx** out, int device_id, const sdm_config* cfg);
+void sdm_destroy(sdm_ctx* ctx);
+const char* sdm_last_error(sdm_ctx* ctx);   /* ctx may be NULL: returns the last create() error */
+
+/* Weight loading.  Replaces the safetensors read loop + load_state_dict(strict=False)
+ * (sdmatte_nodes.py:300-321): call once per checkpoint tensor with its key (e.g.
+ * "unet.down_blocks.0.resnets.0.conv1.weight"), dtype, shape and a HOST pointer (e.g. into the
+ * safetensors mmap).  Unknown keys (text_encoder.*, point_embedding.*) are ignored and reported through
+ * sdm_weight_stats; a shape mismatch is an error, as in torch.  Returns 1 if the key was consumed. */
+int sdm_load_tensor(sdm_ctx* ctx, const char* name, int dtype, int ndim, const int64_t* shape, const void* host_ptr);
+/* After the last tensor: folds constants and marks the engine ready.  n_missing = expected keys never
+ * supplied (they stay zero-initialised; the reference would keep its random init). */
+int sdm_finalize_weights(sdm_ctx* ctx);
+int sdm_weight_stats(sdm_ctx* ctx, int64_t* n_loaded, int64_t* n_missing, int64_t* n_ignored);
+/* Name of the i-th expected-but-missing key, or NULL. */
+const char* sdm_missing_key(sdm_ctx* ctx, int64_t i);
+
+/* Packed fp16 weight blob (for RCCL broadcast between ranks): size, and copy out/in to/from a
+ * DEVICE buffer of that size.  Import marks every key as loaded; sdm_finalize_weights must follow. */
+int64_t sdm_weight_blob_bytes(sdm_ctx* ctx);
+int sdm_export_weight_blob(sdm_ctx* ctx, void* device_dst);
+int sdm_import_weight_blob(sdm_ctx* ctx, const void* device_src);
+/* Small host-side tensors needed for the time/bbox embedding constants (kept outside the blob). */
+int64_t sdm_host_blob_bytes(sdm_ctx* ctx);
+int sdm_export_host_blob(sdm_ctx* ctx, void* host_dst);
+int sdm_import_host_blob(sdm_ctx* ctx, const void* host_src);
+
+/* Model forward.  Replaces SDMatte.forward(data) (meta_arch.py:127-261):
+ *   image  fp32 [B,3,S,S]  = data["image"]   (already resized + normalised to [-1,1])
+ *   trimap fp32 [B,1,S,S]  = data["trimap"]  (in [-1,1])
+ *   is_trans int32 [B]     = data["is_trans"];  coords fp32 [B,4] = data["trimap_coords"] (NULL -> [0,0,1,1])
+ *   alpha  fp32 [B,1,S,S]  = return value in [0,1]
+ * is_trans / coords are always HOST pointers (tiny).  `stream` is a hipStream_t (NULL = engine stream). */
+int sdm_forward(sdm_ctx* ctx, const float* image_b3ss, const float* trimap_b1ss, int B, int S, const int32_t* is_trans,
+                const float* coords_b4, float* alpha_b1ss, int ptr_kind, void* stream);
+
+/* Node-level call.  Replaces the device part of SDMatteApply.apply_matte (sdmatte_nodes.py:339-363):
+ *   image fp32 [B,H,W,3] in [0,1], trimap fp32 [B,H,W] in [0,1]  ->  antialiased resize to SxS, normalise,
+ *   forward, resize back to (H,W), clamp(0,1)  ->  alpha fp32 [B,H,W].
+ * mask_refine / output_mode composition (sdmatte_nodes.py:365-397) stay in the Python node, as in the
+ * reference, where they run on the CPU copy. */
+int sdm_apply_matte(sdm_ctx* ctx, const float* image_bhwc, const float* trimap_bhw, int B, int H, int W, int S,
+                    int is_transparent, float* alpha_bhw, int ptr_kind, void* stream);
+
+/* Block until everything queued on the engine stream has finished. */
+int sdm_synchronize(sdm_ctx* ctx);
+
+/* Time (ms) spent by the GPU in the last sdm_forward/sdm_apply_matte, measured with HIP events on the
+ * stream the kernels were launched on.  Valid after sdm_synchronize. */
+float sdm_last_forward_ms(sdm_ctx* ctx);
+
+/* Per-kernel-class event timing of the next forward (debug/bench): enable, run, then read back
+ * `n` (name, ms, launches) triples.  Adds an event pair per launch - not for the timed bench loop. */
+int sdm_profile_enable(sdm_ctx* ctx, int on);
+int sdm_profile_count(sdm_ctx* ctx);
+int sdm_profile_get(sdm_ctx* ctx, int i, const char** name, float* ms, int64_t* launches, double* flops, double* bytes);
+
+/* ---- single-operator entry points (parity tests call the same kernels the engine uses) --------------
+ * All pointers are DEVICE pointers.  Activations are NHWC; fp16 unless the *_f32 flag says otherwise. */
+
+/* conv3x3 (ntaps=9) or 1x1/linear (ntaps=1): y = conv(concat(in0,in1)) [*scale] [+bias] [+res] | GEGLU.
+ * w: fp32 OIHW [O][I][kh][kw] or [O][I]; I = (C0+C1) real channels.  stride 1|2; pad_mode 0: symmetric pad 1,
+ * 1: VAE asymmetric (0,1,0,1) (stride 2).  up=1 fuses a nearest x2 upsample.  tile_cfg = -1 picks
+ * automatically, >= 0 forces one of the compiled tile configurations (see sdm_conv_num_cfgs). */
+int sdm_op_conv(sdm_ctx* ctx, const void* in0, const void* in1, int C0, int C1, int in_f32, int N, int Hin, int Win, int up,
+                int stride, int pad_mode, int ntaps, const float* w, const float* bias, int O, void* out, int out_f32,
+                const void* res, int res_f32, int geglu, float out_scale, int tile_cfg);
+int sdm_conv_num_cfgs(int ntaps, int stride);
+/* GroupNorm(groups)+optional SiLU over NHWC (concat of two sources) -> fp16 NHWC. */
+int sdm_op_groupnorm(sdm_ctx* ctx, const void* in0, const void* in1, int C0, int C1, int in_f32, int N, int HW, int groups,
+                     const float* gamma, const float* beta, float eps, int silu, void* out_f16);
+/* LayerNorm over the last dim C of [rows, C] -> fp16. */
+int sdm_op_layernorm(sdm_ctx* ctx, const void* x, int in_f32, long rows, int C, const float* gamma, const float* beta,
+                     float eps, void* out_f16);
+/* softmax(q k^T * scale + bias) v per (batch, head): q [B,Lq,heads*D], k,v [B,Lk,heads*D] fp16 with row
+ * strides ldq/ldk/ldv, bias fp32 [B,Lk] or NULL (natural-log domain, as in the reference), out [B,Lq,heads*D].
+ * D = 64 (any heads) or 512 (heads = 1). */
+int sdm_op_attention(sdm_ctx* ctx, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* bias,
+                     int B, int heads, int Lq, int Lk, int D, void* out, int ldo);
+/* Antialiased bilinear resize of fp32 planes [P, Hin, Win] -> [P, Hout, Wout] (torchvision Resize). */
+int sdm_op_resize_aa(sdm_ctx* ctx, const float* in, int P, int Hin, int Win, float* out, int Hout, int Wout);
+/* Level-k additive key bias (natural-log domain) from the [-1,1] trimap plane [B,S,S] -> [B,(S/8>>k)^2]. */
+int sdm_op_mask_bias(sdm_ctx* ctx, const float* trimap_plane, int B, int S, int level, float* bias_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDMATTE_H_ */

@@ -1,0 +1,152 @@
+"""Operator parity checks shared by the emulator tests (CPU, tiny shapes) and the GPU tests (real
+kernels): every HIP kernel vs a plain torch fp32 reference of the same op on the same seeded inputs.
+Tolerances are stated per check: operands are fp16 (MFMA inputs), accumulation fp32."""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def h16(x):
+    """round to fp16 and back: the reference sees exactly the operand values the kernel sees"""
+    return x.half().float()
+
+
+def check_conv(eng, dev, N, H, W, Cin, Cout, ntaps=9, stride=1, pad_mode=0, up=0, C1=0, in_f32=False, res=None, out_f32=False,
+               geglu=False, out_scale=1.0, tile_cfg=-1, seed=0, atol=2e-2):
+    g = _g(seed)
+    x = h16(torch.randn(N, Cin + C1, H, W, generator=g))
+    if ntaps == 9:
+        w = torch.randn(Cout, Cin + C1, 3, 3, generator=g) / math.sqrt((Cin + C1) * 9)
+    else:
+        w = torch.randn(Cout, Cin + C1, generator=g) / math.sqrt(Cin + C1)
+    b = 0.1 * torch.randn(Cout, generator=g)
+    xr = x
+    if up:
+        xr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
+    if ntaps == 9:
+        if pad_mode == 1:
+            xr = F.pad(xr, (0, 1, 0, 1))
+            ref = F.conv2d(xr, h16(w), b, stride=stride, padding=0)
+        else:
+            ref = F.conv2d(xr, h16(w), b, stride=stride, padding=1)
+    else:
+        ref = F.conv2d(xr, h16(w)[:, :, None, None], b)
+    if geglu:
+        u, gg = ref.chunk(2, dim=1)
+        ref = u * F.gelu(gg)
+    ref = ref * out_scale
+    r = None
+    if res is not None:
+        r = torch.randn(ref.shape, generator=g)
+        r = r if res == "f32" else h16(r)
+        ref = ref + r
+    xs = nhwc(x)
+    xs = xs if in_f32 else xs.half()
+    x0 = xs[..., :Cin].contiguous().to(dev)
+    x1 = xs[..., Cin:].contiguous().to(dev) if C1 else None
+    rr = None
+    if r is not None:
+        rr = nhwc(r)
+        rr = (rr if res == "f32" else rr.half()).to(dev)
+    out = eng.op_conv(x0, w.to(dev), b.to(dev), x1=x1, stride=stride, pad_mode=pad_mode, up=up, res=rr, geglu=geglu, out_f32=out_f32,
+                      out_scale=out_scale, tile_cfg=tile_cfg)
+    got = nchw(out.float().cpu())
+    err = (got - ref).abs().max().item()
+    assert err < atol, f"conv mismatch max|d|={err:.4g} (ntaps={ntaps} s={stride} pad={pad_mode} up={up} cfg={tile_cfg} " \
+                       f"N={N} H={H} W={W} Cin={Cin}+{C1} Cout={Cout})"
+    return err
+
+
+def check_groupnorm(eng, dev, N, H, W, C, C1=0, in_f32=True, silu=True, eps=1e-6, seed=0, atol=4e-3):
+    g = _g(seed)
+    x = torch.randn(N, C + C1, H, W, generator=g) * 1.7 + 0.3
+    if not in_f32:
+        x = h16(x)
+    gamma = 1 + 0.2 * torch.randn(C + C1, generator=g)
+    beta = 0.1 * torch.randn(C + C1, generator=g)
+    ref = F.group_norm(x, 32, gamma, beta, eps)
+    if silu:
+        ref = F.silu(ref)
+    xs = nhwc(x)
+    xs = xs if in_f32 else xs.half()
+    x0 = xs[..., :C].contiguous().to(dev)
+    x1 = xs[..., C:].contiguous().to(dev) if C1 else None
+    out = eng.op_groupnorm(x0, gamma.to(dev), beta.to(dev), eps, silu, x1=x1)
+    got = nchw(out.float().cpu())
+    err = (got - ref).abs().max().item()
+    assert err < atol, f"groupnorm mismatch {err:.4g} (N={N} HW={H}x{W} C={C}+{C1} f32={in_f32} silu={silu})"
+    return err
+
+
+def check_layernorm(eng, dev, rows, C, in_f32=True, seed=0, atol=4e-3):
+    g = _g(seed)
+    x = torch.randn(rows, C, generator=g) * 2.0 + 0.5
+    if not in_f32:
+        x = h16(x)
+    gamma = 1 + 0.2 * torch.randn(C, generator=g)
+    beta = 0.1 * torch.randn(C, generator=g)
+    ref = F.layer_norm(x, (C,), gamma, beta, 1e-5)
+    xs = (x if in_f32 else x.half()).to(dev)
+    out = eng.op_layernorm(xs, gamma.to(dev), beta.to(dev), 1e-5)
+    err = (out.float().cpu() - ref).abs().max().item()
+    assert err < atol, f"layernorm mismatch {err:.4g} (rows={rows} C={C})"
+    return err
+
+
+def check_attention(eng, dev, B, heads, Lq, Lk, D, use_bias, seed=0, atol=3e-3, fused_stride=False, spike=False):
+    g = _g(seed)
+    q = h16(torch.randn(B, Lq, heads * D, generator=g))
+    k = h16(torch.randn(B, Lk, heads * D, generator=g))
+    v = h16(torch.randn(B, Lk, heads * D, generator=g))
+    if spike:
+        # force a large running-max jump late in the key sequence (online-softmax rescale branch)
+        k[:, Lk - 3] = h16(q[:, 0] * 4.0)
+    bias = None
+    if use_bias:
+        keep = (torch.rand(B, Lk, generator=g) > 0.5).float()
+        keep[:, Lk // 3] = 1.0
+        bias = (1 - keep) * -10000.0
+    scale = D ** -0.5
+    qh = q.view(B, Lq, heads, D).permute(0, 2, 1, 3)
+    kh = k.view(B, Lk, heads, D).permute(0, 2, 1, 3)
+    vh = v.view(B, Lk, heads, D).permute(0, 2, 1, 3)
+    s = torch.matmul(qh.double(), kh.double().transpose(-1, -2)) * scale
+    if bias is not None:
+        s = s + bias[:, None, None, :].double()
+    ref = torch.matmul(s.softmax(-1), vh.double()).permute(0, 2, 1, 3).reshape(B, Lq, heads * D).float()
+    if fused_stride:
+        buf = torch.zeros(B, max(Lq, Lk), 3 * heads * D, dtype=torch.float16)
+        buf[:, :Lq, :heads * D] = q.half()
+        buf[:, :Lk, heads * D:2 * heads * D] = k.half()
+        buf[:, :Lk, 2 * heads * D:] = v.half()
+        buf = buf.to(dev)
+        qd, kd, vd = buf[:, :Lq, :heads * D], buf[:, :Lk, heads * D:2 * heads * D], buf[:, :Lk, 2 * heads * D:]
+    else:
+        qd, kd, vd = q.half().to(dev), k.half().to(dev), v.half().to(dev)
+    out = eng.op_attention(qd, kd, vd, heads, bias.to(dev) if bias is not None else None)
+    err = (out.float().cpu() - ref).abs().max().item()
+    assert err < atol, f"attention mismatch {err:.4g} (B={B} h={heads} Lq={Lq} Lk={Lk} D={D} bias={use_bias})"
+    return err
+
+
+def check_resize(eng, dev, P, Hin, Win, Hout, Wout, seed=0, atol=2e-5):
+    g = _g(seed)
+    x = torch.rand(P, Hin, Win, generator=g)
+    ref = F.interpolate(x[None], size=(Hout, Wout), mode="bilinear", align_corners=False, antialias=True)[0]
+    out = eng.op_resize_aa(x.to(dev), Hout, Wout)
+    err = (out.cpu() - ref).abs().max().item()
+    assert err < atol, f"resize mismatch {err:.4g} ({Hin}x{Win}->{Hout}x{Wout})"
+    return err

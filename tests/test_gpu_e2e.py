@@ -1,0 +1,159 @@
+"""-m gpu: end-to-end parity of the HIP engine against the CPU oracle on the same seeded weights + inputs.
+
+Tolerances.  The north star asks for max|d alpha| <= 1e-3 vs the reference's fp32 CPU path.  Any evaluation
+of this graph with fp16 MFMA operands (the reference's own CUDA autocast path included)
+differs from the fp32 path by more than that on synthetic (untrained, un-saturated) weights: rounding ONLY the
+weights to fp16 inside the fp32 oracle moves alpha by ~3e-3 max / 4e-4 mean (tests/test_precision_floor.py).
+The engine therefore is held to: (a) no further from the fp32 oracle than 1.5x the oracle's own fp16-operand
+emulation, (b) max <= 1e-2 and mean <= 1.5e-3 absolute; measured values are printed and recorded in DESIGN.md."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def _fp16_operand_oracle(O, w, cfgd, data):
+    """fp32 oracle with conv/linear inputs and weights rounded to fp16 = emulation of ANY fp16-operand path."""
+    w16 = {k: (v.half().float() if (k.endswith(".weight") and v.dim() >= 2) else v) for k, v in w.items()}
+    oc, ol = F.conv2d, F.linear
+    try:
+        F.conv2d = lambda x, ww, b=None, **kw: oc(x.half().float(), ww, b, **kw)
+        F.linear = lambda x, ww, b=None: ol(x.half().float(), ww, b)
+        return O.sdmatte_forward(w16, cfgd, data)
+    finally:
+        F.conv2d, F.linear = oc, ol
+
+
+def _run(pkg, cfg, S, B, seed=1234):
+    from comfyui_sdmatte_amd.weights import synthetic_state_dict
+    from comfyui_sdmatte_amd.synth import synthetic_inputs
+    from comfyui_sdmatte_amd.core import SDMatte
+    from oracle import sdmatte_oracle as O
+    w = synthetic_state_dict(cfg, 0)
+    img, tri = synthetic_inputs(B, S, S, seed)
+    data = O.preprocess(img, tri, S, False)
+    ref = O.sdmatte_forward(w, cfg.as_dict(), data)
+    emu16 = _fp16_operand_oracle(O, w, cfg.as_dict(), data)
+    m = SDMatte(None, use_aux_input=True, aux_input="trimap", aux_input_list=["trimap"], attn_mask_aux_input=["trimap"], load_weight=False,
+                config=cfg)
+    m.load_state_dict(w, strict=False)
+    m.eval().to("cuda:0")
+    assert not m.missing_keys
+    dcu = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data.items()}
+    out = m(dcu).cpu()
+    d = (out - ref).abs()
+    floor = (emu16 - ref).abs()
+    print(f"\n[{cfg.name} S={S} B={B}] max|d|={d.max():.3e} mean|d|={d.mean():.3e}  fp16-operand floor: max={floor.max():.3e} mean={floor.mean():.3e}")
+    return m, w, img, tri, data, ref, out, d, floor
+
+
+def _assert_parity(d, floor):
+    assert d.mean().item() <= max(1.5 * floor.mean().item(), 2e-4)
+    assert d.max().item() <= max(1.5 * floor.max().item(), 1e-3)
+    assert d.max().item() <= 1e-2 and d.mean().item() <= 1.5e-3
+
+
+def test_e2e_tiny_core_api(pkg):
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    m, w, img, tri, data, ref, out, d, floor = _run(pkg, SDMatteConfig.tiny(), 64, 3)
+    _assert_parity(d, floor)
+    # batch invariance on the GPU path: image 1 alone == image 1 in the batch (bitwise: same kernels, same tiles)
+    d1 = {k: (v[1:2].cuda() if torch.is_tensor(v) else v[1:2]) for k, v in data.items()}
+    o1 = m(d1).cpu()
+    assert (o1[0] - out[1]).abs().max().item() < 2e-3
+    # is_trans flips the opacity embedding -> output must change and still match the oracle
+    from oracle import sdmatte_oracle as O
+    data_t = dict(data); data_t["is_trans"] = torch.ones_like(data["is_trans"])
+    ref_t = O.sdmatte_forward(w, SDMatteConfig.tiny().as_dict(), data_t)
+    out_t = m({k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data_t.items()}).cpu()
+    assert (ref_t - ref).abs().max().item() > 1e-3
+    assert (out_t - ref_t).abs().max().item() <= 1e-2 and (out_t - ref_t).abs().mean().item() <= 1.5e-3
+    m.engine.close()
+
+
+def test_e2e_tiny_s192_ragged_levels(pkg):
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    # S=192 -> latent 24, levels 24/12/6/3: token counts 576/144/36/9 (ragged vs the 64-key / 128-query tiles)
+    m, w, img, tri, data, ref, out, d, floor = _run(pkg, SDMatteConfig.tiny(), 192, 1)
+    _assert_parity(d, floor)
+    m.engine.close()
+
+
+def test_e2e_tiny_d512_vae_attention(pkg):
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    m, w, img, tri, data, ref, out, d, floor = _run(pkg, SDMatteConfig.tiny_d512(), 128, 1)
+    _assert_parity(d, floor)
+    m.engine.close()
+
+
+def test_e2e_node_api_resize_refine_compose(pkg, tmp_path, monkeypatch):
+    """Config #4-like: non-square 100x120 input at S=128 through the real node signature, mask_refine + trimap_constraint,
+    all output modes; checkpoint is a synthetic safetensors file discovered through the registered model folder."""
+    from safetensors.torch import save_file
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    from comfyui_sdmatte_amd.weights import synthetic_state_dict
+    from comfyui_sdmatte_amd.synth import synthetic_inputs
+    from comfyui_sdmatte_amd import sdmatte_nodes as N
+    from comfyui_sdmatte_amd import core
+    from oracle import sdmatte_oracle as O
+    cfg = SDMatteConfig.tiny()
+    w = synthetic_state_dict(cfg, 0)
+    d = tmp_path / "SDMatte"
+    d.mkdir()
+    save_file({k: v.contiguous() for k, v in w.items()}, str(d / "SDMatte_plus.safetensors"))
+    N.folder_paths.add_model_folder_path("SDMatte", str(d))
+    monkeypatch.setattr(core.SDMatteConfig, "full", staticmethod(lambda: cfg))     # tiny architecture for the tiny checkpoint
+    N._MODEL_CACHE.clear()
+    img, tri = synthetic_inputs(2, 100, 120)
+    node = N.SDMatteApply()
+    for mode in ("alpha_only", "matted_rgba", "matted_rgb"):
+        a, mimg = node.apply_matte("SDMatte_plus.safetensors", img, tri, 128, False, mode, True, 0.8)
+        ra, rm = O.apply_matte(w, cfg.as_dict(), img, tri, 128, False, mode, True, 0.8)
+        assert a.shape == ra.shape and mimg.shape == rm.shape and a.device.type == "cpu"
+        # refined alpha has hard thresholds (a<0.3 -> 0, x1.2 clamp): compare where both sides are away from a threshold flip
+        diff = (a - ra).abs()
+        frac_bad = (diff > 1e-2).float().mean().item()
+        assert frac_bad < 5e-3, f"{mode}: {frac_bad}"
+        assert torch.equal(mimg[..., :3], rm[..., :3]) or mode == "matted_rgb"
+    with pytest.raises(RuntimeError):
+        node.apply_matte("SDMatte_plus.safetensors", img, tri, 128, False, "alpha_only", True, 0.8, force_cpu=True)
+    with pytest.raises(ValueError):
+        N.download_model("nope.safetensors")
+    N._MODEL_CACHE.clear()
+
+
+def test_e2e_pre_post_match_reference_fixture(pkg, golden_dir):
+    """G1: the GPU preprocessing (resize+normalise) and postprocessing (resize back + clamp) against what the REFERENCE node
+    produced for the same inputs (tests/golden/g1_node_prepost.npz)."""
+    import numpy as np
+    from comfyui_sdmatte_amd.engine import Engine
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    g = np.load(os.path.join(golden_dir, "g1_node_prepost.npz"))
+    eng = Engine(SDMatteConfig.tiny(), 0)
+    image = torch.from_numpy(g["image"])              # [B,H,W,3]
+    tri = torch.from_numpy(g["trimap"])
+    S = int(g["inference_size"])
+    B, H, W, _ = image.shape
+    planes = image.permute(0, 3, 1, 2).reshape(B * 3, H, W).contiguous().cuda()
+    r = eng.op_resize_aa(planes, S, S).cpu().view(B, 3, S, S)
+    assert ((r - 0.5) / 0.5 - torch.from_numpy(g["data_image"])).abs().max().item() < 2e-5
+    rt = eng.op_resize_aa(tri.cuda(), S, S).cpu()
+    assert (rt * 2 - 1 - torch.from_numpy(g["data_trimap"])[:, 0]).abs().max().item() < 2e-5
+    fake = torch.from_numpy(g["fake_alpha"])[:, 0].contiguous().cuda()
+    back = eng.op_resize_aa(fake, H, W).cpu().clamp(0, 1)
+    assert (back - torch.from_numpy(g["alpha__alpha_only__refine0__c8"])).abs().max().item() < 2e-5
+    eng.close()
+
+
+@pytest.mark.slow
+def test_e2e_full_model_512(pkg):
+    """BASELINE config #1 size on the real SD-2.1 architecture (synthetic weights): 512x512, B=1, vs the fp32 CPU oracle."""
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    m, w, img, tri, data, ref, out, d, floor = _run(pkg, SDMatteConfig.full(), 512, 1)
+    _assert_parity(d, floor)
+    m.engine.close()
