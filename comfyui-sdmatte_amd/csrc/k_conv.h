@@ -28,7 +28,7 @@
 struct ConvParams {
   const void* in0; const void* in1;     // NHWC sources (channel concat: in0 then in1); in1 may be null
   int C0, C1;                           // channel counts (row strides) of the sources; (C0+C1) % KC == 0
-  int in_f32;                           // sources are fp32 (1) or fp16 (0)
+  int in_f32;                           // sources are fp32 (1) or fp16 (0): must match the IN_F32 template argument
   int N, Hin, Win;                      // source dims (before the fused upsample)
   int up;                               // 1: nearest x2 upsample fused into the load
   int Hout, Wout;
@@ -65,12 +65,14 @@ struct ConvCfg {
   static_assert(KC % 16 == 0, "KC multiple of the MFMA K (16)");
 };
 
-template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN>
+template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN, int IN_F32>
 __global__ void __launch_bounds__(64 * WM * WN)
 conv_mfma_kernel(ConvParams p) {
   using C = ConvCfg<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN>;
   constexpr int NT = C::NTHREADS, MT = C::MT, NTL = C::NTL, PITCH = C::PITCH, KV = C::KV;
   constexpr int HPW = C::HPW, HP = C::HP, WTM = C::WTM, WTN = C::WTN;
+  constexpr int A_VEC = HP * KV, B_VEC = NTAPS * BN * KV;
+  constexpr int A_PER = (A_VEC + NT - 1) / NT, B_PER = (B_VEC + NT - 1) / NT;
   SDM_DYN_SMEM(smem);
   unsigned char* As = smem;
   unsigned char* Bs = smem + C::A_BYTES;
@@ -109,42 +111,102 @@ conv_mfma_kernel(ConvParams p) {
 #pragma unroll
   for (int j = 0; j < NTL; ++j) bbase[j] = (wn * WTN + j * 32 + (lane & 31)) * PITCH + (lane >> 5) * 16;
 
-  for (int c0 = 0; c0 < Cin; c0 += KC) {
-    __syncthreads();
-    // ---- stage A: halo tile [HP pixels][KC channels], zero-filled outside the (upsampled) image ----
-    const void* src = p.in0;
-    int Csrc = p.C0, cc = c0;
-    if (c0 >= p.C0) { src = p.in1; Csrc = p.C1; cc = c0 - p.C0; }
-    for (int v = tid; v < HP * KV; v += NT) {
-      const int hp = v / KV, part = v % KV;
-      f16x8 val;
+  // ---- K-loop invariant staging descriptors (hoisted: no address math inside the chunk loop) ----
+  // A vector v = tid + i*NT -> (halo pixel hp, 8-channel part); a_pix = pixel index inside the batch (-1: zero fill)
+  int a_pix[A_PER], a_part[A_PER], a_lds[A_PER];      // pixel indices < 2^31 (checked by the host)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) val[e] = (half_t)0.0f;
+  for (int i = 0; i < A_PER; ++i) {
+    const int v = tid + i * NT;
+    const int hp = v / KV, part = v % KV;
+    a_part[i] = part * 8;
+    a_lds[i] = hp * PITCH + part * 16;
+    a_pix[i] = -1;
+    if (v < A_VEC) {
       if (NTAPS == 9) {
         const int hy = hp / HPW, hx = hp % HPW;
         const int iy = oy0 * STRIDE + hy - p.pad_t, ix = ox0 * STRIDE + hx - p.pad_l;
-        if (iy >= 0 && iy < Hl && ix >= 0 && ix < Wl) {
-          const size_t pix = ((size_t)img * p.Hin + (iy >> p.up)) * p.Win + (ix >> p.up);
-          val = sdm_load8_as_f16(src, pix * Csrc + cc + part * 8, p.in_f32);
-        }
+        if (iy >= 0 && iy < Hl && ix >= 0 && ix < Wl) a_pix[i] = (img * p.Hin + (iy >> p.up)) * p.Win + (ix >> p.up);
       } else {
         const long m = m0 + hp;
-        if (m < p.M) val = sdm_load8_as_f16(src, (size_t)m * Csrc + cc + part * 8, p.in_f32);
+        if (m < p.M) a_pix[i] = (int)m;
       }
-      *(f16x8*)(As + hp * PITCH + part * 16) = val;
+    } else {
+      a_lds[i] = -1;
     }
-    // ---- stage B: weights of this K-chunk, all taps: LDS [NTAPS][BN][KC] from the K16-packed tensor ----
-    for (int v = tid; v < NTAPS * BN * KV; v += NT) {
-      const int h = v & 1, co = (v >> 1) % BN, rest = (v >> 1) / BN;
-      const int tap = rest % NTAPS, sc = rest / NTAPS;
-      f16x8 val;
+  }
+  // B vector v -> (tap, co, 16-channel sub-chunk sc, half h) of the K16-packed weight tensor
+  int b_src[B_PER], b_lds[B_PER];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) val[e] = (half_t)0.0f;
-      if (n0 + co < p.Cout_pad)
-        val = *(const f16x8*)(p.w + (((size_t)(c0 / 16 + sc) * NTAPS + tap) * p.Cout_pad + n0 + co) * 16 + h * 8);
-      *(f16x8*)(Bs + (tap * BN + co) * PITCH + (sc * 2 + h) * 16) = val;
+  for (int i = 0; i < B_PER; ++i) {
+    const int v = tid + i * NT;
+    const int h = v & 1, co = (v >> 1) % BN, rest = (v >> 1) / BN;
+    const int tap = rest % NTAPS, sc = rest / NTAPS;
+    b_lds[i] = (v < B_VEC) ? (tap * BN + co) * PITCH + (sc * 2 + h) * 16 : -1;
+    b_src[i] = (v < B_VEC && n0 + co < p.Cout_pad) ? ((sc * NTAPS + tap) * p.Cout_pad + n0 + co) * 16 + h * 8 : -1;
+  }
+  const long b_chunk_stride = (long)(KC / 16) * NTAPS * p.Cout_pad * 16;
+
+  // raw staging registers (the global loads of chunk k+1 are in flight while chunk k is multiplied)
+  f32x4 a_raw[A_PER][IN_F32 ? 2 : 1];
+  f16x8 b_raw[B_PER];
+  auto issue_loads = [&](int c0) {
+    const void* src = p.in0;
+    int Csrc = p.C0, cc = c0;
+    if (c0 >= p.C0) { src = p.in1; Csrc = p.C1; cc = c0 - p.C0; }
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      if (a_pix[i] >= 0) {
+        const size_t e = (size_t)a_pix[i] * Csrc + cc + a_part[i];
+        if (IN_F32) {
+          const f32x4* q = (const f32x4*)((const float*)src + e);
+          a_raw[i][0] = q[0];
+          a_raw[i][IN_F32 ? 1 : 0] = q[1];
+        } else {
+          a_raw[i][0] = *(const f32x4*)((const half_t*)src + e);
+        }
+      }
     }
+    const half_t* wsrc = p.w + (size_t)(c0 / KC) * b_chunk_stride;
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i)
+      if (b_src[i] >= 0) b_raw[i] = *(const f16x8*)(wsrc + b_src[i]);
+  };
+  auto write_lds = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      if (a_lds[i] >= 0) {
+        f16x8 val;
+        if (a_pix[i] < 0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) val[e] = (half_t)0.0f;
+        } else if (IN_F32) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { val[e] = (half_t)a_raw[i][0][e]; val[4 + e] = (half_t)a_raw[i][IN_F32 ? 1 : 0][e]; }
+        } else {
+          val = __builtin_bit_cast(f16x8, a_raw[i][0]);
+        }
+        *(f16x8*)(As + a_lds[i]) = val;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      if (b_lds[i] >= 0) {
+        f16x8 val = b_raw[i];
+        if (b_src[i] < 0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) val[e] = (half_t)0.0f;
+        }
+        *(f16x8*)(Bs + b_lds[i]) = val;
+      }
+    }
+  };
+
+  issue_loads(0);
+  for (int c0 = 0; c0 < Cin; c0 += KC) {
+    __syncthreads();            // every wave has finished reading the previous chunk from LDS
+    write_lds();
     __syncthreads();
+    if (c0 + KC < Cin) issue_loads(c0 + KC);
     // ---- MFMA over taps and K sub-steps ----
 #pragma unroll
     for (int tap = 0; tap < NTAPS; ++tap) {

@@ -69,20 +69,26 @@ static inline size_t rupz(size_t a, size_t b) { return ((a + b - 1) / b) * b; }
 template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN>
 static void launch_conv_t(const ConvParams& p, void* stream) {
   using C = ConvCfg<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN>;
-  auto k = conv_mfma_kernel<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN>;
-  SDM_SET_SMEM(k, C::SMEM);
   dim3 grid;
   if (NTAPS == 9) grid = dim3(sdm_cdiv(p.Wout, TW) * sdm_cdiv(p.Hout, TH), sdm_cdiv(p.Cout_pad, BN), p.N);
   else grid = dim3((unsigned)((p.M + C::BM - 1) / C::BM), sdm_cdiv(p.Cout_pad, BN), 1);
-  SDM_LAUNCH(k, grid, dim3(C::NTHREADS), C::SMEM, stream, p);
+  if (p.in_f32) {
+    auto k = conv_mfma_kernel<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN, 1>;
+    SDM_SET_SMEM(k, C::SMEM);
+    SDM_LAUNCH(k, grid, dim3(C::NTHREADS), C::SMEM, stream, p);
+  } else {
+    auto k = conv_mfma_kernel<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN, 0>;
+    SDM_SET_SMEM(k, C::SMEM);
+    SDM_LAUNCH(k, grid, dim3(C::NTHREADS), C::SMEM, stream, p);
+  }
 }
 
 struct ConvCfgInfo { int TH, TW, BN, KC; };
-static const ConvCfgInfo kCfg3s1[] = {{8, 32, 128, 16}, {4, 32, 64, 32}, {8, 8, 64, 32}, {8, 8, 64, 16}};
+static const ConvCfgInfo kCfg3s1[] = {{8, 32, 128, 16}, {4, 32, 64, 32}, {8, 8, 64, 16}};
 static const ConvCfgInfo kCfg3s2[] = {{4, 32, 64, 16}, {8, 8, 64, 16}};
 static const ConvCfgInfo kCfg1[] = {{8, 32, 128, 64}, {4, 32, 64, 64}, {8, 8, 64, 64}, {8, 8, 64, 16}};
 
-static int conv_num_cfgs(int ntaps, int stride) { return ntaps == 9 ? (stride == 1 ? 4 : 2) : 4; }
+static int conv_num_cfgs(int ntaps, int stride) { return ntaps == 9 ? (stride == 1 ? 3 : 2) : 4; }
 static const ConvCfgInfo* conv_cfg_table(int ntaps, int stride) { return ntaps == 9 ? (stride == 1 ? kCfg3s1 : kCfg3s2) : kCfg1; }
 
 static bool conv_cfg_ok(const ConvCfgInfo& c, const ConvParams& p) {
@@ -99,6 +105,7 @@ static int conv_pick_cfg(int ntaps, int stride, const ConvParams& p) {
   int best = -1;
   for (int i = 0; i < n; ++i) {
     if (!conv_cfg_ok(t[i], p)) continue;
+    if (ntaps == 1 && i == 0 && p.in_f32) continue;   // 256x128x64 tile + fp32 staging registers would drop to 1 wave/SIMD
     long blocks;
     if (ntaps == 9) {
       if (t[i].TW > 8 && p.Wout < 24) continue;   // 32-wide strips would be mostly padding
@@ -118,8 +125,7 @@ static int launch_conv(int ntaps, int stride, int cfg, const ConvParams& p, void
     switch (cfg) {
       case 0: launch_conv_t<9, 1, 8, 32, 128, 16, 2, 2>(p, stream); return 0;
       case 1: launch_conv_t<9, 1, 4, 32, 64, 32, 4, 1>(p, stream); return 0;
-      case 2: launch_conv_t<9, 1, 8, 8, 64, 32, 2, 1>(p, stream); return 0;
-      case 3: launch_conv_t<9, 1, 8, 8, 64, 16, 2, 1>(p, stream); return 0;
+      case 2: launch_conv_t<9, 1, 8, 8, 64, 16, 2, 1>(p, stream); return 0;
     }
   } else if (ntaps == 9 && stride == 2) {
     switch (cfg) {
@@ -545,6 +551,7 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
   p.out_ch_off = a.out_ch_off;
   if (a.res) { p.res = a.res->p; p.res_f32 = a.res->f32; p.res_C = a.res->C; }
   p.epi = L.geglu; p.out_scale = a.out_scale;
+  if ((long)a.in0->rows() >= (1L << 31) || p.M >= (1L << 31)) SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: tensor too large for 32-bit pixel indices", L.name.c_str());
   if (p.C0 + p.C1 != L.Cin_pad) SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: input channels %d+%d != %d", L.name.c_str(), p.C0, p.C1, L.Cin_pad);
   if (a.in1 && a.in1->f32 != a.in0->f32) SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: concat sources differ in dtype", L.name.c_str());
   int cfg = a.force_cfg >= 0 ? a.force_cfg : conv_pick_cfg(L.ntaps, a.stride, p);
@@ -1358,7 +1365,7 @@ int sdm_op_conv(sdm_ctx* e, const void* in0, const void* in1, int C0, int C1, in
   if (bias) SDM_LAUNCH(pack_bias_kernel, dim3(sdm_cdiv(L.Cout_pad, 256)), dim3(256), 0, e->stream, bias, L.b, O, L.Cout_pad, 0, geglu);
   int Ho = Hin << up, Wo = Win << up;
   if (stride == 2) { Ho /= 2; Wo /= 2; }
-  const int Cst = geglu ? O / 2 : O;
+  const int Cst = rup(geglu ? O / 2 : O, 4);   // rows are stored with 4-channel vectors
   T tin0, tin1, tout, tres;
   tin0.p = (void*)in0; tin0.N = N; tin0.H = Hin; tin0.W = Win; tin0.C = C0; tin0.f32 = in_f32;
   tin1 = tin0; tin1.p = (void*)in1; tin1.C = C1;

@@ -255,7 +255,8 @@ class Engine:
         Ho, Wo = (H << up), (W_ << up)
         if stride == 2:
             Ho, Wo = Ho // 2, Wo // 2
-        Cst = O // 2 if geglu else O
+        Creal = O // 2 if geglu else O
+        Cst = (Creal + 3) // 4 * 4          # rows are stored with 4-channel vector stores
         out = torch.empty(N, Ho, Wo, Cst, dtype=torch.float32 if out_f32 else torch.float16, device=x0.device)
         w = w.float().contiguous()
         b = bias.float().contiguous() if bias is not None else None
@@ -263,7 +264,7 @@ class Engine:
                                          pad_mode, ntaps, _ptr(w), _ptr(b), O, _ptr(out), int(out_f32), _ptr(res),
                                          int(res is not None and res.dtype == torch.float32), int(geglu), float(out_scale), tile_cfg),
                     "sdm_op_conv")
-        return out
+        return out[..., :Creal]
 
     def op_groupnorm(self, x0, gamma, beta, eps, silu, groups=32, x1=None):
         N, H, W_, C0 = x0.shape
