@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-size", type=int, default=512)
+    ap.add_argument("--dump-profile", type=str, default=None, help="write the per-launch profile CSV here")
     ap.add_argument("--fp16-stream", action="store_true", help="keep the residual stream in fp16 instead of fp32")
     args = ap.parse_args()
 
@@ -120,6 +121,9 @@ def main():
         eng.apply_matte(img_d, tri_d, S, False, out=alpha, sync=True)
         eng.profile(False)
         prof = eng.profile_results()
+        if args.dump_profile:
+            with open(args.dump_profile, "w") as fh:
+                fh.write(eng.profile_dump())
         roof = None
         if "conv3x3_mfma" in prof:
             c = prof["conv3x3_mfma"]

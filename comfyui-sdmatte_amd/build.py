@@ -12,7 +12,7 @@ LIB = os.path.join(CSRC, "libsdmatte_hip.so")
 SOURCES = ["sdm_engine.cpp"]
 HEADERS = ["sdm_common.h", "k_conv.h", "k_norm.h", "k_attn.h", "k_misc.h", os.path.join("..", "..", "include", "sdmatte.h")]
 FLAGS = ["-x", "hip", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
-         "-Wno-unused-result", "-Wno-unused-value", "-DNDEBUG"]
+         "-Wno-unused-result", "-Wno-unused-value", "-DNDEBUG", "-munsafe-fp-atomics"]
 
 
 def _hipcc():

@@ -45,6 +45,8 @@ struct ConvParams {
   const void* res; int res_f32; int res_C;
   int epi;                              // 0: linear, 1: GEGLU (cols come in [u32|g32] groups of 64)
   float out_scale;
+  double* stats;                        // optional [N][Cout_store][2]: per-(image,channel) sum / sum of squares of the stored
+                                        // values (fused GroupNorm statistics of the NEXT layer); NTAPS==9 or one image per launch
 };
 
 template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN>
@@ -226,14 +228,18 @@ conv_mfma_kernel(ConvParams p) {
     }
   }
 
-  // ---- epilogue: per-wave fp32 staging tile (32 x WTN) in LDS -> coalesced row stores ----
-  __syncthreads();
+  // ---- epilogue: per-wave PRIVATE fp32 staging tile (32 x WTN) in LDS -> coalesced row stores ----
+  __syncthreads();               // all waves are done with the A/B tiles: the region is reused for staging
   float* stg = (float*)smem + wave * (32 * WTN);
   constexpr int LPR = WTN / 4;   // lanes per output row (4 channels each)
   constexpr int RPP = 64 / LPR;  // rows per pass
   const float* bias = p.bias;
   if (bias && p.bias_sel) bias += (size_t)p.bias_sel[img] * p.Cout_pad;
   const int colbase = n0 + wn * WTN;
+  const int c4 = (lane % LPR) * 4;
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+  int oc = 0;
+  bool colok = true;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -243,11 +249,10 @@ conv_mfma_kernel(ConvParams p) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         stg[row * WTN + j * 32 + (lane & 31)] = acc[i][j][r];
       }
-    __syncthreads();
+    SDM_WAVE_SYNC();
 #pragma unroll
     for (int pass = 0; pass < 32 / RPP; ++pass) {
       const int row = pass * RPP + lane / LPR;
-      const int c4 = (lane % LPR) * 4;
       const int m = wm * WTM + i * 32 + row;
       long opix;
       bool valid;
@@ -260,8 +265,6 @@ conv_mfma_kernel(ConvParams p) {
         valid = opix < p.M;
       }
       float v[4];
-      int oc;
-      bool colok = true;
       if (p.epi == 1) {
         // GEGLU: this wave's 64 columns are [u(32) | g(32)] of the same 32 output channels
         colok = (c4 & 63) < 32;
@@ -310,10 +313,28 @@ conv_mfma_kernel(ConvParams p) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
           *(f16x4*)((half_t*)p.out + oidx) = o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (float)o[e];      // statistics of what the next layer will actually read
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
       }
     }
-    __syncthreads();
+    SDM_WAVE_SYNC();
+  }
+  // ---- fused GroupNorm statistics of the consumer: per-(image, channel) sum / sumsq of this tile ----
+  if (p.stats) {
+    // lanes {l, l+LPR, l+2*LPR, ...} own the same 4 channels: fold them, then one fp64 atomic per channel per wave
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+      for (int m = LPR; m < 64; m <<= 1) { ssum[e] += __shfl_xor(ssum[e], m); ssq[e] += __shfl_xor(ssq[e], m); }
+    }
+    if (lane < LPR && colok && oc < p.Cout_valid) {
+      double* st = p.stats + ((size_t)img * p.Cout_store + p.out_ch_off + oc) * 2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { atomicAdd(st + 2 * e, (double)ssum[e]); atomicAdd(st + 2 * e + 1, (double)ssq[e]); }
+    }
   }
 }
 

@@ -76,6 +76,30 @@ __global__ void gn_finalize_kernel(const double* __restrict__ sums, const float*
   shift[i] = beta[c] - (float)mean * a;
 }
 
+// Same, but from per-(image, channel) sums produced by the conv epilogues of the producer(s) (k_conv.h `stats`):
+// st0/st1 are [N][C0|C1][2] doubles for the two concat sources; a group may straddle the concat boundary.
+__global__ void gn_finalize_ch_kernel(const double* __restrict__ st0, const double* __restrict__ st1, int C0, int C1,
+                                      const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ scale,
+                                      float* __restrict__ shift, int N, int groups, long hw, float eps) {
+  const int C = C0 + C1;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * C) return;
+  const int n = i / C, c = i % C, cpg = C / groups, g = c / cpg;
+  double s = 0.0, q = 0.0;
+  for (int j = g * cpg; j < (g + 1) * cpg; ++j) {
+    const double* p = (j < C0) ? st0 + ((size_t)n * C0 + j) * 2 : st1 + ((size_t)n * C1 + (j - C0)) * 2;
+    s += p[0]; q += p[1];
+  }
+  const double cnt = (double)hw * cpg;
+  const double mean = s / cnt;
+  double var = q / cnt - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float a = rstd * gamma[c];
+  scale[i] = a;
+  shift[i] = beta[c] - (float)mean * a;
+}
+
 // y = act(x*scale + shift) -> fp16 NHWC with C channels (concat materialised)
 __global__ void __launch_bounds__(512) gn_apply_kernel(GnSrc s, const float* __restrict__ scale, const float* __restrict__ shift,
                                                        half_t* __restrict__ out, int silu, int pix_per_block) {

@@ -26,6 +26,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define SDM_LAUNCH(kernel, grid, block, smem, stream, ...) \
   emu::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); })
 #define SDM_DEV_INLINE static inline
+#define SDM_WAVE_SYNC() emu::wave_barrier()
 static inline float sdm_exp2(float x) { return exp2f(x); }
 static inline float sdm_rcp(float x) { return 1.0f / x; }
 #else
@@ -35,6 +36,9 @@ static inline float sdm_rcp(float x) { return 1.0f / x; }
 #define SDM_LAUNCH(kernel, grid, block, smem, stream, ...) \
   hipLaunchKernelGGL(kernel, (grid), (block), (smem), (hipStream_t)(stream), __VA_ARGS__)
 #define SDM_DEV_INLINE __device__ __forceinline__
+// LDS operations of ONE wave execute in issue order, so lanes of a wave may exchange data through a wave-private LDS
+// region without s_barrier; only the compiler must not reorder the accesses.
+#define SDM_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 __device__ __forceinline__ float sdm_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float sdm_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 #endif

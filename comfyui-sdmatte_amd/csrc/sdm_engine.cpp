@@ -114,7 +114,7 @@ static int conv_pick_cfg(int ntaps, int stride, const ConvParams& p) {
       blocks = ((p.M + t[i].TH * t[i].TW - 1) / (t[i].TH * t[i].TW)) * sdm_cdiv(p.Cout_pad, t[i].BN);
     }
     if (best < 0) { best = i; best_blocks = blocks; }
-    if (blocks >= 384) return i;                 // first (largest) tile that still fills 256 CUs
+    if (blocks >= 256) return i;                 // first (largest) tile that still gives every CU a block
     if (blocks > best_blocks) { best = i; best_blocks = blocks; }
   }
   return best;
@@ -175,13 +175,15 @@ struct T {  // NHWC activation tensor living in the arena
   size_t off = 0, bytes = 0;
   void* p = nullptr;
   int N = 0, H = 0, W = 0, C = 0, f32 = 0;
+  double* stats = nullptr;      // optional per-(image,channel) {sum, sumsq}, filled by the producing conv epilogue
+  size_t soff = 0, sbytes = 0;
   long rows() const { return (long)N * H * W; }
 };
 
 static const int kMaxVariants = 8;
 struct Variant { int trans; float c[4]; };
 
-struct ProfRec { std::string name; double flops, bytes;
+struct ProfRec { std::string name, desc; double flops, bytes;
 #ifndef SDM_EMU
   hipEvent_t e0, e1;
 #endif
@@ -239,6 +241,7 @@ struct sdm_ctx {
   std::vector<ProfRec> prof;
   struct ProfAgg { std::string name; float ms; int64_t n; double flops, bytes; };
   std::vector<ProfAgg> prof_agg;
+  std::string prof_dump;   // per-launch CSV of the last profiled forward
 #ifndef SDM_EMU
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 #endif
@@ -484,9 +487,14 @@ static T talloc(sdm_ctx* e, int N, int H, int W, int C, int f32) {
   return t;
 }
 
+static void tfree_raw(sdm_ctx* e, size_t off, size_t sz);
 static void tfree(sdm_ctx* e, T& t) {
   if (!t.bytes) return;
-  size_t off = t.off, sz = t.bytes;
+  if (t.sbytes) { tfree_raw(e, t.soff, t.sbytes); t.sbytes = 0; t.stats = nullptr; }
+  tfree_raw(e, t.off, t.bytes);
+  t.bytes = 0; t.p = nullptr;
+}
+static void tfree_raw(sdm_ctx* e, size_t off, size_t sz) {
   auto nx = e->freelist.lower_bound(off);
   if (nx != e->freelist.begin()) {
     auto pv = std::prev(nx);
@@ -496,7 +504,14 @@ static void tfree(sdm_ctx* e, T& t) {
   if (nx != e->freelist.end() && nx->first == off + sz) { sz += nx->second; e->freelist.erase(nx); }
   if (off + sz == e->arena_top) e->arena_top = off;
   else e->freelist[off] = sz;
-  t.bytes = 0; t.p = nullptr;
+}
+
+// attach a zero-initialised statistics buffer to t (filled by the conv that produces t)
+static int tstats(sdm_ctx* e, T& t) {
+  T s = talloc(e, 1, 1, 1, t.N * t.C * 4, 1);        // N*C*2 doubles
+  t.soff = s.off; t.sbytes = s.bytes; t.stats = (double*)s.p;
+  if (!e->dry) SDM_CHECK_DEV(e, dev_memset(s.p, 0, (size_t)t.N * t.C * 16, e->stream));
+  return 0;
 }
 
 static void arena_reset(sdm_ctx* e) { e->freelist.clear(); e->arena_top = 0; }
@@ -504,9 +519,9 @@ static void arena_reset(sdm_ctx* e) { e->freelist.clear(); e->arena_top = 0; }
 // ------------------------------------------------------------------------------------------------
 // profiling helpers
 // ------------------------------------------------------------------------------------------------
-static void prof_begin(sdm_ctx* e, const char* name, double flops, double bytes) {
+static void prof_begin(sdm_ctx* e, const char* name, double flops, double bytes, const std::string& desc = std::string()) {
   if (!e->prof_on || e->dry) return;
-  ProfRec r; r.name = name; r.flops = flops; r.bytes = bytes;
+  ProfRec r; r.name = name; r.desc = desc; r.flops = flops; r.bytes = bytes;
 #ifndef SDM_EMU
   (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1);
   (void)hipEventRecord(r.e0, (hipStream_t)e->stream);
@@ -558,18 +573,47 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
   if (cfg < 0 || cfg >= conv_num_cfgs(L.ntaps, a.stride) || !conv_cfg_ok(conv_cfg_table(L.ntaps, a.stride)[cfg], p))
     SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: no tile configuration for Cin=%d+%d (cfg %d)", L.name.c_str(), p.C0, p.C1, cfg);
   if (e->dry) return 0;
+  if (a.out->stats) {
+    if (L.geglu || a.out_ch_off) SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: fused statistics unsupported with this epilogue", L.name.c_str());
+    p.stats = a.out->stats;
+  }
   const double flops = 2.0 * (double)p.M * L.O * L.I * L.ntaps;
   const double bytes = (double)a.in0->rows() * L.Cin_pad * (p.in_f32 ? 4 : 2) + (double)p.M * p.Cout_valid * (p.out_f32 ? 4 : 2) +
                        (double)L.Cin_pad * L.ntaps * L.Cout_pad * 2 + (a.res ? (double)p.M * p.Cout_valid * (p.res_f32 ? 4 : 2) : 0.0);
-  prof_begin(e, L.ntaps == 9 ? "conv3x3_mfma" : "gemm_mfma", flops, bytes);
-  if (launch_conv(L.ntaps, a.stride, cfg, p, e->stream) != 0) SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: bad cfg", L.name.c_str());
+  if (e->prof_on) {
+    char d[256];
+    snprintf(d, sizeof(d), "%s N=%d Hout=%d Wout=%d Cin=%d Cout=%d s=%d up=%d f32in=%d cfg=%d", L.name.c_str(), p.N, p.Hout, p.Wout, L.Cin_pad, L.O, a.stride,
+             a.up, p.in_f32, cfg);
+    prof_begin(e, L.ntaps == 9 ? "conv3x3_mfma" : "gemm_mfma", flops, bytes, d);
+  } else {
+    prof_begin(e, L.ntaps == 9 ? "conv3x3_mfma" : "gemm_mfma", flops, bytes);
+  }
+  int rc = 0;
+  if (L.ntaps == 1 && p.stats && p.N > 1) {
+    // the statistics are per image: one launch per image so that a row tile never straddles two images
+    const long rows = (long)p.Hout * p.Wout;
+    for (int n = 0; n < p.N && rc == 0; ++n) {
+      ConvParams q = p;
+      q.M = rows; q.N = 1;
+      q.in0 = (const unsigned char*)p.in0 + (size_t)n * rows * p.C0 * (p.in_f32 ? 4 : 2);
+      if (p.in1) q.in1 = (const unsigned char*)p.in1 + (size_t)n * rows * p.C1 * (p.in_f32 ? 4 : 2);
+      q.out = (unsigned char*)p.out + (size_t)n * rows * p.Cout_store * (p.out_f32 ? 4 : 2);
+      if (p.res) q.res = (const unsigned char*)p.res + (size_t)n * rows * p.res_C * (p.res_f32 ? 4 : 2);
+      q.stats = p.stats + (size_t)n * p.Cout_store * 2;
+      rc = launch_conv(L.ntaps, a.stride, cfg, q, e->stream);
+    }
+  } else {
+    rc = launch_conv(L.ntaps, a.stride, cfg, p, e->stream);
+  }
+  if (rc != 0) SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: bad cfg", L.name.c_str());
   prof_end(e);
   return 0;
 }
 
 // scratch for GroupNorm statistics: sums (double [N][G][2]) + scale/shift (float [N][C] each), allocated from the arena
 static int op_groupnorm_raw(sdm_ctx* e, const void* in0, const void* in1, int C0, int C1, int in_f32, int N, int HW, int groups,
-                            const float* gamma, const float* beta, float eps, int silu, half_t* out) {
+                            const float* gamma, const float* beta, float eps, int silu, half_t* out, const double* st0 = nullptr,
+                            const double* st1 = nullptr, bool have_stats = false) {
   const int C = C0 + C1;
   if (C % 8 || (C / groups) * groups != C || C0 % 8) SDM_FAIL(e, SDM_ERR_INVALID, "groupnorm: bad channels %d+%d", C0, C1);
   T scratch = talloc(e, 1, 1, 1, (int)(((size_t)N * groups * 2 * 8 + (size_t)N * C * 8 + 3) / 4), 1);
@@ -585,12 +629,17 @@ static int op_groupnorm_raw(sdm_ctx* e, const void* in0, const void* in1, int C0
     ppb = rup(ppb, slots);
     const int nb = sdm_cdiv(HW, ppb);
     const double bytes_in = (double)N * HW * C * (in_f32 ? 4 : 2);
-    SDM_CHECK_DEV(e, dev_memset(sums, 0, (size_t)N * groups * 16, e->stream));
-    prof_begin(e, "gn_stats", 0, bytes_in);
-    SDM_LAUNCH(gn_stats_kernel, dim3(nb, N), dim3(threads), (size_t)2 * C * 4, e->stream, s, sums, groups, ppb);
-    prof_end(e);
-    SDM_LAUNCH(gn_finalize_kernel, dim3(sdm_cdiv(N * C, 256)), dim3(256), 0, e->stream, (const double*)sums, gamma, beta, scale, shift, N, C,
-               groups, (long)HW * (C / groups), eps);
+    if (have_stats) {
+      SDM_LAUNCH(gn_finalize_ch_kernel, dim3(sdm_cdiv(N * C, 256)), dim3(256), 0, e->stream, st0, st1, C0, C1, gamma, beta, scale, shift, N, groups,
+                 (long)HW, eps);
+    } else {
+      SDM_CHECK_DEV(e, dev_memset(sums, 0, (size_t)N * groups * 16, e->stream));
+      prof_begin(e, "gn_stats", 0, bytes_in);
+      SDM_LAUNCH(gn_stats_kernel, dim3(nb, N), dim3(threads), (size_t)2 * C * 4, e->stream, s, sums, groups, ppb);
+      prof_end(e);
+      SDM_LAUNCH(gn_finalize_kernel, dim3(sdm_cdiv(N * C, 256)), dim3(256), 0, e->stream, (const double*)sums, gamma, beta, scale, shift, N, C,
+                 groups, (long)HW * (C / groups), eps);
+    }
     prof_begin(e, "gn_apply", 0, bytes_in + (double)N * HW * C * 2);
     SDM_LAUNCH(gn_apply_kernel, dim3(nb, N), dim3(threads), 0, e->stream, s, (const float*)scale, (const float*)shift, out, silu, ppb);
     prof_end(e);
@@ -603,8 +652,9 @@ static int op_gn(sdm_ctx* e, const NormL& n, const T& x, const T* x2, int silu, 
   const int C = x.C + (x2 ? x2->C : 0);
   if (C != n.C) SDM_FAIL(e, SDM_ERR_INVALID, "groupnorm: C %d != %d", C, n.C);
   *out = talloc(e, x.N, x.H, x.W, C, 0);
+  const bool hs = x.sbytes && (!x2 || x2->sbytes);     // statistics already produced by the conv epilogue(s)
   return op_groupnorm_raw(e, x.p, x2 ? x2->p : nullptr, x.C, x2 ? x2->C : 0, x.f32, x.N, x.H * x.W, e->cfg.groups, n.g, n.b, eps, silu,
-                          (half_t*)out->p);
+                          (half_t*)out->p, x.stats, x2 ? x2->stats : nullptr, hs);
 }
 
 static int op_ln(sdm_ctx* e, const NormL& n, const T& x, float eps, T* out) {
@@ -644,7 +694,7 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
     const double flops = 4.0 * B * heads * (double)Lq * Lk * D;
     const double bytes = 2.0 * B * heads * D * (2.0 * Lq + 2.0 * Lk);
     if (D == 64) {
-      prof_begin(e, "attn_d64", flops, bytes);
+      prof_begin(e, "attn_d64", flops, bytes, "B=" + std::to_string(B) + " h=" + std::to_string(heads) + " Lq=" + std::to_string(Lq) + " Lk=" + std::to_string(Lk));
       SDM_LAUNCH(attn_d64_kernel, dim3(sdm_cdiv(Lq, 128), heads, B), dim3(256), ATTN64_SMEM, e->stream, p);
       prof_end(e);
     } else {
@@ -664,11 +714,12 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
 // blocks
 // ------------------------------------------------------------------------------------------------
 static int conv_simple(sdm_ctx* e, int layer, const T& in, T* out, int Cout_store, int out_f32, int stride = 1, int pad_mode = 0, int up = 0,
-                       const T* res = nullptr, float scale = 1.0f) {
+                       const T* res = nullptr, float scale = 1.0f, bool want_stats = false) {
   const ConvL& L = e->convs[layer];
   int Ho = in.H << up, Wo = in.W << up;
   if (stride == 2) { Ho /= 2; Wo /= 2; }
   *out = talloc(e, in.N, Ho, Wo, Cout_store, out_f32);
+  if (want_stats) TRY(tstats(e, *out));
   ConvArgs a; a.in0 = &in; a.out = out; a.stride = stride; a.pad_mode = pad_mode; a.up = up; a.res = res; a.out_scale = scale;
   return op_conv(e, L, a);
 }
@@ -679,6 +730,7 @@ static int resblock(sdm_ctx* e, const ResB& r, const T& x, const T* x2, float ep
   T h, h1, h2;
   TRY(op_gn(e, e->norms[r.norm1], x, x2, 1, eps, &h));
   h1 = talloc(e, x.N, x.H, x.W, r.cout, 0);
+  TRY(tstats(e, h1));
   {
     ConvArgs a; a.in0 = &h; a.out = &h1;
     if (r.temb >= 0) { a.bias_override = e->tembs[r.temb].table; a.bias_sel = e->d_bias_sel; }
@@ -697,6 +749,7 @@ static int resblock(sdm_ctx* e, const ResB& r, const T& x, const T* x2, float ep
     SDM_FAIL(e, SDM_ERR_INVALID, "resblock: concat input without shortcut");
   }
   *out = talloc(e, x.N, x.H, x.W, r.cout, sf);
+  TRY(tstats(e, *out));
   {
     ConvArgs a; a.in0 = &h2; a.out = out; a.res = resid;
     TRY(op_conv(e, e->convs[r.conv2], a));
@@ -706,8 +759,9 @@ static int resblock(sdm_ctx* e, const ResB& r, const T& x, const T* x2, float ep
   return 0;
 }
 
-static int linear(sdm_ctx* e, int layer, const T& in, T* out, int Cout, int out_f32, const T* res = nullptr) {
+static int linear(sdm_ctx* e, int layer, const T& in, T* out, int Cout, int out_f32, const T* res = nullptr, bool want_stats = false) {
   *out = talloc(e, in.N, in.H, in.W, Cout, out_f32);
+  if (want_stats) TRY(tstats(e, *out));
   ConvArgs a; a.in0 = &in; a.out = out; a.res = res;
   return op_conv(e, e->convs[layer], a);
 }
@@ -724,7 +778,7 @@ static int vae_attention(sdm_ctx* e, const VaeAttnB& a, const T& x, T* out) {
   TRY(op_attention_raw(e, q, 3 * a.C, q ? q + a.C : nullptr, 3 * a.C, q ? q + 2 * a.C : nullptr, 3 * a.C, nullptr, x.N, 1, L, L, a.C,
                        (half_t*)ao.p, a.C));
   tfree(e, qkv);
-  TRY(linear(e, a.out, ao, out, a.C, e->cfg.stream_f32, &x));
+  TRY(linear(e, a.out, ao, out, a.C, e->cfg.stream_f32, &x, true));
   tfree(e, ao);
   return 0;
 }
@@ -768,7 +822,7 @@ static int transformer(sdm_ctx* e, const TfB& t, const T& x, const T& ehs, const
   tfree(e, n);
   TRY(linear(e, t.ff2, f, &h2, C, sf, &h));
   tfree(e, f); tfree(e, h);
-  TRY(linear(e, t.proj_out, h2, out, C, sf, &x));
+  TRY(linear(e, t.proj_out, h2, out, C, sf, &x, true));
   tfree(e, h2);
   return 0;
 }
@@ -868,10 +922,10 @@ static int prepare_variants(sdm_ctx* e, int B, const int32_t* is_trans, const fl
 static int vae_encode(sdm_ctx* e, const T& x16, T* moments) {
   const float eps = e->cfg.vae_eps;
   T h, t;
-  TRY(conv_simple(e, e->enc_conv_in, x16, &h, e->cfg.vae_channels[0], e->cfg.stream_f32));
+  TRY(conv_simple(e, e->enc_conv_in, x16, &h, e->cfg.vae_channels[0], e->cfg.stream_f32, 1, 0, 0, nullptr, 1.0f, true));
   for (int i = 0; i < 4; ++i) {
     for (auto& r : e->enc_res[i]) { TRY(resblock(e, r, h, nullptr, eps, &t)); tfree(e, h); h = t; }
-    if (i < 3) { TRY(conv_simple(e, e->enc_down[i], h, &t, e->cfg.vae_channels[i], e->cfg.stream_f32, 2, 1)); tfree(e, h); h = t; }
+    if (i < 3) { TRY(conv_simple(e, e->enc_down[i], h, &t, e->cfg.vae_channels[i], e->cfg.stream_f32, 2, 1, 0, nullptr, 1.0f, true)); tfree(e, h); h = t; }
   }
   TRY(resblock(e, e->enc_mid0, h, nullptr, eps, &t)); tfree(e, h); h = t;
   TRY(vae_attention(e, e->enc_attn, h, &t)); tfree(e, h); h = t;
@@ -884,13 +938,13 @@ static int vae_encode(sdm_ctx* e, const T& x16, T* moments) {
 static int vae_decode(sdm_ctx* e, const T& z, T* dec) {
   const float eps = e->cfg.vae_eps;
   T h, t;
-  TRY(conv_simple(e, e->dec_conv_in, z, &h, e->cfg.vae_channels[3], e->cfg.stream_f32));
+  TRY(conv_simple(e, e->dec_conv_in, z, &h, e->cfg.vae_channels[3], e->cfg.stream_f32, 1, 0, 0, nullptr, 1.0f, true));
   TRY(resblock(e, e->dec_mid0, h, nullptr, eps, &t)); tfree(e, h); h = t;
   TRY(vae_attention(e, e->dec_attn, h, &t)); tfree(e, h); h = t;
   TRY(resblock(e, e->dec_mid1, h, nullptr, eps, &t)); tfree(e, h); h = t;
   for (int i = 0; i < 4; ++i) {
     for (auto& r : e->dec_res[i]) { TRY(resblock(e, r, h, nullptr, eps, &t)); tfree(e, h); h = t; }
-    if (i < 3) { TRY(conv_simple(e, e->dec_up[i], h, &t, e->cfg.vae_channels[3 - i], e->cfg.stream_f32, 1, 0, 1)); tfree(e, h); h = t; }
+    if (i < 3) { TRY(conv_simple(e, e->dec_up[i], h, &t, e->cfg.vae_channels[3 - i], e->cfg.stream_f32, 1, 0, 1, nullptr, 1.0f, true)); tfree(e, h); h = t; }
   }
   TRY(op_gn(e, e->norms[e->dec_norm_out], h, nullptr, 1, eps, &t)); tfree(e, h); h = t;
   TRY(conv_simple(e, e->dec_conv_out, h, dec, 4, 1)); tfree(e, h);
@@ -903,7 +957,7 @@ static int unet_forward(sdm_ctx* e, const T& uin, const T& ehs, float* const* bi
   const int sf = c.stream_f32;
   std::vector<T> skips;
   T h, t;
-  TRY(conv_simple(e, e->u_conv_in, uin, &h, c.unet_channels[0], sf));
+  TRY(conv_simple(e, e->u_conv_in, uin, &h, c.unet_channels[0], sf, 1, 0, 0, nullptr, 1.0f, true));
   skips.push_back(h);
   for (int i = 0; i < 4; ++i) {
     for (size_t j = 0; j < e->u_down_res[i].size(); ++j) {
@@ -917,7 +971,7 @@ static int unet_forward(sdm_ctx* e, const T& uin, const T& ehs, float* const* bi
       skips.push_back(h);
     }
     if (i < 3) {
-      TRY(conv_simple(e, e->u_down_ds[i], h, &t, c.unet_channels[i], sf, 2, 0));
+      TRY(conv_simple(e, e->u_down_ds[i], h, &t, c.unet_channels[i], sf, 2, 0, 0, nullptr, 1.0f, true));
       h = t;
       skips.push_back(h);
     }
@@ -936,7 +990,7 @@ static int unet_forward(sdm_ctx* e, const T& uin, const T& ehs, float* const* bi
         tfree(e, h); h = t;
       }
     }
-    if (i < 3) { TRY(conv_simple(e, e->u_up_us[i], h, &t, c.unet_channels[3 - i], sf, 1, 0, 1)); tfree(e, h); h = t; }
+    if (i < 3) { TRY(conv_simple(e, e->u_up_us[i], h, &t, c.unet_channels[3 - i], sf, 1, 0, 1, nullptr, 1.0f, true)); tfree(e, h); h = t; }
   }
   TRY(op_gn(e, e->norms[e->u_norm_out], h, nullptr, 1, eps, &t)); tfree(e, h); h = t;
   // label_latent / scaling_factor (meta_arch.py:254) folded into the conv_out epilogue
@@ -1313,9 +1367,13 @@ int sdm_synchronize(sdm_ctx* e) {
   if (hipEventElapsedTime(&ms, e->ev0, e->ev1) == hipSuccess) e->last_ms = ms;
   if (!e->prof.empty()) {
     std::map<std::string, sdm_ctx::ProfAgg> agg;
+    e->prof_dump = "kernel,ms,gflop,mbytes,desc\n";
     for (auto& r : e->prof) {
       float t = 0.f;
       (void)hipEventElapsedTime(&t, r.e0, r.e1);
+      char line[512];
+      snprintf(line, sizeof(line), "%s,%.4f,%.3f,%.3f,%s\n", r.name.c_str(), t, r.flops * 1e-9, r.bytes * 1e-6, r.desc.c_str());
+      e->prof_dump += line;
       auto& a = agg[r.name];
       a.name = r.name; a.ms += t; a.n += 1; a.flops += r.flops; a.bytes += r.bytes;
       (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
@@ -1332,6 +1390,7 @@ float sdm_last_forward_ms(sdm_ctx* e) { return e ? e->last_ms : 0.f; }
 
 int sdm_profile_enable(sdm_ctx* e, int on) { if (!e) return SDM_ERR_INVALID; e->prof_on = on != 0; return SDM_OK; }
 int sdm_profile_count(sdm_ctx* e) { return e ? (int)e->prof_agg.size() : 0; }
+const char* sdm_profile_dump(sdm_ctx* e) { return e ? e->prof_dump.c_str() : ""; }
 int sdm_profile_get(sdm_ctx* e, int i, const char** name, float* ms, int64_t* launches, double* flops, double* bytes) {
   if (!e || i < 0 || i >= (int)e->prof_agg.size()) return SDM_ERR_INVALID;
   auto& a = e->prof_agg[(size_t)i];

@@ -57,7 +57,7 @@ EXPORTS = [
     "sdm_default_config", "sdm_create", "sdm_destroy", "sdm_last_error", "sdm_load_tensor", "sdm_finalize_weights",
     "sdm_weight_stats", "sdm_missing_key", "sdm_weight_blob_bytes", "sdm_export_weight_blob", "sdm_import_weight_blob",
     "sdm_host_blob_bytes", "sdm_export_host_blob", "sdm_import_host_blob", "sdm_forward", "sdm_apply_matte",
-    "sdm_synchronize", "sdm_last_forward_ms", "sdm_profile_enable", "sdm_profile_count", "sdm_profile_get",
+    "sdm_synchronize", "sdm_last_forward_ms", "sdm_profile_enable", "sdm_profile_count", "sdm_profile_get", "sdm_profile_dump",
     "sdm_op_conv", "sdm_conv_num_cfgs", "sdm_op_groupnorm", "sdm_op_layernorm", "sdm_op_attention", "sdm_op_resize_aa",
     "sdm_op_mask_bias",
 ]
@@ -90,6 +90,7 @@ class Bindings:
             "sdm_last_forward_ms": (f32, [vp]),
             "sdm_profile_enable": (i32, [vp, i32]),
             "sdm_profile_count": (i32, [vp]),
+            "sdm_profile_dump": (C.c_char_p, [vp]),
             "sdm_profile_get": (i32, [vp, i32, C.POINTER(C.c_char_p), C.POINTER(f32), C.POINTER(i64), C.POINTER(C.c_double),
                                       C.POINTER(C.c_double)]),
             "sdm_op_conv": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, i32,
@@ -243,6 +244,9 @@ class Engine:
             self.lib.sdm_profile_get(self.h, i, C.byref(name), C.byref(ms), C.byref(n), C.byref(fl), C.byref(by))
             res[name.value.decode()] = {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
         return res
+
+    def profile_dump(self):
+        return self.lib.sdm_profile_dump(self.h).decode()
 
     # ---- single operators (parity tests) ---------------------------------------------------------
     def op_conv(self, x0, w, bias=None, x1=None, stride=1, pad_mode=0, up=0, res=None, geglu=False, out_f32=False, out_scale=1.0,

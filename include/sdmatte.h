@@ -117,6 +117,8 @@ float sdm_last_forward_ms(sdm_ctx* ctx);
  * `n` (name, ms, launches) triples.  Adds an event pair per launch - not for the timed bench loop. */
 int sdm_profile_enable(sdm_ctx* ctx, int on);
 int sdm_profile_count(sdm_ctx* ctx);
+/* CSV (kernel,ms,gflop,mbytes,desc), one line per launch of the last profiled forward. */
+const char* sdm_profile_dump(sdm_ctx* ctx);
 int sdm_profile_get(sdm_ctx* ctx, int i, const char** name, float* ms, int64_t* launches, double* flops, double* bytes);
 
 /* ---- single-operator entry points (parity tests call the same kernels the engine uses) --------------
