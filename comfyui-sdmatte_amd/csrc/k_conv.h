@@ -45,8 +45,9 @@ struct ConvParams {
   const void* res; int res_f32; int res_C;
   int epi;                              // 0: linear, 1: GEGLU (cols come in [u32|g32] groups of 64)
   float out_scale;
-  double* stats;                        // optional [N][Cout_store][2]: per-(image,channel) sum / sum of squares of the stored
-                                        // values (fused GroupNorm statistics of the NEXT layer); NTAPS==9 or one image per launch
+  float* stats;                         // optional [N][gridDim.x*WM][Cout_store][2]: per-(image, wave row-tile, channel) partial
+                                        // sum / sum of squares of the stored values = fused GroupNorm statistics of the NEXT
+                                        // layer (reduced by gn_reduce_partials_kernel); NTAPS==9 or one image per launch
 };
 
 template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN>
@@ -322,18 +323,22 @@ conv_mfma_kernel(ConvParams p) {
     }
     SDM_WAVE_SYNC();
   }
-  // ---- fused GroupNorm statistics of the consumer: per-(image, channel) sum / sumsq of this tile ----
+  // ---- fused GroupNorm statistics of the consumer: one partial row per (tile, wave-row); plain stores, no atomics ----
   if (p.stats) {
-    // lanes {l, l+LPR, l+2*LPR, ...} own the same 4 channels: fold them, then one fp64 atomic per channel per wave
+    // lanes {l, l+LPR, l+2*LPR, ...} own the same 4 channels: fold them
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
 #pragma unroll
       for (int m = LPR; m < 64; m <<= 1) { ssum[e] += __shfl_xor(ssum[e], m); ssq[e] += __shfl_xor(ssq[e], m); }
     }
     if (lane < LPR && colok && oc < p.Cout_valid) {
-      double* st = p.stats + ((size_t)img * p.Cout_store + p.out_ch_off + oc) * 2;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { atomicAdd(st + 2 * e, (double)ssum[e]); atomicAdd(st + 2 * e + 1, (double)ssq[e]); }
+      const size_t prow = (size_t)img * (gridDim.x * WM) + (size_t)blockIdx.x * WM + wm;
+      float* st = p.stats + (prow * p.Cout_store + p.out_ch_off + oc) * 2;
+      f32x4 o0, o1;
+      o0[0] = ssum[0]; o0[1] = ssq[0]; o0[2] = ssum[1]; o0[3] = ssq[1];
+      o1[0] = ssum[2]; o1[1] = ssq[2]; o1[2] = ssum[3]; o1[3] = ssq[3];
+      *(f32x4*)st = o0;
+      *(f32x4*)(st + 4) = o1;
     }
   }
 }

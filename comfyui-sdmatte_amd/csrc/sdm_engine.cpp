@@ -83,10 +83,10 @@ static void launch_conv_t(const ConvParams& p, void* stream) {
   }
 }
 
-struct ConvCfgInfo { int TH, TW, BN, KC; };
-static const ConvCfgInfo kCfg3s1[] = {{8, 32, 128, 16}, {4, 32, 64, 32}, {8, 8, 64, 16}};
-static const ConvCfgInfo kCfg3s2[] = {{4, 32, 64, 16}, {8, 8, 64, 16}};
-static const ConvCfgInfo kCfg1[] = {{8, 32, 128, 64}, {4, 32, 64, 64}, {8, 8, 64, 64}, {8, 8, 64, 16}};
+struct ConvCfgInfo { int TH, TW, BN, KC, WM; };
+static const ConvCfgInfo kCfg3s1[] = {{8, 32, 128, 16, 2}, {4, 32, 64, 32, 4}, {8, 8, 64, 16, 2}};
+static const ConvCfgInfo kCfg3s2[] = {{4, 32, 64, 16, 4}, {8, 8, 64, 16, 2}};
+static const ConvCfgInfo kCfg1[] = {{8, 32, 128, 64, 2}, {4, 32, 64, 64, 4}, {8, 8, 64, 64, 2}, {8, 8, 64, 16, 2}};
 
 static int conv_num_cfgs(int ntaps, int stride) { return ntaps == 9 ? (stride == 1 ? 3 : 2) : 4; }
 static const ConvCfgInfo* conv_cfg_table(int ntaps, int stride) { return ntaps == 9 ? (stride == 1 ? kCfg3s1 : kCfg3s2) : kCfg1; }
@@ -175,7 +175,9 @@ struct T {  // NHWC activation tensor living in the arena
   size_t off = 0, bytes = 0;
   void* p = nullptr;
   int N = 0, H = 0, W = 0, C = 0, f32 = 0;
-  double* stats = nullptr;      // optional per-(image,channel) {sum, sumsq}, filled by the producing conv epilogue
+  bool want_stats = false;      // the producing conv should emit fused GroupNorm statistics
+  float* stats = nullptr;       // [N][srows][C][2] partial {sum, sumsq} rows written by the producing conv epilogue
+  int srows = 0;
   size_t soff = 0, sbytes = 0;
   long rows() const { return (long)N * H * W; }
 };
@@ -506,13 +508,9 @@ static void tfree_raw(sdm_ctx* e, size_t off, size_t sz) {
   else e->freelist[off] = sz;
 }
 
-// attach a zero-initialised statistics buffer to t (filled by the conv that produces t)
-static int tstats(sdm_ctx* e, T& t) {
-  T s = talloc(e, 1, 1, 1, t.N * t.C * 4, 1);        // N*C*2 doubles
-  t.soff = s.off; t.sbytes = s.bytes; t.stats = (double*)s.p;
-  if (!e->dry) SDM_CHECK_DEV(e, dev_memset(s.p, 0, (size_t)t.N * t.C * 16, e->stream));
-  return 0;
-}
+// mark t so that the conv producing it also emits the GroupNorm statistics of its consumer (op_conv allocates the
+// partial-row buffer once the tile configuration, hence the number of rows, is known)
+static int tstats(sdm_ctx* e, T& t) { (void)e; t.want_stats = true; return 0; }
 
 static void arena_reset(sdm_ctx* e) { e->freelist.clear(); e->arena_top = 0; }
 
@@ -572,11 +570,17 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
   int cfg = a.force_cfg >= 0 ? a.force_cfg : conv_pick_cfg(L.ntaps, a.stride, p);
   if (cfg < 0 || cfg >= conv_num_cfgs(L.ntaps, a.stride) || !conv_cfg_ok(conv_cfg_table(L.ntaps, a.stride)[cfg], p))
     SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: no tile configuration for Cin=%d+%d (cfg %d)", L.name.c_str(), p.C0, p.C1, cfg);
-  if (e->dry) return 0;
-  if (a.out->stats) {
+  if (a.out->want_stats) {
     if (L.geglu || a.out_ch_off) SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: fused statistics unsupported with this epilogue", L.name.c_str());
+    const ConvCfgInfo& ci = conv_cfg_table(L.ntaps, a.stride)[cfg];
+    const long tiles = (L.ntaps == 9) ? (long)sdm_cdiv(p.Hout, ci.TH) * sdm_cdiv(p.Wout, ci.TW)
+                                      : ((long)p.Hout * p.Wout + ci.TH * ci.TW - 1) / (ci.TH * ci.TW);
+    a.out->srows = (int)(tiles * ci.WM);
+    T sb = talloc(e, 1, 1, 1, (int)((size_t)p.N * a.out->srows * a.out->C * 2), 1);
+    a.out->soff = sb.off; a.out->sbytes = sb.bytes; a.out->stats = (float*)sb.p;
     p.stats = a.out->stats;
   }
+  if (e->dry) return 0;
   const double flops = 2.0 * (double)p.M * L.O * L.I * L.ntaps;
   const double bytes = (double)a.in0->rows() * L.Cin_pad * (p.in_f32 ? 4 : 2) + (double)p.M * p.Cout_valid * (p.out_f32 ? 4 : 2) +
                        (double)L.Cin_pad * L.ntaps * L.Cout_pad * 2 + (a.res ? (double)p.M * p.Cout_valid * (p.res_f32 ? 4 : 2) : 0.0);
@@ -599,7 +603,7 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
       if (p.in1) q.in1 = (const unsigned char*)p.in1 + (size_t)n * rows * p.C1 * (p.in_f32 ? 4 : 2);
       q.out = (unsigned char*)p.out + (size_t)n * rows * p.Cout_store * (p.out_f32 ? 4 : 2);
       if (p.res) q.res = (const unsigned char*)p.res + (size_t)n * rows * p.res_C * (p.res_f32 ? 4 : 2);
-      q.stats = p.stats + (size_t)n * p.Cout_store * 2;
+      q.stats = p.stats + (size_t)n * a.out->srows * p.Cout_store * 2;
       rc = launch_conv(L.ntaps, a.stride, cfg, q, e->stream);
     }
   } else {
@@ -612,14 +616,16 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
 
 // scratch for GroupNorm statistics: sums (double [N][G][2]) + scale/shift (float [N][C] each), allocated from the arena
 static int op_groupnorm_raw(sdm_ctx* e, const void* in0, const void* in1, int C0, int C1, int in_f32, int N, int HW, int groups,
-                            const float* gamma, const float* beta, float eps, int silu, half_t* out, const double* st0 = nullptr,
-                            const double* st1 = nullptr, bool have_stats = false) {
+                            const float* gamma, const float* beta, float eps, int silu, half_t* out, const float* st0 = nullptr,
+                            int rows0 = 0, const float* st1 = nullptr, int rows1 = 0, bool have_stats = false) {
   const int C = C0 + C1;
   if (C % 8 || (C / groups) * groups != C || C0 % 8) SDM_FAIL(e, SDM_ERR_INVALID, "groupnorm: bad channels %d+%d", C0, C1);
-  T scratch = talloc(e, 1, 1, 1, (int)(((size_t)N * groups * 2 * 8 + (size_t)N * C * 8 + 3) / 4), 1);
+  // scratch: [N][groups][2] doubles (stats kernel path) or [N][C][2] doubles (fused path), then scale/shift [N][C] floats each
+  const size_t sum_bytes = (size_t)N * std::max(groups, C) * 16;
+  T scratch = talloc(e, 1, 1, 1, (int)((sum_bytes + (size_t)N * C * 8 + 3) / 4), 1);
   if (!e->dry) {
     double* sums = (double*)scratch.p;
-    float* scale = (float*)((unsigned char*)scratch.p + (size_t)N * groups * 16);
+    float* scale = (float*)((unsigned char*)scratch.p + sum_bytes);
     float* shift = scale + (size_t)N * C;
     GnSrc s; s.in0 = in0; s.in1 = in1; s.C0 = C0; s.C1 = C1; s.in_f32 = in_f32; s.HW = HW;
     const int CV = C / 8;
@@ -630,8 +636,15 @@ static int op_groupnorm_raw(sdm_ctx* e, const void* in0, const void* in1, int C0
     const int nb = sdm_cdiv(HW, ppb);
     const double bytes_in = (double)N * HW * C * (in_f32 ? 4 : 2);
     if (have_stats) {
-      SDM_LAUNCH(gn_finalize_ch_kernel, dim3(sdm_cdiv(N * C, 256)), dim3(256), 0, e->stream, st0, st1, C0, C1, gamma, beta, scale, shift, N, groups,
-                 (long)HW, eps);
+      SDM_CHECK_DEV(e, dev_memset(sums, 0, (size_t)N * C * 16, e->stream));
+      double* s0 = sums;
+      double* s1 = sums + (size_t)N * C0 * 2;
+      prof_begin(e, "gn_reduce", 0, ((double)rows0 * C0 + (double)rows1 * C1) * N * 8);
+      SDM_LAUNCH(gn_reduce_partials_kernel, dim3(sdm_cdiv(C0, 32), N, std::max(1, std::min(16, rows0 / 64))), dim3(256), 0, e->stream, st0, s0, rows0, C0);
+      if (C1) SDM_LAUNCH(gn_reduce_partials_kernel, dim3(sdm_cdiv(C1, 32), N, std::max(1, std::min(16, rows1 / 64))), dim3(256), 0, e->stream, st1, s1, rows1, C1);
+      prof_end(e);
+      SDM_LAUNCH(gn_finalize_ch_kernel, dim3(sdm_cdiv(N * C, 256)), dim3(256), 0, e->stream, (const double*)s0, (const double*)s1, C0, C1, gamma, beta,
+                 scale, shift, N, groups, (long)HW, eps);
     } else {
       SDM_CHECK_DEV(e, dev_memset(sums, 0, (size_t)N * groups * 16, e->stream));
       prof_begin(e, "gn_stats", 0, bytes_in);
@@ -654,7 +667,7 @@ static int op_gn(sdm_ctx* e, const NormL& n, const T& x, const T* x2, int silu, 
   *out = talloc(e, x.N, x.H, x.W, C, 0);
   const bool hs = x.sbytes && (!x2 || x2->sbytes);     // statistics already produced by the conv epilogue(s)
   return op_groupnorm_raw(e, x.p, x2 ? x2->p : nullptr, x.C, x2 ? x2->C : 0, x.f32, x.N, x.H * x.W, e->cfg.groups, n.g, n.b, eps, silu,
-                          (half_t*)out->p, x.stats, x2 ? x2->stats : nullptr, hs);
+                          (half_t*)out->p, x.stats, x.srows, x2 ? x2->stats : nullptr, x2 ? x2->srows : 0, hs);
 }
 
 static int op_ln(sdm_ctx* e, const NormL& n, const T& x, float eps, T* out) {
