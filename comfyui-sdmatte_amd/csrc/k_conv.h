@@ -210,22 +210,27 @@ conv_mfma_kernel(ConvParams p) {
     write_lds();
     __syncthreads();
     if (c0 + KC < Cin) issue_loads(c0 + KC);
-    // ---- MFMA over taps and K sub-steps ----
-#pragma unroll
-    for (int tap = 0; tap < NTAPS; ++tap) {
+    // ---- MFMA over taps and K sub-steps; fragment reads are software-pipelined one step ahead ----
+    constexpr int NSTEP = NTAPS * (KC / 16);
+    f16x8 fa[2][MT], fb[2][NTL];
+    auto load_frags = [&](int step, int buf) {
+      const int tap = step / (KC / 16), ks = step % (KC / 16);
       const int toff = (NTAPS == 9) ? ((tap / 3) * HPW + (tap % 3)) * PITCH : 0;
 #pragma unroll
-      for (int ks = 0; ks < KC / 16; ++ks) {
-        f16x8 a[MT], b[NTL];
+      for (int i = 0; i < MT; ++i) fa[buf][i] = *(const f16x8*)(As + abase[i] + toff + ks * 32);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) a[i] = *(const f16x8*)(As + abase[i] + toff + ks * 32);
+      for (int j = 0; j < NTL; ++j) fb[buf][j] = *(const f16x8*)(Bs + tap * BN * PITCH + bbase[j] + ks * 32);
+    };
+    load_frags(0, 0);
 #pragma unroll
-        for (int j = 0; j < NTL; ++j) b[j] = *(const f16x8*)(Bs + tap * BN * PITCH + bbase[j] + ks * 32);
+    for (int step = 0; step < NSTEP; ++step) {
+      if (step + 1 < NSTEP) load_frags(step + 1, (step + 1) & 1);
+      SDM_SCHED_FENCE();
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int j = 0; j < NTL; ++j) acc[i][j] = SDM_MFMA_32x32x16_F16(a[i], b[j], acc[i][j]);
-      }
+        for (int j = 0; j < NTL; ++j) acc[i][j] = SDM_MFMA_32x32x16_F16(fa[step & 1][i], fb[step & 1][j], acc[i][j]);
+      SDM_SCHED_FENCE();
     }
   }
 

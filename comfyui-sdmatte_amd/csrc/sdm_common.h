@@ -27,6 +27,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
   emu::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); })
 #define SDM_DEV_INLINE static inline
 #define SDM_WAVE_SYNC() emu::wave_barrier()
+#define SDM_SCHED_FENCE() ((void)0)
 static inline float sdm_exp2(float x) { return exp2f(x); }
 static inline float sdm_rcp(float x) { return 1.0f / x; }
 #else
@@ -39,6 +40,8 @@ static inline float sdm_rcp(float x) { return 1.0f / x; }
 // LDS operations of ONE wave execute in issue order, so lanes of a wave may exchange data through a wave-private LDS
 // region without s_barrier; only the compiler must not reorder the accesses.
 #define SDM_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+// pin the instruction schedule at this point (used to keep hand-pipelined LDS fragment reads ahead of the MFMAs)
+#define SDM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 __device__ __forceinline__ float sdm_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float sdm_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 #endif
