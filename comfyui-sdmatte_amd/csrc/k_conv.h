@@ -25,6 +25,10 @@
 #pragma once
 #include "sdm_common.h"
 
+#ifndef SDM_CONV_PIPE
+#define SDM_CONV_PIPE 0
+#endif
+
 struct ConvParams {
   const void* in0; const void* in1;     // NHWC sources (channel concat: in0 then in1); in1 may be null
   int C0, C1;                           // channel counts (row strides) of the sources; (C0+C1) % KC == 0
@@ -114,17 +118,17 @@ conv_mfma_kernel(ConvParams p) {
 #pragma unroll
   for (int j = 0; j < NTL; ++j) bbase[j] = (wn * WTN + j * 32 + (lane & 31)) * PITCH + (lane >> 5) * 16;
 
-  // ---- K-loop invariant staging descriptors (hoisted: no address math inside the chunk loop) ----
-  // A vector v = tid + i*NT -> (halo pixel hp, 8-channel part); a_pix = pixel index inside the batch (-1: zero fill)
-  int a_pix[A_PER], a_part[A_PER], a_lds[A_PER];      // pixel indices < 2^31 (checked by the host)
+  // ---- K-loop invariant staging descriptors.  Vector v = tid + i*NT; everything except the A pixel index is affine in
+  //      the (compile-time) unrolled index i, so only a_pix[] is kept in registers. ----
+  static_assert(NT % KV == 0 && NT % (2 * BN) == 0, "staging decomposition: one thread keeps one (co, half) for every i");
+  const int a_part = (tid % KV) * 8;                 // channel offset inside the chunk (same for every i)
+  const int a_hp0 = tid / KV;                        // halo pixel of vector i: a_hp0 + i*(NT/KV)
+  int a_pix[A_PER];                                  // pixel index inside the batch (< 2^31, host-checked); -1: zero fill
 #pragma unroll
   for (int i = 0; i < A_PER; ++i) {
-    const int v = tid + i * NT;
-    const int hp = v / KV, part = v % KV;
-    a_part[i] = part * 8;
-    a_lds[i] = hp * PITCH + part * 16;
+    const int hp = a_hp0 + i * (NT / KV);
     a_pix[i] = -1;
-    if (v < A_VEC) {
+    if (tid + i * NT < A_VEC) {
       if (NTAPS == 9) {
         const int hy = hp / HPW, hx = hp % HPW;
         const int iy = oy0 * STRIDE + hy - p.pad_t, ix = ox0 * STRIDE + hx - p.pad_l;
@@ -133,20 +137,12 @@ conv_mfma_kernel(ConvParams p) {
         const long m = m0 + hp;
         if (m < p.M) a_pix[i] = (int)m;
       }
-    } else {
-      a_lds[i] = -1;
     }
   }
-  // B vector v -> (tap, co, 16-channel sub-chunk sc, half h) of the K16-packed weight tensor
-  int b_src[B_PER], b_lds[B_PER];
-#pragma unroll
-  for (int i = 0; i < B_PER; ++i) {
-    const int v = tid + i * NT;
-    const int h = v & 1, co = (v >> 1) % BN, rest = (v >> 1) / BN;
-    const int tap = rest % NTAPS, sc = rest / NTAPS;
-    b_lds[i] = (v < B_VEC) ? (tap * BN + co) * PITCH + (sc * 2 + h) * 16 : -1;
-    b_src[i] = (v < B_VEC && n0 + co < p.Cout_pad) ? ((sc * NTAPS + tap) * p.Cout_pad + n0 + co) * 16 + h * 8 : -1;
-  }
+  // B vector v -> (h = v&1, co = (v>>1)%BN, rest = (v>>1)/BN -> tap = rest%NTAPS, sc = rest/NTAPS) of the K16-packed weights
+  const int b_h = tid & 1, b_co = (tid >> 1) % BN, b_rest0 = (tid >> 1) / BN;
+  constexpr int B_RSTEP_NUM = NT / 2;                // (v>>1) advances by NT/2 per i
+  const bool b_ok = (n0 + b_co) < p.Cout_pad;
   const long b_chunk_stride = (long)(KC / 16) * NTAPS * p.Cout_pad * 16;
 
   // raw staging registers (the global loads of chunk k+1 are in flight while chunk k is multiplied)
@@ -159,7 +155,7 @@ conv_mfma_kernel(ConvParams p) {
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
       if (a_pix[i] >= 0) {
-        const size_t e = (size_t)a_pix[i] * Csrc + cc + a_part[i];
+        const size_t e = (size_t)a_pix[i] * Csrc + cc + a_part;
         if (IN_F32) {
           const f32x4* q = (const f32x4*)((const float*)src + e);
           a_raw[i][0] = q[0];
@@ -169,15 +165,19 @@ conv_mfma_kernel(ConvParams p) {
         }
       }
     }
-    const half_t* wsrc = p.w + (size_t)(c0 / KC) * b_chunk_stride;
+    const half_t* wsrc = p.w + (size_t)(c0 / KC) * b_chunk_stride + (size_t)(n0 + b_co) * 16 + b_h * 8;
 #pragma unroll
-    for (int i = 0; i < B_PER; ++i)
-      if (b_src[i] >= 0) b_raw[i] = *(const f16x8*)(wsrc + b_src[i]);
+    for (int i = 0; i < B_PER; ++i) {
+      const int lin = (tid >> 1) + i * B_RSTEP_NUM;          // = (v >> 1)
+      const int rest = (2 * BN >= NT) ? (lin / BN) : (b_rest0 + i * (NT / (2 * BN)));
+      const int tap = rest % NTAPS, sc = rest / NTAPS;
+      if (b_ok && (tid + i * NT) < B_VEC) b_raw[i] = *(const f16x8*)(wsrc + (size_t)(sc * NTAPS + tap) * p.Cout_pad * 16);
+    }
   };
   auto write_lds = [&]() {
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
-      if (a_lds[i] >= 0) {
+      if (tid + i * NT < A_VEC) {
         f16x8 val;
         if (a_pix[i] < 0) {
 #pragma unroll
@@ -188,18 +188,22 @@ conv_mfma_kernel(ConvParams p) {
         } else {
           val = __builtin_bit_cast(f16x8, a_raw[i][0]);
         }
-        *(f16x8*)(As + a_lds[i]) = val;
+        *(f16x8*)(As + (a_hp0 + i * (NT / KV)) * PITCH + (a_part * 2)) = val;
       }
     }
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
-      if (b_lds[i] >= 0) {
+      if ((tid + i * NT) < B_VEC) {
+        const int lin = (tid >> 1) + i * B_RSTEP_NUM;
+        const int rest = (2 * BN >= NT) ? (lin / BN) : (b_rest0 + i * (NT / (2 * BN)));
+        const int co = (2 * BN >= NT) ? (lin % BN) : b_co;
+        const int tap = rest % NTAPS, sc = rest / NTAPS;
         f16x8 val = b_raw[i];
-        if (b_src[i] < 0) {
+        if (!b_ok) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) val[e] = (half_t)0.0f;
         }
-        *(f16x8*)(Bs + b_lds[i]) = val;
+        *(f16x8*)(Bs + (tap * BN + co) * PITCH + (sc * 2 + b_h) * 16) = val;
       }
     }
   };
@@ -210,7 +214,10 @@ conv_mfma_kernel(ConvParams p) {
     write_lds();
     __syncthreads();
     if (c0 + KC < Cin) issue_loads(c0 + KC);
-    // ---- MFMA over taps and K sub-steps; fragment reads are software-pipelined one step ahead ----
+    // ---- MFMA over taps and K sub-steps ----
+#if SDM_CONV_PIPE
+    // fragment reads hand-pipelined one step ahead with a pinned schedule (costs ~40 VGPRs: only pays where occupancy
+    // is not register-limited)
     constexpr int NSTEP = NTAPS * (KC / 16);
     f16x8 fa[2][MT], fb[2][NTL];
     auto load_frags = [&](int step, int buf) {
@@ -232,6 +239,24 @@ conv_mfma_kernel(ConvParams p) {
         for (int j = 0; j < NTL; ++j) acc[i][j] = SDM_MFMA_32x32x16_F16(fa[step & 1][i], fb[step & 1][j], acc[i][j]);
       SDM_SCHED_FENCE();
     }
+#else
+#pragma unroll
+    for (int tap = 0; tap < NTAPS; ++tap) {
+      const int toff = (NTAPS == 9) ? ((tap / 3) * HPW + (tap % 3)) * PITCH : 0;
+#pragma unroll
+      for (int ks = 0; ks < KC / 16; ++ks) {
+        f16x8 a[MT], b[NTL];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a[i] = *(const f16x8*)(As + abase[i] + toff + ks * 32);
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) b[j] = *(const f16x8*)(Bs + tap * BN * PITCH + bbase[j] + ks * 32);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NTL; ++j) acc[i][j] = SDM_MFMA_32x32x16_F16(a[i], b[j], acc[i][j]);
+      }
+    }
+#endif
   }
 
   // ---- epilogue: per-wave PRIVATE fp32 staging tile (32 x WTN) in LDS -> coalesced row stores ----
