@@ -67,19 +67,24 @@ __global__ void __launch_bounds__(256) attn_d64_kernel(AttnParams p) {
 
   f16x8 kreg[2], vreg[2];
   float breg = 0.0f;
+  // all prefetch loads are UNCONDITIONAL (clamped rows): a conditional load makes hipcc wait vmcnt(0) per element.
+  // Keys >= Lk are neutralised by the -1e30 bias (K rows) and by the zero padding of V^T.
   auto prefetch = [&](int t) {
     const int k0 = t * 64;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int v = tid + i * 256;
       const int row = v >> 3, part = v & 7;
-      f16x8 z;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) z[e] = (half_t)0.0f;
-      kreg[i] = (k0 + row < p.Lk) ? *(const f16x8*)(kbase + (size_t)(k0 + row) * p.ldk + part * 8) : z;
+      int kr = k0 + row;
+      if (kr > p.Lk - 1) kr = p.Lk - 1;
+      kreg[i] = *(const f16x8*)(kbase + (size_t)kr * p.ldk + part * 8);
       vreg[i] = *(const f16x8*)(vbase + (size_t)row * p.ldvt + k0 + part * 8);
     }
-    if (tid < 64) breg = (k0 + tid < p.Lk) ? (bbase ? bbase[k0 + tid] : 0.0f) : SDM_NEG_BIG;
+    int kb = k0 + (tid & 63);
+    const bool inr = kb < p.Lk;
+    if (!inr) kb = p.Lk - 1;
+    const float bv = bbase ? bbase[kb] : 0.0f;
+    breg = inr ? bv : SDM_NEG_BIG;
   };
   prefetch(0);
 
@@ -235,11 +240,9 @@ __global__ void __launch_bounds__(512) attn_d512_kernel(AttnParams p) {
       const int v = tid + i * 512;
       {  // K tile: 32 keys x 64 vectors
         const int row = v >> 6, part = v & 63;
-        f16x8 z;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) z[e] = (half_t)0.0f;
-        const f16x8 kv = (k0 + row < p.Lk) ? *(const f16x8*)(kbase + (size_t)(k0 + row) * p.ldk + part * 8) : z;
-        *(f16x8*)(Ks + row * PKK + part * 16) = kv;
+        int kr = k0 + row;
+        if (kr > p.Lk - 1) kr = p.Lk - 1;                    // unconditional load; keys >= Lk are masked after QK^T
+        *(f16x8*)(Ks + row * PKK + part * 16) = *(const f16x8*)(kbase + (size_t)kr * p.ldk + part * 8);
       }
       {  // V^T tile: 512 d x 4 vectors (32 keys)
         const int row = v >> 2, part = v & 3;

@@ -26,7 +26,7 @@
 #include "sdm_common.h"
 
 #ifndef SDM_CONV_PIPE
-#define SDM_CONV_PIPE 0
+#define SDM_CONV_PIPE 1
 #endif
 
 struct ConvParams {
@@ -49,6 +49,8 @@ struct ConvParams {
   const void* res; int res_f32; int res_C;
   int epi;                              // 0: linear, 1: GEGLU (cols come in [u32|g32] groups of 64)
   float out_scale;
+  int ablate;                           // debug/bench only (sdm_bench_conv): 1 skip global loads, 2 skip LDS writes, 4 skip MFMA,
+                                        // 8 skip the epilogue stores -- after the first K-chunk; always 0 in the engine
   float* stats;                         // optional [N][gridDim.x*WM][Cout_store][2]: per-(image, wave row-tile, channel) partial
                                         // sum / sum of squares of the stored values = fused GroupNorm statistics of the NEXT
                                         // layer (reduced by gn_reduce_partials_kernel); NTAPS==9 or one image per launch
@@ -152,26 +154,29 @@ conv_mfma_kernel(ConvParams p) {
     const void* src = p.in0;
     int Csrc = p.C0, cc = c0;
     if (c0 >= p.C0) { src = p.in1; Csrc = p.C1; cc = c0 - p.C0; }
+    // NOTE: every load is UNCONDITIONAL (invalid / padded vectors read a clamped, valid address and are zeroed when they
+    // are written to LDS).  A conditional `if (ok) reg = load` makes hipcc branch around each load and drain vmcnt(0) per
+    // element: 12 serialized L2 round trips per K-chunk (measured: 4.9 us/chunk, 2x on the whole kernel).
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
-      if (a_pix[i] >= 0) {
-        const size_t e = (size_t)a_pix[i] * Csrc + cc + a_part;
-        if (IN_F32) {
-          const f32x4* q = (const f32x4*)((const float*)src + e);
-          a_raw[i][0] = q[0];
-          a_raw[i][IN_F32 ? 1 : 0] = q[1];
-        } else {
-          a_raw[i][0] = *(const f32x4*)((const half_t*)src + e);
-        }
+      const int pix = a_pix[i] >= 0 ? a_pix[i] : 0;
+      const size_t e = (size_t)pix * Csrc + cc + a_part;
+      if (IN_F32) {
+        const f32x4* q = (const f32x4*)((const float*)src + e);
+        a_raw[i][0] = q[0];
+        a_raw[i][IN_F32 ? 1 : 0] = q[1];
+      } else {
+        a_raw[i][0] = *(const f32x4*)((const half_t*)src + e);
       }
     }
-    const half_t* wsrc = p.w + (size_t)(c0 / KC) * b_chunk_stride + (size_t)(n0 + b_co) * 16 + b_h * 8;
+    const half_t* wsrc = p.w + (size_t)(c0 / KC) * b_chunk_stride + (size_t)(b_ok ? (n0 + b_co) : 0) * 16 + b_h * 8;
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
       const int lin = (tid >> 1) + i * B_RSTEP_NUM;          // = (v >> 1)
       const int rest = (2 * BN >= NT) ? (lin / BN) : (b_rest0 + i * (NT / (2 * BN)));
       const int tap = rest % NTAPS, sc = rest / NTAPS;
-      if (b_ok && (tid + i * NT) < B_VEC) b_raw[i] = *(const f16x8*)(wsrc + (size_t)(sc * NTAPS + tap) * p.Cout_pad * 16);
+      const int row = ((tid + i * NT) < B_VEC) ? (sc * NTAPS + tap) : 0;
+      b_raw[i] = *(const f16x8*)(wsrc + (size_t)row * p.Cout_pad * 16);
     }
   };
   auto write_lds = [&]() {
@@ -211,33 +216,45 @@ conv_mfma_kernel(ConvParams p) {
   issue_loads(0);
   for (int c0 = 0; c0 < Cin; c0 += KC) {
     __syncthreads();            // every wave has finished reading the previous chunk from LDS
-    write_lds();
+    if (!(p.ablate & 2) || c0 == 0) write_lds();
     __syncthreads();
-    if (c0 + KC < Cin) issue_loads(c0 + KC);
+    if (c0 + KC < Cin && !(p.ablate & 1)) issue_loads(c0 + KC);
+    if ((p.ablate & 4) && c0 > 0) continue;
     // ---- MFMA over taps and K sub-steps ----
 #if SDM_CONV_PIPE
-    // fragment reads hand-pipelined one step ahead with a pinned schedule (costs ~40 VGPRs: only pays where occupancy
-    // is not register-limited)
+    // Software-pipelined fragment reads with a pinned schedule: B fragments of step s+1 are read at the top of step s
+    // (double buffer, 2*NTL regs x4), each A fragment is re-read IN PLACE for step s+1 right after the MFMAs that consumed it.
+    // Every ds_read therefore has ~3/4 of a step (6 MFMAs = 192 cycles) of cover instead of none.
     constexpr int NSTEP = NTAPS * (KC / 16);
-    f16x8 fa[2][MT], fb[2][NTL];
-    auto load_frags = [&](int step, int buf) {
+    f16x8 fa[MT], fb[2][NTL];
+    auto a_addr = [&](int step, int i) {
       const int tap = step / (KC / 16), ks = step % (KC / 16);
       const int toff = (NTAPS == 9) ? ((tap / 3) * HPW + (tap % 3)) * PITCH : 0;
-#pragma unroll
-      for (int i = 0; i < MT; ++i) fa[buf][i] = *(const f16x8*)(As + abase[i] + toff + ks * 32);
-#pragma unroll
-      for (int j = 0; j < NTL; ++j) fb[buf][j] = *(const f16x8*)(Bs + tap * BN * PITCH + bbase[j] + ks * 32);
+      return (const f16x8*)(As + abase[i] + toff + ks * 32);
     };
-    load_frags(0, 0);
+    auto b_addr = [&](int step, int j) {
+      const int tap = step / (KC / 16), ks = step % (KC / 16);
+      return (const f16x8*)(Bs + tap * BN * PITCH + bbase[j] + ks * 32);
+    };
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) fb[0][j] = *b_addr(0, j);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) fa[i] = *a_addr(0, i);
 #pragma unroll
     for (int step = 0; step < NSTEP; ++step) {
-      if (step + 1 < NSTEP) load_frags(step + 1, (step + 1) & 1);
+      if (step + 1 < NSTEP) {
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) fb[(step + 1) & 1][j] = *b_addr(step + 1, j);
+      }
       SDM_SCHED_FENCE();
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+      for (int i = 0; i < MT; ++i) {
 #pragma unroll
-        for (int j = 0; j < NTL; ++j) acc[i][j] = SDM_MFMA_32x32x16_F16(fa[step & 1][i], fb[step & 1][j], acc[i][j]);
-      SDM_SCHED_FENCE();
+        for (int j = 0; j < NTL; ++j) acc[i][j] = SDM_MFMA_32x32x16_F16(fa[i], fb[step & 1][j], acc[i][j]);
+        SDM_SCHED_FENCE();
+        if (step + 1 < NSTEP) fa[i] = *a_addr(step + 1, i);
+        SDM_SCHED_FENCE();
+      }
     }
 #else
 #pragma unroll
@@ -319,7 +336,7 @@ conv_mfma_kernel(ConvParams p) {
           for (int e = 0; e < 4; ++e) v[e] += bb[e];
         }
       }
-      if (valid && colok && oc < p.Cout_valid) {
+      if (valid && colok && oc < p.Cout_valid && !(p.ablate & 8)) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= p.out_scale;
         if (p.res) {

@@ -1452,6 +1452,46 @@ int sdm_op_conv(sdm_ctx* e, const void* in0, const void* in1, int C0, int C1, in
   return rc;
 }
 
+/* Bench/ablation helper (not used by the engine): times `iters` launches of one conv with HIP events; returns ms per launch
+ * (negative on error).  ablate bits: see ConvParams::ablate. */
+float sdm_bench_conv(sdm_ctx* e, int N, int H, int W, int Cin, int Cout, int ntaps, int stride, int in_f32, int tile_cfg, int ablate, int iters) {
+  if (!e) return -1.f;
+#ifdef SDM_EMU
+  return -1.f;
+#else
+  ConvL L;
+  L.name = "bench"; L.ntaps = ntaps; L.I = Cin; L.O = Cout; L.Cin_pad = rup(Cin, 16); L.Cout_pad = rup(Cout, 32);
+  void *wp = nullptr, *bp = nullptr, *in = nullptr, *out = nullptr;
+  const int Ho = stride == 2 ? H / 2 : H, Wo = stride == 2 ? W / 2 : W;
+  const size_t wbytes = (size_t)L.Cin_pad * ntaps * L.Cout_pad * 2, inb = (size_t)N * H * W * L.Cin_pad * (in_f32 ? 4 : 2),
+               outb = (size_t)N * Ho * Wo * L.Cout_pad * 2;
+  if (dev_malloc(&wp, wbytes) || dev_malloc(&bp, (size_t)L.Cout_pad * 4) || dev_malloc(&in, inb) || dev_malloc(&out, outb)) return -2.f;
+  dev_memset(wp, 0x11, wbytes, e->stream); dev_memset(bp, 0, (size_t)L.Cout_pad * 4, e->stream); dev_memset(in, 0x11, inb, e->stream);
+  L.w = (half_t*)wp; L.b = (float*)bp;
+  T tin, tout;
+  tin.p = in; tin.N = N; tin.H = H; tin.W = W; tin.C = L.Cin_pad; tin.f32 = in_f32;
+  tout.p = out; tout.N = N; tout.H = Ho; tout.W = Wo; tout.C = L.Cout_pad; tout.f32 = 0;
+  ConvParams p;
+  memset(&p, 0, sizeof(p));
+  p.in0 = in; p.C0 = L.Cin_pad; p.in_f32 = in_f32; p.N = N; p.Hin = H; p.Win = W; p.Hout = Ho; p.Wout = Wo; p.pad_t = p.pad_l = 1;
+  p.M = (long)N * Ho * Wo; p.w = L.w; p.bias = L.b; p.Cout_pad = L.Cout_pad; p.out = out; p.Cout_store = L.Cout_pad; p.Cout_valid = L.Cout_pad;
+  p.out_scale = 1.f; p.ablate = ablate;
+  int cfg = tile_cfg >= 0 ? tile_cfg : conv_pick_cfg(ntaps, stride, p);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  launch_conv(ntaps, stride, cfg, p, e->stream);
+  (void)hipEventRecord(e0, (hipStream_t)e->stream);
+  for (int i = 0; i < iters; ++i) launch_conv(ntaps, stride, cfg, p, e->stream);
+  (void)hipEventRecord(e1, (hipStream_t)e->stream);
+  (void)hipStreamSynchronize((hipStream_t)e->stream);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  dev_free(wp); dev_free(bp); dev_free(in); dev_free(out);
+  return ms / (float)iters;
+#endif
+}
+
 int sdm_op_groupnorm(sdm_ctx* e, const void* in0, const void* in1, int C0, int C1, int in_f32, int N, int HW, int groups, const float* gamma,
                      const float* beta, float eps, int silu, void* out) {
   if (!e || !in0 || !out) return SDM_ERR_INVALID;
