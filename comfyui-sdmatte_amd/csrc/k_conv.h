@@ -75,7 +75,7 @@ struct ConvCfg {
 };
 
 template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN, int IN_F32>
-__global__ void __launch_bounds__(64 * WM * WN)
+__global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BN == 128) ? 2 : 1)   // big tiles: keep 2 blocks/CU (2 waves/SIMD) resident
 conv_mfma_kernel(ConvParams p) {
   using C = ConvCfg<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN>;
   constexpr int NT = C::NTHREADS, MT = C::MT, NTL = C::NTL, PITCH = C::PITCH, KV = C::KV;
@@ -121,11 +121,13 @@ conv_mfma_kernel(ConvParams p) {
   for (int j = 0; j < NTL; ++j) bbase[j] = (wn * WTN + j * 32 + (lane & 31)) * PITCH + (lane >> 5) * 16;
 
   // ---- K-loop invariant staging descriptors.  Vector v = tid + i*NT; everything except the A pixel index is affine in
-  //      the (compile-time) unrolled index i, so only a_pix[] is kept in registers. ----
+  //      the (compile-time) unrolled index i.  All global reads are raw BUFFER loads: per-block SGPR descriptors, one
+  //      32-bit byte offset per load, hardware zero-fill for anything out of range (halo, ragged rows, padded channels). ----
   static_assert(NT % KV == 0 && NT % (2 * BN) == 0, "staging decomposition: one thread keeps one (co, half) for every i");
+  const unsigned int es = IN_F32 ? 4u : 2u;
   const int a_part = (tid % KV) * 8;                 // channel offset inside the chunk (same for every i)
   const int a_hp0 = tid / KV;                        // halo pixel of vector i: a_hp0 + i*(NT/KV)
-  int a_pix[A_PER];                                  // pixel index inside the batch (< 2^31, host-checked); -1: zero fill
+  int a_pix[A_PER];                                  // pixel index inside the image / row inside the tile; -1: zero fill
 #pragma unroll
   for (int i = 0; i < A_PER; ++i) {
     const int hp = a_hp0 + i * (NT / KV);
@@ -134,49 +136,51 @@ conv_mfma_kernel(ConvParams p) {
       if (NTAPS == 9) {
         const int hy = hp / HPW, hx = hp % HPW;
         const int iy = oy0 * STRIDE + hy - p.pad_t, ix = ox0 * STRIDE + hx - p.pad_l;
-        if (iy >= 0 && iy < Hl && ix >= 0 && ix < Wl) a_pix[i] = (img * p.Hin + (iy >> p.up)) * p.Win + (ix >> p.up);
+        if (iy >= 0 && iy < Hl && ix >= 0 && ix < Wl) a_pix[i] = (iy >> p.up) * p.Win + (ix >> p.up);
       } else {
-        const long m = m0 + hp;
-        if (m < p.M) a_pix[i] = (int)m;
+        a_pix[i] = hp;                                // rows beyond M fall outside the descriptor -> 0
       }
     }
+  }
+  sdm_rsrc rs0, rs1, rsw;
+  {
+    size_t base_px, npx;
+    if (NTAPS == 9) { base_px = (size_t)img * p.Hin * p.Win; npx = (size_t)p.Hin * p.Win; }
+    else { base_px = (size_t)m0; npx = (size_t)((p.M - m0) < (long)C::BM ? (p.M - m0) : (long)C::BM); }
+    rs0 = sdm_make_rsrc((const unsigned char*)p.in0 + base_px * p.C0 * es, (unsigned int)(npx * p.C0 * es));
+    rs1 = sdm_make_rsrc(p.in1 ? (const unsigned char*)p.in1 + base_px * p.C1 * es : (const unsigned char*)p.in0, p.in1 ? (unsigned int)(npx * p.C1 * es) : 0u);
+    rsw = sdm_make_rsrc(p.w, (unsigned int)((size_t)Cin * NTAPS * p.Cout_pad * 2));
   }
   // B vector v -> (h = v&1, co = (v>>1)%BN, rest = (v>>1)/BN -> tap = rest%NTAPS, sc = rest/NTAPS) of the K16-packed weights
   const int b_h = tid & 1, b_co = (tid >> 1) % BN, b_rest0 = (tid >> 1) / BN;
   constexpr int B_RSTEP_NUM = NT / 2;                // (v>>1) advances by NT/2 per i
-  const bool b_ok = (n0 + b_co) < p.Cout_pad;
-  const long b_chunk_stride = (long)(KC / 16) * NTAPS * p.Cout_pad * 16;
+  const unsigned int b_voff = ((n0 + b_co) < p.Cout_pad) ? (unsigned int)(((n0 + b_co) * 16 + b_h * 8) * 2) : SDM_BUF_INVALID;
+  const unsigned int b_row_bytes = (unsigned int)p.Cout_pad * 32u;          // one (chunk16, tap) row of the packed tensor
 
   // raw staging registers (the global loads of chunk k+1 are in flight while chunk k is multiplied)
-  f32x4 a_raw[A_PER][IN_F32 ? 2 : 1];
-  f16x8 b_raw[B_PER];
+  u32x4 a_raw[A_PER][IN_F32 ? 2 : 1];
+  u32x4 b_raw[B_PER];
   auto issue_loads = [&](int c0) {
-    const void* src = p.in0;
-    int Csrc = p.C0, cc = c0;
-    if (c0 >= p.C0) { src = p.in1; Csrc = p.C1; cc = c0 - p.C0; }
-    // NOTE: every load is UNCONDITIONAL (invalid / padded vectors read a clamped, valid address and are zeroed when they
-    // are written to LDS).  A conditional `if (ok) reg = load` makes hipcc branch around each load and drain vmcnt(0) per
-    // element: 12 serialized L2 round trips per K-chunk (measured: 4.9 us/chunk, 2x on the whole kernel).
+    // every load is unconditional and independent: they are all in flight at once (a per-element `if (ok) load` makes hipcc
+    // branch around each load and drain vmcnt(0) per element - measured 4.9 us per K-chunk)
+    const bool second = c0 >= p.C0;
+    const sdm_rsrc rs = second ? rs1 : rs0;
+    const unsigned int Cs = (unsigned int)(second ? p.C1 : p.C0) * es;
+    const unsigned int cc = (unsigned int)((second ? c0 - p.C0 : c0) + a_part) * es;
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
-      const int pix = a_pix[i] >= 0 ? a_pix[i] : 0;
-      const size_t e = (size_t)pix * Csrc + cc + a_part;
-      if (IN_F32) {
-        const f32x4* q = (const f32x4*)((const float*)src + e);
-        a_raw[i][0] = q[0];
-        a_raw[i][IN_F32 ? 1 : 0] = q[1];
-      } else {
-        a_raw[i][0] = *(const f32x4*)((const half_t*)src + e);
-      }
+      const unsigned int off = a_pix[i] >= 0 ? (unsigned int)a_pix[i] * Cs + cc : SDM_BUF_INVALID;
+      a_raw[i][0] = sdm_buffer_load16(rs, off, 0);
+      if (IN_F32) a_raw[i][IN_F32 ? 1 : 0] = sdm_buffer_load16(rs, off, 16);
     }
-    const half_t* wsrc = p.w + (size_t)(c0 / KC) * b_chunk_stride + (size_t)(b_ok ? (n0 + b_co) : 0) * 16 + b_h * 8;
+    const unsigned int chunk_row0 = (unsigned int)(c0 / 16) * NTAPS;
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
       const int lin = (tid >> 1) + i * B_RSTEP_NUM;          // = (v >> 1)
       const int rest = (2 * BN >= NT) ? (lin / BN) : (b_rest0 + i * (NT / (2 * BN)));
       const int tap = rest % NTAPS, sc = rest / NTAPS;
-      const int row = ((tid + i * NT) < B_VEC) ? (sc * NTAPS + tap) : 0;
-      b_raw[i] = *(const f16x8*)(wsrc + (size_t)row * p.Cout_pad * 16);
+      const unsigned int voff = ((tid + i * NT) < B_VEC) ? b_voff : SDM_BUF_INVALID;
+      b_raw[i] = sdm_buffer_load16(rsw, voff, (chunk_row0 + (unsigned int)(sc * NTAPS + tap)) * b_row_bytes);
     }
   };
   auto write_lds = [&]() {
@@ -184,12 +188,10 @@ conv_mfma_kernel(ConvParams p) {
     for (int i = 0; i < A_PER; ++i) {
       if (tid + i * NT < A_VEC) {
         f16x8 val;
-        if (a_pix[i] < 0) {
+        if (IN_F32) {
+          const f32x4 lo = __builtin_bit_cast(f32x4, a_raw[i][0]), hi4 = __builtin_bit_cast(f32x4, a_raw[i][IN_F32 ? 1 : 0]);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) val[e] = (half_t)0.0f;
-        } else if (IN_F32) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { val[e] = (half_t)a_raw[i][0][e]; val[4 + e] = (half_t)a_raw[i][IN_F32 ? 1 : 0][e]; }
+          for (int e = 0; e < 4; ++e) { val[e] = (half_t)lo[e]; val[4 + e] = (half_t)hi4[e]; }
         } else {
           val = __builtin_bit_cast(f16x8, a_raw[i][0]);
         }
@@ -203,12 +205,7 @@ conv_mfma_kernel(ConvParams p) {
         const int rest = (2 * BN >= NT) ? (lin / BN) : (b_rest0 + i * (NT / (2 * BN)));
         const int co = (2 * BN >= NT) ? (lin % BN) : b_co;
         const int tap = rest % NTAPS, sc = rest / NTAPS;
-        f16x8 val = b_raw[i];
-        if (!b_ok) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) val[e] = (half_t)0.0f;
-        }
-        *(f16x8*)(Bs + (tap * BN + co) * PITCH + (sc * 2 + b_h) * 16) = val;
+        *(f16x8*)(Bs + (tap * BN + co) * PITCH + (sc * 2 + b_h) * 16) = __builtin_bit_cast(f16x8, b_raw[i]);
       }
     }
   };

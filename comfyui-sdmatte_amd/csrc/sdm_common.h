@@ -46,6 +46,29 @@ __device__ __forceinline__ float sdm_exp2(float x) { return __builtin_amdgcn_exp
 __device__ __forceinline__ float sdm_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 #endif
 
+// ---- raw buffer loads: SGPR resource descriptor + 32-bit byte offset; out-of-range offsets return 0 in hardware
+//      (free zero padding for conv halos / ragged tiles) and cost no 64-bit address VGPRs.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define SDM_BUF_INVALID 0x7FFFFFF0u
+#ifdef SDM_EMU
+struct sdm_rsrc { const unsigned char* base; unsigned int bytes; };
+static inline sdm_rsrc sdm_make_rsrc(const void* p, unsigned int bytes) { sdm_rsrc r; r.base = (const unsigned char*)p; r.bytes = bytes; return r; }
+static inline u32x4 sdm_buffer_load16(sdm_rsrc r, unsigned int voff, unsigned int soff) {
+  u32x4 v = {0u, 0u, 0u, 0u};
+  const unsigned long long o = (unsigned long long)voff + soff;
+  if (o + 16 <= r.bytes) memcpy(&v, r.base + o, 16);
+  return v;
+}
+#else
+typedef __amdgpu_buffer_rsrc_t sdm_rsrc;
+__device__ __forceinline__ sdm_rsrc sdm_make_rsrc(const void* p, unsigned int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 sdm_buffer_load16(sdm_rsrc r, unsigned int voff, unsigned int soff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+}
+#endif
+
 #define SDM_LOG2E 1.4426950408889634f
 
 SDM_DEV_INLINE float sdm_silu(float x) {
