@@ -29,36 +29,42 @@ struct AttnParams {
 #define SDM_NEG_BIG (-1.0e30f)
 
 // ------------------------------------------------------------------------------------------------
-// d = 64, any number of heads (grid.y), 4 waves x 32 queries per block, 64-key tiles.
+// d = 64, any number of heads (grid.y).  4 waves per block, QT x 32 queries per wave (QT = 2 halves the K / V^T fragment
+// reads per MFMA), 64-key tiles, K / V^T / bias tiles DOUBLE-buffered in LDS: the global loads of tile t+1 are issued
+// before the MFMAs of tile t, written to the other buffer afterwards, ONE barrier per tile.
 // ------------------------------------------------------------------------------------------------
 #define ATTN64_PK 144
-#define ATTN64_SMEM (2 * 64 * ATTN64_PK + 256)
+#define ATTN64_BUF (2 * 64 * ATTN64_PK + 256)
+#define ATTN64_SMEM (2 * ATTN64_BUF)
 
-__global__ void __launch_bounds__(256) attn_d64_kernel(AttnParams p) {
+template <int QT>
+__global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
   SDM_DYN_SMEM(smem);
   constexpr int PK = ATTN64_PK;
-  unsigned char* Ks = smem;
-  unsigned char* Vs = smem + 64 * PK;
-  float* Bs = (float*)(smem + 2 * 64 * PK);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, l31 = lane & 31;
   const int b = blockIdx.z, head = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = blockIdx.x * (128 * QT) + wave * (32 * QT);
 
-  f16x8 qf[4];
-  {
-    int qrow = q0 + l31;
+  f16x8 qf[QT][4];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    int qrow = q0 + qt * 32 + l31;
     if (qrow > p.Lq - 1) qrow = p.Lq - 1;
     const half_t* qp = p.q + (size_t)b * p.q_bs + (size_t)qrow * p.ldq + head * 64 + hi * 8;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const f16x8*)(qp + ks * 16);
+    for (int ks = 0; ks < 4; ++ks) qf[qt][ks] = *(const f16x8*)(qp + ks * 16);
   }
-  f32x16 o[2];
+  f32x16 o[QT][2];
+  float m_i[QT], l_i[QT];
 #pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
+  for (int qt = 0; qt < QT; ++qt) {
+    m_i[qt] = SDM_NEG_BIG; l_i[qt] = 0.0f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[dt][r] = 0.0f;
-  float m_i = SDM_NEG_BIG, l_i = 0.0f;
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[qt][dt][r] = 0.0f;
+  }
 
   const half_t* kbase = p.k + (size_t)b * p.k_bs + head * 64;
   const half_t* vbase = p.vt + (size_t)b * p.vt_bs + (size_t)head * p.vt_hs;
@@ -86,73 +92,91 @@ __global__ void __launch_bounds__(256) attn_d64_kernel(AttnParams p) {
     const float bv = bbase ? bbase[kb] : 0.0f;
     breg = inr ? bv : SDM_NEG_BIG;
   };
-  prefetch(0);
-
-  for (int t = 0; t < ntiles; ++t) {
-    __syncthreads();
+  auto stage = [&](int buf) {
+    unsigned char* base = smem + buf * ATTN64_BUF;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int v = tid + i * 256;
       const int row = v >> 3, part = v & 7;
-      *(f16x8*)(Ks + row * PK + part * 16) = kreg[i];
-      *(f16x8*)(Vs + row * PK + part * 16) = vreg[i];
+      *(f16x8*)(base + row * PK + part * 16) = kreg[i];
+      *(f16x8*)(base + 64 * PK + row * PK + part * 16) = vreg[i];
     }
-    if (tid < 64) Bs[tid] = breg;
-    __syncthreads();
+    if (tid < 64) ((float*)(base + 2 * 64 * PK))[tid] = breg;
+  };
+  prefetch(0);
+  stage(0);
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const unsigned char* Ks = smem + (t & 1) * ATTN64_BUF;
+    const unsigned char* Vs = Ks + 64 * PK;
+    const float* Bs = (const float*)(Ks + 2 * 64 * PK);
     if (t + 1 < ntiles) prefetch(t + 1);
 
-    // S^T[key][q] for 2 key tiles of 32
-    f32x16 s[2];
+    // S^T[key][q] for 2 key tiles of 32 (x QT query tiles)
+    f32x16 s[QT][2];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
+    for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[kt][r] = 0.0f;
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[qt][kt][r] = 0.0f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const f16x8 a = *(const f16x8*)(Ks + (kt * 32 + l31) * PK + ks * 32 + hi * 16);
-        s[kt] = SDM_MFMA_32x32x16_F16(a, qf[ks], s[kt]);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) s[qt][kt] = SDM_MFMA_32x32x16_F16(a, qf[qt][ks], s[qt][kt]);
       }
-    }
-    float mx = SDM_NEG_BIG;
+    f32x4 bb[2][4];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 bb = *(const f32x4*)(Bs + kt * 32 + 8 * g + 4 * hi);
+      for (int g = 0; g < 4; ++g) bb[kt][g] = *(const f32x4*)(Bs + kt * 32 + 8 * g + 4 * hi);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float x = s[kt][4 * g + e] * p.scale_log2e + bb[e];
-          s[kt][4 * g + e] = x;
-          mx = fmaxf(mx, x);
+    for (int qt = 0; qt < QT; ++qt) {
+      float mx = SDM_NEG_BIG;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float x = s[qt][kt][4 * g + e] * p.scale_log2e + bb[kt][g][e];
+            s[qt][kt][4 * g + e] = x;
+            mx = fmaxf(mx, x);
+          }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float mnew = fmaxf(m_i[qt], mx);
+      const float alpha = sdm_exp2(m_i[qt] - mnew);
+      m_i[qt] = mnew;
+      float rs = 0.0f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = sdm_exp2(s[qt][kt][r] - mnew);
+          s[qt][kt][r] = pv;
+          rs += pv;
         }
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float mnew = fmaxf(m_i, mx);
-    const float alpha = sdm_exp2(m_i - mnew);
-    m_i = mnew;
-    float rs = 0.0f;
+      l_i[qt] = l_i[qt] * alpha + rs;
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+      for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = sdm_exp2(s[kt][r] - mnew);
-        s[kt][r] = pv;
-        rs += pv;
-      }
-    l_i = l_i * alpha + rs;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        for (int r = 0; r < 16; ++r) o[qt][dt][r] *= alpha;
+    }
 
     // O^T[d][q] += V^T[d][key] . P^T[key][q]
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        f16x8 pf;
+        f16x8 pf[QT];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pf[j] = (half_t)s[kt][8 * u + j];
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pf[qt][j] = (half_t)s[qt][kt][8 * u + j];
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           const unsigned char* vp = Vs + (dt * 32 + l31) * PK + (kt * 32 + 16 * u + 4 * hi) * 2;
@@ -161,31 +185,39 @@ __global__ void __launch_bounds__(256) attn_d64_kernel(AttnParams p) {
           f16x8 vf;
 #pragma unroll
           for (int e = 0; e < 4; ++e) { vf[e] = v0[e]; vf[4 + e] = v1[e]; }
-          o[dt] = SDM_MFMA_32x32x16_F16(vf, pf, o[dt]);
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) o[qt][dt] = SDM_MFMA_32x32x16_F16(vf, pf[qt], o[qt][dt]);
         }
       }
+    if (t + 1 < ntiles) stage((t + 1) & 1);     // the other buffer: nobody reads it during this iteration
+    __syncthreads();
   }
 
-  l_i += __shfl_xor(l_i, 32);
-  const float inv = 1.0f / l_i;
-  __syncthreads();
+  // epilogue: per-wave staging [32 q][64 d] fp16 -> coalesced 16-B row stores (all waves passed the last barrier)
   unsigned char* stg = smem + wave * (32 * PK);
 #pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
+  for (int qt = 0; qt < QT; ++qt) {
+    float l = l_i[qt];
+    l += __shfl_xor(l, 32);
+    const float inv = 1.0f / l;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f16x4 h;
+    for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) h[e] = (half_t)(o[dt][4 * g + e] * inv);
-      *(f16x4*)(stg + l31 * PK + (dt * 32 + 8 * g + 4 * hi) * 2) = h;
+      for (int g = 0; g < 4; ++g) {
+        f16x4 h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = (half_t)(o[qt][dt][4 * g + e] * inv);
+        *(f16x4*)(stg + l31 * PK + (dt * 32 + 8 * g + 4 * hi) * 2) = h;
+      }
+    SDM_WAVE_SYNC();
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int row = pass * 8 + (lane >> 3), part = lane & 7;
+      const int qg = q0 + qt * 32 + row;
+      if (qg < p.Lq)
+        *(f16x8*)(p.o + (size_t)b * p.o_bs + (size_t)qg * p.ldo + head * 64 + part * 8) = *(const f16x8*)(stg + row * PK + part * 16);
     }
-  __syncthreads();
-#pragma unroll
-  for (int pass = 0; pass < 4; ++pass) {
-    const int row = pass * 8 + (lane >> 3), part = lane & 7;
-    const int qg = q0 + row;
-    if (qg < p.Lq)
-      *(f16x8*)(p.o + (size_t)b * p.o_bs + (size_t)qg * p.ldo + head * 64 + part * 8) = *(const f16x8*)(stg + row * PK + part * 16);
+    SDM_WAVE_SYNC();
   }
 }
 

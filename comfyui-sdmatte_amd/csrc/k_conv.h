@@ -276,15 +276,26 @@ conv_mfma_kernel(ConvParams p) {
   // ---- epilogue: per-wave PRIVATE fp32 staging tile (32 x WTN) in LDS -> coalesced row stores ----
   __syncthreads();               // all waves are done with the A/B tiles: the region is reused for staging
   float* stg = (float*)smem + wave * (32 * WTN);
-  constexpr int LPR = WTN / 4;   // lanes per output row (4 channels each)
-  constexpr int RPP = 64 / LPR;  // rows per pass
+  const bool geglu = (p.epi == 1);
+  // linear: WTN/4 lanes per row (4 channels each).  GEGLU: the wave's columns are [u32|g32] pairs -> WTN/2 outputs per
+  // row, WTN/8 lanes per row (all 64 lanes stay busy, u and g are read as two 16-B vectors)
+  constexpr int LPR = WTN / 4;
+  const int lpr = geglu ? LPR / 2 : LPR;          // lanes per output row
+  const int rpp = 64 / lpr;                       // rows per pass
   const float* bias = p.bias;
   if (bias && p.bias_sel) bias += (size_t)p.bias_sel[img] * p.Cout_pad;
   const int colbase = n0 + wn * WTN;
-  const int c4 = (lane % LPR) * 4;
+  const int lc = (lane % lpr) * 4;                // first of this lane's 4 output channels inside the wave tile
+  // GEMM column(s) feeding them and the output channel
+  const int ucol = geglu ? ((lc >> 5) * 64 + (lc & 31)) : lc;      // column of u (or of the value) in the staging tile
+  const int oc = geglu ? (colbase / 2 + lc) : (colbase + lc);
+  f32x4 bu = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
+  if (bias && colbase + ucol < p.Cout_pad) {
+    bu = *(const f32x4*)(bias + colbase + ucol);
+    if (geglu) bg = *(const f32x4*)(bias + colbase + ucol + 32);
+  }
   float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
-  int oc = 0;
-  bool colok = true;
+  const bool colok = true;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -295,9 +306,7 @@ conv_mfma_kernel(ConvParams p) {
         stg[row * WTN + j * 32 + (lane & 31)] = acc[i][j][r];
       }
     SDM_WAVE_SYNC();
-#pragma unroll
-    for (int pass = 0; pass < 32 / RPP; ++pass) {
-      const int row = pass * RPP + lane / LPR;
+    for (int row = lane / lpr; row < 32; row += rpp) {
       const int m = wm * WTM + i * 32 + row;
       long opix;
       bool valid;
@@ -310,30 +319,16 @@ conv_mfma_kernel(ConvParams p) {
         valid = opix < p.M;
       }
       float v[4];
-      if (p.epi == 1) {
-        // GEGLU: this wave's 64 columns are [u(32) | g(32)] of the same 32 output channels
-        colok = (c4 & 63) < 32;
-        const int grp = c4 & ~63, c = c4 & 31;
-        const int gcol = colbase + grp + c;                   // GEMM column of u
-        oc = (colbase + grp) / 2 + c;
+      const f32x4 t = *(const f32x4*)(stg + row * WTN + ucol);
+      if (geglu) {
+        const f32x4 g4 = *(const f32x4*)(stg + row * WTN + ucol + 32);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float u = stg[row * WTN + grp + c + e], g = stg[row * WTN + grp + 32 + c + e];
-          if (bias && colok && gcol + 32 + e < p.Cout_pad) { u += bias[gcol + e]; g += bias[gcol + 32 + e]; }
-          v[e] = u * sdm_gelu_erf(g);
-        }
+        for (int e = 0; e < 4; ++e) v[e] = (t[e] + bu[e]) * sdm_gelu_erf(g4[e] + bg[e]);
       } else {
-        oc = colbase + c4;
-        const f32x4 t = *(const f32x4*)(stg + row * WTN + c4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = t[e];
-        if (bias && oc < p.Cout_pad) {
-          const f32x4 bb = *(const f32x4*)(bias + oc);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += bb[e];
-        }
+        for (int e = 0; e < 4; ++e) v[e] = t[e] + bu[e];
       }
-      if (valid && colok && oc < p.Cout_valid && !(p.ablate & 8)) {
+      if (valid && oc < p.Cout_valid && !(p.ablate & 8)) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= p.out_scale;
         if (p.res) {

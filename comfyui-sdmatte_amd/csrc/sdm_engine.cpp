@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -708,7 +709,14 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
     const double bytes = 2.0 * B * heads * D * (2.0 * Lq + 2.0 * Lk);
     if (D == 64) {
       prof_begin(e, "attn_d64", flops, bytes, "B=" + std::to_string(B) + " h=" + std::to_string(heads) + " Lq=" + std::to_string(Lq) + " Lk=" + std::to_string(Lk));
-      SDM_LAUNCH(attn_d64_kernel, dim3(sdm_cdiv(Lq, 128), heads, B), dim3(256), ATTN64_SMEM, e->stream, p);
+      // 64 queries per wave when that still leaves >= 2 blocks per CU, else 32
+      const char* force_qt = getenv("SDM_ATTN_QT");       // test hook: force the 32- or 64-query-per-wave variant
+      const bool qt2 = force_qt ? (force_qt[0] == '2') : ((long)sdm_cdiv(Lq, 256) * heads * B >= 512);
+      if (qt2) {
+        SDM_LAUNCH(attn_d64_kernel<2>, dim3(sdm_cdiv(Lq, 256), heads, B), dim3(256), ATTN64_SMEM, e->stream, p);
+      } else {
+        SDM_LAUNCH(attn_d64_kernel<1>, dim3(sdm_cdiv(Lq, 128), heads, B), dim3(256), ATTN64_SMEM, e->stream, p);
+      }
       prof_end(e);
     } else {
       SDM_SET_SMEM(attn_d512_kernel, ATTN512_SMEM);
