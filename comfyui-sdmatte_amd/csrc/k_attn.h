@@ -33,14 +33,15 @@ struct AttnParams {
 // reads per MFMA), 64-key tiles, K / V^T / bias tiles DOUBLE-buffered in LDS: the global loads of tile t+1 are issued
 // before the MFMAs of tile t, written to the other buffer afterwards, ONE barrier per tile.
 // ------------------------------------------------------------------------------------------------
-#define ATTN64_PK 144
-#define ATTN64_BUF (2 * 64 * ATTN64_PK + 256)
+#define ATTN64_PK 144   /* K rows: conflict-free ds_read_b128 */
+#define ATTN64_PV 136   /* V^T rows: 34 dwords -> the 32 lanes of a ds_read_b64 half-wave hit 64 distinct banks */
+#define ATTN64_BUF (64 * ATTN64_PK + 64 * ATTN64_PV + 256)
 #define ATTN64_SMEM (2 * ATTN64_BUF)
 
 template <int QT>
 __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
   SDM_DYN_SMEM(smem);
-  constexpr int PK = ATTN64_PK;
+  constexpr int PK = ATTN64_PK, PV = ATTN64_PV;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, l31 = lane & 31;
   const int b = blockIdx.z, head = blockIdx.y;
@@ -99,9 +100,14 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
       const int v = tid + i * 256;
       const int row = v >> 3, part = v & 7;
       *(f16x8*)(base + row * PK + part * 16) = kreg[i];
-      *(f16x8*)(base + 64 * PK + row * PK + part * 16) = vreg[i];
+      // V^T rows are only 8-byte aligned (pitch 136): two ds_write_b64
+      f16x4 lo, hi4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { lo[e] = vreg[i][e]; hi4[e] = vreg[i][4 + e]; }
+      *(f16x4*)(base + 64 * PK + row * PV + part * 16) = lo;
+      *(f16x4*)(base + 64 * PK + row * PV + part * 16 + 8) = hi4;
     }
-    if (tid < 64) ((float*)(base + 2 * 64 * PK))[tid] = breg;
+    if (tid < 64) ((float*)(base + 64 * PK + 64 * PV))[tid] = breg;
   };
   prefetch(0);
   stage(0);
@@ -110,7 +116,7 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
   for (int t = 0; t < ntiles; ++t) {
     const unsigned char* Ks = smem + (t & 1) * ATTN64_BUF;
     const unsigned char* Vs = Ks + 64 * PK;
-    const float* Bs = (const float*)(Ks + 2 * 64 * PK);
+    const float* Bs = (const float*)(Ks + 64 * PK + 64 * PV);
     if (t + 1 < ntiles) prefetch(t + 1);
 
     // S^T[key][q] for 2 key tiles of 32 (x QT query tiles)
@@ -161,10 +167,13 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
           rs += pv;
         }
       l_i[qt] = l_i[qt] * alpha + rs;
+      // the running max stops moving after the first tiles: skip the O rescale when no lane of the wave needs it
+      if (__any(alpha != 1.0f)) {
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
+        for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[qt][dt][r] *= alpha;
+          for (int r = 0; r < 16; ++r) o[qt][dt][r] *= alpha;
+      }
     }
 
     // O^T[d][q] += V^T[d][key] . P^T[key][q]
@@ -179,7 +188,7 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
           for (int j = 0; j < 8; ++j) pf[qt][j] = (half_t)s[qt][kt][8 * u + j];
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          const unsigned char* vp = Vs + (dt * 32 + l31) * PK + (kt * 32 + 16 * u + 4 * hi) * 2;
+          const unsigned char* vp = Vs + (dt * 32 + l31) * PV + (kt * 32 + 16 * u + 4 * hi) * 2;
           const f16x4 v0 = *(const f16x4*)vp;
           const f16x4 v1 = *(const f16x4*)(vp + 16);
           f16x8 vf;
@@ -227,7 +236,7 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
 // same softmax and each accumulates O^T for its own 256 d.  32-key tiles.
 // ------------------------------------------------------------------------------------------------
 #define ATTN512_PKK 1040
-#define ATTN512_PKV 80
+#define ATTN512_PKV 72    /* 18 dwords: conflict-free ds_read_b64 across the 32 d-rows of a half-wave */
 #define ATTN512_KS_BYTES (32 * ATTN512_PKK)
 #define ATTN512_VS_BYTES (512 * ATTN512_PKV)
 #define ATTN512_X_BYTES (8 * 16 * 64 * 4)
@@ -278,7 +287,12 @@ __global__ void __launch_bounds__(512) attn_d512_kernel(AttnParams p) {
       }
       {  // V^T tile: 512 d x 4 vectors (32 keys)
         const int row = v >> 2, part = v & 3;
-        *(f16x8*)(Vs + row * PKV + part * 16) = *(const f16x8*)(vbase + (size_t)row * p.ldvt + k0 + part * 8);
+        const f16x8 vv = *(const f16x8*)(vbase + (size_t)row * p.ldvt + k0 + part * 8);
+        f16x4 lo, hi4;                                       // rows are only 8-byte aligned (pitch 72)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lo[e] = vv[e]; hi4[e] = vv[4 + e]; }
+        *(f16x4*)(Vs + row * PKV + part * 16) = lo;
+        *(f16x4*)(Vs + row * PKV + part * 16 + 8) = hi4;
       }
     }
     __syncthreads();

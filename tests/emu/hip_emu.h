@@ -77,6 +77,15 @@ template <typename T> static inline T __shfl(T v, int src, int width = 64) {
   return r;
 }
 
+// wave vote: true if any lane's predicate is true
+static inline int __any(int pred) {
+  auto& w = emu::wave(); int l = emu::lane_id();
+  w.slot[l][0] = pred ? 1u : 0u; emu::wave_barrier();
+  int r = 0; for (int i = 0; i < 64; ++i) r |= (int)w.slot[i][0];
+  emu::wave_barrier();
+  return r;
+}
+
 // ---- atomics (global memory may be touched by several OS threads = several workgroups) ----
 static inline float atomicAdd(float* p, float v) { std::lock_guard<std::mutex> g(emu::g_atomic_mu); float o = *p; *p = o + v; return o; }
 static inline double atomicAdd(double* p, double v) { std::lock_guard<std::mutex> g(emu::g_atomic_mu); double o = *p; *p = o + v; return o; }
