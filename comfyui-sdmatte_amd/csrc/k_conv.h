@@ -56,7 +56,7 @@ struct ConvParams {
                                         // layer (reduced by gn_reduce_partials_kernel); NTAPS==9 or one image per launch
 };
 
-template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN>
+template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN, int DB = 0>
 struct ConvCfg {
   static constexpr int NTHREADS = 64 * WM * WN;
   static constexpr int BM = TH * TW;
@@ -69,21 +69,22 @@ struct ConvCfg {
   static constexpr int A_BYTES = HP * PITCH;
   static constexpr int B_BYTES = NTAPS * BN * PITCH;
   static constexpr int STG_BYTES = WM * WN * 32 * WTN * 4;
-  static constexpr int SMEM = (A_BYTES + B_BYTES) > STG_BYTES ? (A_BYTES + B_BYTES) : STG_BYTES;
+  static constexpr int TILE_BYTES = A_BYTES + B_BYTES;          // one K-chunk of A halo + B taps
+  static constexpr int SMEM = ((DB ? 2 : 1) * TILE_BYTES) > STG_BYTES ? ((DB ? 2 : 1) * TILE_BYTES) : STG_BYTES;
   static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of 32x32");
   static_assert(KC % 16 == 0, "KC multiple of the MFMA K (16)");
 };
 
-template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN, int IN_F32>
-__global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BN == 128) ? 2 : 1)   // big tiles: keep 2 blocks/CU (2 waves/SIMD) resident
+template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN, int IN_F32, int DB>
+__global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BN == 128) ? 2 : 1)   // big 4-wave tiles: keep 2 blocks/CU resident
 conv_mfma_kernel(ConvParams p) {
-  using C = ConvCfg<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN>;
+  using C = ConvCfg<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN, DB>;
   constexpr int NT = C::NTHREADS, MT = C::MT, NTL = C::NTL, PITCH = C::PITCH, KV = C::KV;
   constexpr int HPW = C::HPW, HP = C::HP, WTM = C::WTM, WTN = C::WTN;
   constexpr int A_VEC = HP * KV, B_VEC = NTAPS * BN * KV;
   constexpr int A_PER = (A_VEC + NT - 1) / NT, B_PER = (B_VEC + NT - 1) / NT;
   SDM_DYN_SMEM(smem);
-  unsigned char* As = smem;
+  unsigned char* As = smem;                 // current K-chunk tile (switches between the two halves when DB)
   unsigned char* Bs = smem + C::A_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -183,7 +184,7 @@ conv_mfma_kernel(ConvParams p) {
       b_raw[i] = sdm_buffer_load16(rsw, voff, (chunk_row0 + (unsigned int)(sc * NTAPS + tap)) * b_row_bytes);
     }
   };
-  auto write_lds = [&]() {
+  auto write_lds = [&](unsigned char* Ad, unsigned char* Bd) {
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
       if (tid + i * NT < A_VEC) {
@@ -195,7 +196,7 @@ conv_mfma_kernel(ConvParams p) {
         } else {
           val = __builtin_bit_cast(f16x8, a_raw[i][0]);
         }
-        *(f16x8*)(As + (a_hp0 + i * (NT / KV)) * PITCH + (a_part * 2)) = val;
+        *(f16x8*)(Ad + (a_hp0 + i * (NT / KV)) * PITCH + (a_part * 2)) = val;
       }
     }
 #pragma unroll
@@ -205,18 +206,29 @@ conv_mfma_kernel(ConvParams p) {
         const int rest = (2 * BN >= NT) ? (lin / BN) : (b_rest0 + i * (NT / (2 * BN)));
         const int co = (2 * BN >= NT) ? (lin % BN) : b_co;
         const int tap = rest % NTAPS, sc = rest / NTAPS;
-        *(f16x8*)(Bs + (tap * BN + co) * PITCH + (sc * 2 + b_h) * 16) = __builtin_bit_cast(f16x8, b_raw[i]);
+        *(f16x8*)(Bd + (tap * BN + co) * PITCH + (sc * 2 + b_h) * 16) = __builtin_bit_cast(f16x8, b_raw[i]);
       }
     }
   };
 
   issue_loads(0);
-  for (int c0 = 0; c0 < Cin; c0 += KC) {
-    __syncthreads();            // every wave has finished reading the previous chunk from LDS
-    if (!(p.ablate & 2) || c0 == 0) write_lds();
+  if (DB) {                      // double-buffered tiles: chunk 0 is staged up front, ONE barrier per K-chunk afterwards
+    write_lds(As, Bs);
     __syncthreads();
-    if (c0 + KC < Cin && !(p.ablate & 1)) issue_loads(c0 + KC);
-    if ((p.ablate & 4) && c0 > 0) continue;
+  }
+  for (int c0 = 0; c0 < Cin; c0 += KC) {
+    if (DB) {
+      const int cur = (c0 / KC) & 1;
+      As = smem + cur * C::TILE_BYTES;
+      Bs = As + C::A_BYTES;
+      if (c0 + KC < Cin) issue_loads(c0 + KC);       // in flight during the MFMAs below
+    } else {
+      __syncthreads();            // every wave has finished reading the previous chunk from LDS
+      if (!(p.ablate & 2) || c0 == 0) write_lds(As, Bs);
+      __syncthreads();
+      if (c0 + KC < Cin && !(p.ablate & 1)) issue_loads(c0 + KC);
+      if ((p.ablate & 4) && c0 > 0) continue;
+    }
     // ---- MFMA over taps and K sub-steps ----
 #if SDM_CONV_PIPE
     // Software-pipelined fragment reads with a pinned schedule: B fragments of step s+1 are read at the top of step s
@@ -271,10 +283,17 @@ conv_mfma_kernel(ConvParams p) {
       }
     }
 #endif
+    if (DB) {
+      if (c0 + KC < Cin) {          // the other half was last read one iteration ago, before the previous barrier
+        unsigned char* An = smem + (((c0 / KC) & 1) ^ 1) * C::TILE_BYTES;
+        write_lds(An, An + C::A_BYTES);
+      }
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: per-wave PRIVATE fp32 staging tile (32 x WTN) in LDS -> coalesced row stores ----
-  __syncthreads();               // all waves are done with the A/B tiles: the region is reused for staging
+  if (!DB) __syncthreads();      // all waves are done with the A/B tiles (DB: the loop ended with a barrier)
   float* stg = (float*)smem + wave * (32 * WTN);
   const bool geglu = (p.epi == 1);
   // linear: WTN/4 lanes per row (4 channels each).  GEGLU: the wave's columns are [u32|g32] pairs -> WTN/2 outputs per

@@ -67,29 +67,29 @@ static inline size_t rupz(size_t a, size_t b) { return ((a + b - 1) / b) * b; }
 // ------------------------------------------------------------------------------------------------
 // conv tile configurations
 // ------------------------------------------------------------------------------------------------
-template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN>
+template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN, int DB = 0>
 static void launch_conv_t(const ConvParams& p, void* stream) {
-  using C = ConvCfg<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN>;
+  using C = ConvCfg<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN, DB>;
   dim3 grid;
   if (NTAPS == 9) grid = dim3(sdm_cdiv(p.Wout, TW) * sdm_cdiv(p.Hout, TH), sdm_cdiv(p.Cout_pad, BN), p.N);
   else grid = dim3((unsigned)((p.M + C::BM - 1) / C::BM), sdm_cdiv(p.Cout_pad, BN), 1);
   if (p.in_f32) {
-    auto k = conv_mfma_kernel<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN, 1>;
+    auto k = conv_mfma_kernel<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN, 1, DB>;
     SDM_SET_SMEM(k, C::SMEM);
     SDM_LAUNCH(k, grid, dim3(C::NTHREADS), C::SMEM, stream, p);
   } else {
-    auto k = conv_mfma_kernel<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN, 0>;
+    auto k = conv_mfma_kernel<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN, 0, DB>;
     SDM_SET_SMEM(k, C::SMEM);
     SDM_LAUNCH(k, grid, dim3(C::NTHREADS), C::SMEM, stream, p);
   }
 }
 
 struct ConvCfgInfo { int TH, TW, BN, KC, WM; };
-static const ConvCfgInfo kCfg3s1[] = {{8, 32, 128, 16, 2}, {4, 32, 64, 32, 4}, {8, 8, 64, 16, 2}};
+static const ConvCfgInfo kCfg3s1[] = {{8, 32, 128, 16, 2}, {4, 32, 64, 32, 4}, {8, 8, 64, 16, 2}, {8, 32, 128, 16, 4}};
 static const ConvCfgInfo kCfg3s2[] = {{4, 32, 64, 16, 4}, {8, 8, 64, 16, 2}};
 static const ConvCfgInfo kCfg1[] = {{8, 32, 128, 64, 2}, {4, 32, 64, 64, 4}, {8, 8, 64, 64, 2}, {8, 8, 64, 16, 2}};
 
-static int conv_num_cfgs(int ntaps, int stride) { return ntaps == 9 ? (stride == 1 ? 3 : 2) : 4; }
+static int conv_num_cfgs(int ntaps, int stride) { return ntaps == 9 ? (stride == 1 ? 4 : 2) : 4; }
 static const ConvCfgInfo* conv_cfg_table(int ntaps, int stride) { return ntaps == 9 ? (stride == 1 ? kCfg3s1 : kCfg3s2) : kCfg1; }
 
 static bool conv_cfg_ok(const ConvCfgInfo& c, const ConvParams& p) {
@@ -104,8 +104,10 @@ static int conv_pick_cfg(int ntaps, int stride, const ConvParams& p) {
   const int n = conv_num_cfgs(ntaps, stride);
   long best_blocks = -1;
   int best = -1;
+  static const bool use_db = getenv("SDM_CONV_DB") && getenv("SDM_CONV_DB")[0] == '1';
   for (int i = 0; i < n; ++i) {
     if (!conv_cfg_ok(t[i], p)) continue;
+    if (ntaps == 9 && stride == 1 && i == 3) continue;          // variant of cfg 0, substituted below
     if (ntaps == 1 && i == 0 && p.in_f32) continue;   // 256x128x64 tile + fp32 staging registers would drop to 1 wave/SIMD
     long blocks;
     if (ntaps == 9) {
@@ -115,7 +117,7 @@ static int conv_pick_cfg(int ntaps, int stride, const ConvParams& p) {
       blocks = ((p.M + t[i].TH * t[i].TW - 1) / (t[i].TH * t[i].TW)) * sdm_cdiv(p.Cout_pad, t[i].BN);
     }
     if (best < 0) { best = i; best_blocks = blocks; }
-    if (blocks >= 256) return i;                 // first (largest) tile that still gives every CU a block
+    if (blocks >= 256) return (use_db && ntaps == 9 && stride == 1 && i == 0 && !p.in_f32) ? 3 : i;   // first (largest) tile that still gives every CU a block
     if (blocks > best_blocks) { best = i; best_blocks = blocks; }
   }
   return best;
@@ -127,6 +129,7 @@ static int launch_conv(int ntaps, int stride, int cfg, const ConvParams& p, void
       case 0: launch_conv_t<9, 1, 8, 32, 128, 16, 2, 2>(p, stream); return 0;
       case 1: launch_conv_t<9, 1, 4, 32, 64, 32, 4, 1>(p, stream); return 0;
       case 2: launch_conv_t<9, 1, 8, 8, 64, 16, 2, 1>(p, stream); return 0;
+      case 3: launch_conv_t<9, 1, 8, 32, 128, 16, 4, 2, 1>(p, stream); return 0;   // 8 waves, double-buffered LDS tiles
     }
   } else if (ntaps == 9 && stride == 2) {
     switch (cfg) {

@@ -26,7 +26,7 @@ def emu_engine(pkg):
 DEV = "cpu"
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
 def test_conv3x3_s1_all_tile_cfgs(emu_engine, cfg):
     cin = 32 if cfg == 1 else 16
     S.check_conv(emu_engine, DEV, 1, 9, 35, cin, 40, tile_cfg=cfg, seed=cfg)

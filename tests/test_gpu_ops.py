@@ -23,7 +23,7 @@ def eng(pkg):
 
 
 @pytest.mark.parametrize("cfg,cin,cout,H,W", [(0, 128, 128, 40, 96), (0, 16, 128, 33, 70), (1, 320, 320, 16, 64), (2, 640, 200, 16, 16),
-                                              (2, 16, 1024, 16, 16), (-1, 256, 256, 64, 64), (-1, 1280, 1280, 8, 8)])
+                                              (2, 16, 1024, 16, 16), (-1, 256, 256, 64, 64), (-1, 1280, 1280, 8, 8), (3, 128, 128, 40, 96), (3, 512, 200, 24, 40)])
 def test_conv3x3_s1(eng, cfg, cin, cout, H, W):
     S.check_conv(eng, DEV, 2, H, W, cin, cout, tile_cfg=cfg, seed=cfg + 5)
 
