@@ -296,90 +296,138 @@ conv_mfma_kernel(ConvParams p) {
   if (!DB) __syncthreads();      // all waves are done with the A/B tiles (DB: the loop ended with a barrier)
   float* stg = (float*)smem + wave * (32 * WTN);
   const bool geglu = (p.epi == 1);
-  // linear: WTN/4 lanes per row (4 channels each).  GEGLU: the wave's columns are [u32|g32] pairs -> WTN/2 outputs per
-  // row, WTN/8 lanes per row (all 64 lanes stay busy, u and g are read as two 16-B vectors)
-  constexpr int LPR = WTN / 4;
-  const int lpr = geglu ? LPR / 2 : LPR;          // lanes per output row
-  const int rpp = 64 / lpr;                       // rows per pass
+  constexpr int LPR = WTN / 4;                    // lanes per output row (linear epilogue: 4 channels per lane)
   const float* bias = p.bias;
   if (bias && p.bias_sel) bias += (size_t)p.bias_sel[img] * p.Cout_pad;
   const int colbase = n0 + wn * WTN;
-  const int lc = (lane % lpr) * 4;                // first of this lane's 4 output channels inside the wave tile
-  // GEMM column(s) feeding them and the output channel
-  const int ucol = geglu ? ((lc >> 5) * 64 + (lc & 31)) : lc;      // column of u (or of the value) in the staging tile
-  const int oc = geglu ? (colbase / 2 + lc) : (colbase + lc);
-  f32x4 bu = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
-  if (bias && colbase + ucol < p.Cout_pad) {
-    bu = *(const f32x4*)(bias + colbase + ucol);
-    if (geglu) bg = *(const f32x4*)(bias + colbase + ucol + 32);
-  }
   float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
   const bool colok = true;
+  int oc;
+  // pixel of row `row` of M-tile i of this wave -> (valid, linear pixel index inside the image / row block)
+  auto pix_of = [&](int i, int row, long& opix_local) {
+    const int m = wm * WTM + i * 32 + row;
+    if (NTAPS == 9) {
+      const int oy = oy0 + m / TW, ox = ox0 + m % TW;
+      opix_local = (long)oy * p.Wout + ox;
+      return (oy < p.Hout) && (ox < p.Wout);
+    }
+    opix_local = m;
+    return (m0 + m) < p.M;
+  };
+  const size_t opix_base = (NTAPS == 9) ? (size_t)img * p.Hout * p.Wout : (size_t)m0;   // block-uniform
+  if (!geglu) {
+    // ---------------- linear epilogue: +bias, *scale, +residual, store, statistics ----------------
+    constexpr int RPP = 64 / LPR, NPASS = 32 / RPP;
+    const int lc = (lane % LPR) * 4;
+    oc = colbase + lc;
+    f32x4 bu = {0.f, 0.f, 0.f, 0.f};
+    if (bias && oc < p.Cout_pad) bu = *(const f32x4*)(bias + oc);
+    // residual through a per-block buffer descriptor: all loads of a 32-row tile are issued up front, unconditionally
+    // (invalid rows/columns get an out-of-range offset -> 0), instead of one dependent global round trip per row pass
+    const unsigned int res_es = p.res_f32 ? 4u : 2u;
+    const size_t res_span = (NTAPS == 9) ? (size_t)p.Hout * p.Wout : (size_t)(((p.M - m0) < (long)C::BM) ? (p.M - m0) : (long)C::BM);
+    const sdm_rsrc rsr = sdm_make_rsrc(p.res ? (const unsigned char*)p.res + opix_base * p.res_C * res_es : (const unsigned char*)p.out,
+                                       p.res ? (unsigned int)(res_span * p.res_C * res_es) : 0u);
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
+    for (int i = 0; i < MT; ++i) {
+      u32x4 rr[NPASS];
+      if (p.res) {
 #pragma unroll
-    for (int j = 0; j < NTL; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        stg[row * WTN + j * 32 + (lane & 31)] = acc[i][j][r];
-      }
-    SDM_WAVE_SYNC();
-    for (int row = lane / lpr; row < 32; row += rpp) {
-      const int m = wm * WTM + i * 32 + row;
-      long opix;
-      bool valid;
-      if (NTAPS == 9) {
-        const int oy = oy0 + m / TW, ox = ox0 + m % TW;
-        valid = (oy < p.Hout) && (ox < p.Wout);
-        opix = ((long)img * p.Hout + oy) * p.Wout + ox;
-      } else {
-        opix = m0 + m;
-        valid = opix < p.M;
-      }
-      float v[4];
-      const f32x4 t = *(const f32x4*)(stg + row * WTN + ucol);
-      if (geglu) {
-        const f32x4 g4 = *(const f32x4*)(stg + row * WTN + ucol + 32);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (t[e] + bu[e]) * sdm_gelu_erf(g4[e] + bg[e]);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = t[e] + bu[e];
-      }
-      if (valid && oc < p.Cout_valid && !(p.ablate & 8)) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= p.out_scale;
-        if (p.res) {
+        for (int pass = 0; pass < NPASS; ++pass) {
+          long lp;
+          const bool valid = pix_of(i, pass * RPP + lane / LPR, lp);
+          const unsigned int off = (valid && oc < p.Cout_valid) ? (unsigned int)(((size_t)lp * p.res_C + oc) * res_es) : SDM_BUF_INVALID;
           if (p.res_f32) {
-            const f32x4 rr = *(const f32x4*)((const float*)p.res + (size_t)opix * p.res_C + oc);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += rr[e];
-          } else {
-            const f16x4 rr = *(const f16x4*)((const half_t*)p.res + (size_t)opix * p.res_C + oc);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
+            rr[pass] = sdm_buffer_load16(rsr, off, 0);
+          } else {                                              // fp16 residual: 4 channels = 8 bytes
+            const u32x2 h2 = sdm_buffer_load8(rsr, off, 0);
+            rr[pass][0] = h2[0]; rr[pass][1] = h2[1]; rr[pass][2] = 0u; rr[pass][3] = 0u;
           }
         }
-        const size_t oidx = (size_t)opix * p.Cout_store + p.out_ch_off + oc;
-        if (p.out_f32) {
-          f32x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = v[e];
-          *(f32x4*)((float*)p.out + oidx) = o;
-        } else {
-          f16x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
-          *(f16x4*)((half_t*)p.out + oidx) = o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = (float)o[e];      // statistics of what the next layer will actually read
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
       }
+#pragma unroll
+      for (int j = 0; j < NTL; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          stg[row * WTN + j * 32 + (lane & 31)] = acc[i][j][r];
+        }
+      SDM_WAVE_SYNC();
+#pragma unroll
+      for (int pass = 0; pass < NPASS; ++pass) {
+        const int row = pass * RPP + lane / LPR;
+        long lp;
+        const bool valid = pix_of(i, row, lp);
+        const f32x4 t = *(const f32x4*)(stg + row * WTN + lc);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (t[e] + bu[e]) * p.out_scale;
+        if (p.res) {
+          if (p.res_f32) {
+            const f32x4 r4 = __builtin_bit_cast(f32x4, rr[pass]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += r4[e];
+          } else {
+            const f16x8 r8 = __builtin_bit_cast(f16x8, rr[pass]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)r8[e];
+          }
+        }
+        if (valid && oc < p.Cout_valid && !(p.ablate & 8)) {
+          const size_t oidx = (opix_base + (size_t)lp) * p.Cout_store + p.out_ch_off + oc;
+          if (p.out_f32) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = v[e];
+            *(f32x4*)((float*)p.out + oidx) = o;
+          } else {
+            f16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
+            *(f16x4*)((half_t*)p.out + oidx) = o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (float)o[e];      // statistics of what the next layer will actually read
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
+        }
+      }
+      SDM_WAVE_SYNC();
     }
-    SDM_WAVE_SYNC();
+  } else {
+    // ---------------- GEGLU epilogue: the wave's columns are [u32|g32] pairs -> WTN/2 outputs per row, WTN/8 lanes per
+    //                  row (all 64 lanes busy), u and g read as two 16-B vectors; no residual / statistics ----------------
+    constexpr int GL = LPR / 2, RPP = 64 / GL, NPASS = 32 / RPP;
+    const int lc = (lane % GL) * 4;
+    const int ucol = (lc >> 5) * 64 + (lc & 31);
+    oc = colbase / 2 + lc;
+    f32x4 bu = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
+    if (bias && colbase + ucol + 32 < p.Cout_pad + 4) { bu = *(const f32x4*)(bias + colbase + ucol); bg = *(const f32x4*)(bias + colbase + ucol + 32); }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int j = 0; j < NTL; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          stg[row * WTN + j * 32 + (lane & 31)] = acc[i][j][r];
+        }
+      SDM_WAVE_SYNC();
+#pragma unroll
+      for (int pass = 0; pass < NPASS; ++pass) {
+        const int row = pass * RPP + lane / GL;
+        long lp;
+        const bool valid = pix_of(i, row, lp);
+        const f32x4 t = *(const f32x4*)(stg + row * WTN + ucol);
+        const f32x4 g4 = *(const f32x4*)(stg + row * WTN + ucol + 32);
+        f16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (half_t)(((t[e] + bu[e]) * sdm_gelu_erf(g4[e] + bg[e])) * p.out_scale);
+        if (valid && oc < p.Cout_valid && !(p.ablate & 8))
+          *(f16x4*)((half_t*)p.out + (opix_base + (size_t)lp) * p.Cout_store + p.out_ch_off + oc) = o;
+      }
+      SDM_WAVE_SYNC();
+    }
   }
   // ---- fused GroupNorm statistics of the consumer: one partial row per (tile, wave-row); plain stores, no atomics ----
   if (p.stats) {

@@ -49,6 +49,7 @@ __device__ __forceinline__ float sdm_rcp(float x) { return __builtin_amdgcn_rcpf
 // ---- raw buffer loads: SGPR resource descriptor + 32-bit byte offset; out-of-range offsets return 0 in hardware
 //      (free zero padding for conv halos / ragged tiles) and cost no 64-bit address VGPRs.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define SDM_BUF_INVALID 0x7FFFFFF0u
 #ifdef SDM_EMU
 struct sdm_rsrc { const unsigned char* base; unsigned int bytes; };
@@ -59,6 +60,12 @@ static inline u32x4 sdm_buffer_load16(sdm_rsrc r, unsigned int voff, unsigned in
   if (o + 16 <= r.bytes) memcpy(&v, r.base + o, 16);
   return v;
 }
+static inline u32x2 sdm_buffer_load8(sdm_rsrc r, unsigned int voff, unsigned int soff) {
+  u32x2 v = {0u, 0u};
+  const unsigned long long o = (unsigned long long)voff + soff;
+  if (o + 8 <= r.bytes) memcpy(&v, r.base + o, 8);
+  return v;
+}
 #else
 typedef __amdgpu_buffer_rsrc_t sdm_rsrc;
 __device__ __forceinline__ sdm_rsrc sdm_make_rsrc(const void* p, unsigned int bytes) {
@@ -66,6 +73,9 @@ __device__ __forceinline__ sdm_rsrc sdm_make_rsrc(const void* p, unsigned int by
 }
 __device__ __forceinline__ u32x4 sdm_buffer_load16(sdm_rsrc r, unsigned int voff, unsigned int soff) {
   return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ u32x2 sdm_buffer_load8(sdm_rsrc r, unsigned int voff, unsigned int soff) {
+  return __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
 }
 #endif
 
