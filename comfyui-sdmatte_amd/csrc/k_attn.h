@@ -24,6 +24,8 @@ struct AttnParams {
   half_t* o; long o_bs; int ldo;                           // o [b][row][head*D + d]
   int Lq, Lk;
   float scale_log2e;
+  int batch, heads, nq_blocks, q_chunks;   // XCD-aware 1-D grid (attn_d64): see attn_block_coords
+  int ablate;   // bench only (sdm_bench_attn): 1 skip softmax VALU, 2 skip PV MFMAs, 4 skip QK^T MFMAs, 8 skip K/V global prefetch; 0 in the engine
 };
 
 #define SDM_NEG_BIG (-1.0e30f)
@@ -38,14 +40,31 @@ struct AttnParams {
 #define ATTN64_BUF (64 * ATTN64_PK + 64 * ATTN64_PV + 256)
 #define ATTN64_SMEM (2 * ATTN64_BUF)
 
+// XCD-aware work mapping.  The dispatcher places block id on XCD id % 8 (MI355X_MICROARCH.md, speed only - never needed for
+// correctness).  All query blocks of one (image, head) should share an XCD so that its K / V^T (4 MB at L = 16384) stay in that
+// XCD's private L2 instead of being re-fetched from Infinity Cache by all 8.  Work unit = (bh, query chunk) with q_chunks
+// chunks per bh (units % 8 == 0); XCD x owns units [x*U/8, (x+1)*U/8) and walks them in order.
+SDM_DEV_INLINE bool attn_block_coords(const AttnParams& p, int bid, int& b, int& head, int& qblk) {
+  const int units = p.batch * p.heads * p.q_chunks;
+  const int upx = units / 8;                                    // host guarantees units % 8 == 0
+  const int qb = (p.nq_blocks + p.q_chunks - 1) / p.q_chunks;   // query blocks per unit
+  const int xcd = bid & 7, s = bid >> 3;
+  const int unit = xcd * upx + s / qb;
+  const int bh = unit / p.q_chunks, chunk = unit % p.q_chunks;
+  qblk = chunk * qb + s % qb;
+  b = bh / p.heads; head = bh % p.heads;
+  return qblk < p.nq_blocks;
+}
+
 template <int QT>
 __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
   SDM_DYN_SMEM(smem);
   constexpr int PK = ATTN64_PK, PV = ATTN64_PV;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, l31 = lane & 31;
-  const int b = blockIdx.z, head = blockIdx.y;
-  const int q0 = blockIdx.x * (128 * QT) + wave * (32 * QT);
+  int b, head, qblk;
+  if (!attn_block_coords(p, blockIdx.x, b, head, qblk)) return;     // padding block of the XCD-aware grid
+  const int q0 = qblk * (128 * QT) + wave * (32 * QT);
 
   f16x8 qf[QT][4];
 #pragma unroll
@@ -117,7 +136,7 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
     const unsigned char* Ks = smem + (t & 1) * ATTN64_BUF;
     const unsigned char* Vs = Ks + 64 * PK;
     const float* Bs = (const float*)(Ks + 64 * PK + 64 * PV);
-    if (t + 1 < ntiles) prefetch(t + 1);
+    if (t + 1 < ntiles && !(p.ablate & 8)) prefetch(t + 1);
 
     // S^T[key][q] for 2 key tiles of 32 (x QT query tiles)
     f32x16 s[QT][2];
@@ -127,6 +146,7 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[qt][kt][r] = 0.0f;
+    if (!(p.ablate & 4)) {
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -135,11 +155,13 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) s[qt][kt] = SDM_MFMA_32x32x16_F16(a, qf[qt][ks], s[qt][kt]);
       }
+    }
     f32x4 bb[2][4];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) bb[kt][g] = *(const f32x4*)(Bs + kt * 32 + 8 * g + 4 * hi);
+    if (!(p.ablate & 1)) {
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       float mx = SDM_NEG_BIG;
@@ -175,8 +197,10 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
           for (int r = 0; r < 16; ++r) o[qt][dt][r] *= alpha;
       }
     }
+    }
 
     // O^T[d][q] += V^T[d][key] . P^T[key][q]
+    if (!(p.ablate & 2)) {
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -198,6 +222,7 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
           for (int qt = 0; qt < QT; ++qt) o[qt][dt] = SDM_MFMA_32x32x16_F16(vf, pf[qt], o[qt][dt]);
         }
       }
+    }
     if (t + 1 < ntiles) stage((t + 1) & 1);     // the other buffer: nobody reads it during this iteration
     __syncthreads();
   }

@@ -713,13 +713,14 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
     if (D == 64) {
       prof_begin(e, "attn_d64", flops, bytes, "B=" + std::to_string(B) + " h=" + std::to_string(heads) + " Lq=" + std::to_string(Lq) + " Lk=" + std::to_string(Lk));
       // 64 queries per wave when that still leaves >= 2 blocks per CU, else 32
-      const char* force_qt = getenv("SDM_ATTN_QT");       // test hook: force the 32- or 64-query-per-wave variant
-      const bool qt2 = force_qt ? (force_qt[0] == '2') : ((long)sdm_cdiv(Lq, 256) * heads * B >= 512);
-      if (qt2) {
-        SDM_LAUNCH(attn_d64_kernel<2>, dim3(sdm_cdiv(Lq, 256), heads, B), dim3(256), ATTN64_SMEM, e->stream, p);
-      } else {
-        SDM_LAUNCH(attn_d64_kernel<1>, dim3(sdm_cdiv(Lq, 128), heads, B), dim3(256), ATTN64_SMEM, e->stream, p);
-      }
+      const char* force_qt = getenv("SDM_ATTN_QT");       // test hook: force the 64-query-per-wave variant (measured slower)
+      const bool qt2 = force_qt && force_qt[0] == '2';
+      const int qrows = qt2 ? 256 : 128;
+      p.batch = B; p.heads = heads; p.nq_blocks = sdm_cdiv(Lq, qrows); p.q_chunks = 8;     // B*heads*8 units: always a multiple of 8
+      const int qb = sdm_cdiv(p.nq_blocks, p.q_chunks);
+      const unsigned nblk = (unsigned)(B * heads * p.q_chunks * qb);                         // 1-D grid, XCD-aware mapping in the kernel
+      if (qt2) { SDM_LAUNCH(attn_d64_kernel<2>, dim3(nblk, 1, 1), dim3(256), ATTN64_SMEM, e->stream, p); }
+      else { SDM_LAUNCH(attn_d64_kernel<1>, dim3(nblk, 1, 1), dim3(256), ATTN64_SMEM, e->stream, p); }
       prof_end(e);
     } else {
       SDM_SET_SMEM(attn_d512_kernel, ATTN512_SMEM);
@@ -1499,6 +1500,42 @@ float sdm_bench_conv(sdm_ctx* e, int N, int H, int W, int Cin, int Cout, int nta
   (void)hipEventElapsedTime(&ms, e0, e1);
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   dev_free(wp); dev_free(bp); dev_free(in); dev_free(out);
+  return ms / (float)iters;
+#endif
+}
+
+/* Bench/ablation helper for the d=64 attention kernel (not used by the engine). */
+float sdm_bench_attn(sdm_ctx* e, int B, int heads, int Lq, int Lk, int qt, int ablate, int iters) {
+  if (!e) return -1.f;
+#ifdef SDM_EMU
+  return -1.f;
+#else
+  const int C = heads * 64, ldvt = rup(Lk, 64);
+  void *q = nullptr, *k = nullptr, *vt = nullptr, *o = nullptr;
+  if (dev_malloc(&q, (size_t)B * Lq * C * 2) || dev_malloc(&k, (size_t)B * Lk * C * 2) || dev_malloc(&vt, (size_t)B * heads * 64 * ldvt * 2) ||
+      dev_malloc(&o, (size_t)B * Lq * C * 2)) return -2.f;
+  dev_memset(q, 0x2c, (size_t)B * Lq * C * 2, e->stream); dev_memset(k, 0x2d, (size_t)B * Lk * C * 2, e->stream);
+  dev_memset(vt, 0x2e, (size_t)B * heads * 64 * ldvt * 2, e->stream);
+  AttnParams p;
+  memset(&p, 0, sizeof(p));
+  p.q = (const half_t*)q; p.q_bs = (long)Lq * C; p.ldq = C; p.k = (const half_t*)k; p.k_bs = (long)Lk * C; p.ldk = C;
+  p.vt = (const half_t*)vt; p.vt_hs = (long)64 * ldvt; p.vt_bs = heads * p.vt_hs; p.ldvt = ldvt; p.o = (half_t*)o; p.o_bs = (long)Lq * C; p.ldo = C;
+  p.Lq = Lq; p.Lk = Lk; p.scale_log2e = 0.125f * SDM_LOG2E; p.ablate = ablate;
+  p.batch = B; p.heads = heads; p.nq_blocks = sdm_cdiv(Lq, qt == 2 ? 256 : 128); p.q_chunks = 8;
+  const unsigned nblk = (unsigned)(B * heads * p.q_chunks * sdm_cdiv(p.nq_blocks, p.q_chunks));
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int i = 0; i <= iters; ++i) {
+    if (i == 1) (void)hipEventRecord(e0, (hipStream_t)e->stream);
+    if (qt == 2) { SDM_LAUNCH(attn_d64_kernel<2>, dim3(nblk), dim3(256), ATTN64_SMEM, e->stream, p); }
+    else { SDM_LAUNCH(attn_d64_kernel<1>, dim3(nblk), dim3(256), ATTN64_SMEM, e->stream, p); }
+  }
+  (void)hipEventRecord(e1, (hipStream_t)e->stream);
+  (void)hipStreamSynchronize((hipStream_t)e->stream);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  dev_free(q); dev_free(k); dev_free(vt); dev_free(o);
   return ms / (float)iters;
 #endif
 }

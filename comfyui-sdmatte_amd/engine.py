@@ -58,7 +58,7 @@ EXPORTS = [
     "sdm_weight_stats", "sdm_missing_key", "sdm_weight_blob_bytes", "sdm_export_weight_blob", "sdm_import_weight_blob",
     "sdm_host_blob_bytes", "sdm_export_host_blob", "sdm_import_host_blob", "sdm_forward", "sdm_apply_matte",
     "sdm_synchronize", "sdm_last_forward_ms", "sdm_profile_enable", "sdm_profile_count", "sdm_profile_get", "sdm_profile_dump",
-    "sdm_op_conv", "sdm_conv_num_cfgs", "sdm_bench_conv", "sdm_op_groupnorm", "sdm_op_layernorm", "sdm_op_attention", "sdm_op_resize_aa",
+    "sdm_op_conv", "sdm_conv_num_cfgs", "sdm_bench_conv", "sdm_bench_attn", "sdm_op_groupnorm", "sdm_op_layernorm", "sdm_op_attention", "sdm_op_resize_aa",
     "sdm_op_mask_bias",
 ]
 
@@ -97,6 +97,7 @@ class Bindings:
                                   f32, i32]),
             "sdm_conv_num_cfgs": (i32, [i32, i32]),
             "sdm_bench_conv": (f32, [vp] + [i32] * 11),
+            "sdm_bench_attn": (f32, [vp] + [i32] * 7),
             "sdm_op_groupnorm": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, f32, i32, vp]),
             "sdm_op_layernorm": (i32, [vp, vp, i32, C.c_long, i32, vp, vp, f32, vp]),
             "sdm_op_attention": (i32, [vp, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32]),
@@ -273,6 +274,9 @@ class Engine:
 
     def bench_conv(self, N, H, W, Cin, Cout, ntaps=9, stride=1, in_f32=0, tile_cfg=-1, ablate=0, iters=10):
         return float(self.lib.sdm_bench_conv(self.h, N, H, W, Cin, Cout, ntaps, stride, in_f32, tile_cfg, ablate, iters))
+
+    def bench_attn(self, B, heads, Lq, Lk, qt=1, ablate=0, iters=10):
+        return float(self.lib.sdm_bench_attn(self.h, B, heads, Lq, Lk, qt, ablate, iters))
 
     def op_groupnorm(self, x0, gamma, beta, eps, silu, groups=32, x1=None):
         N, H, W_, C0 = x0.shape

@@ -133,6 +133,7 @@ int sdm_op_conv(sdm_ctx* ctx, const void* in0, const void* in1, int C0, int C1, 
                 const void* res, int res_f32, int geglu, float out_scale, int tile_cfg);
 int sdm_conv_num_cfgs(int ntaps, int stride);
 /* Bench/ablation helper: ms per launch of one conv (random-ish data), HIP-event timed on the engine stream. */
+float sdm_bench_attn(sdm_ctx* ctx, int B, int heads, int Lq, int Lk, int qt, int ablate, int iters);
 float sdm_bench_conv(sdm_ctx* ctx, int N, int H, int W, int Cin, int Cout, int ntaps, int stride, int in_f32, int tile_cfg, int ablate, int iters);
 /* GroupNorm(groups)+optional SiLU over NHWC (concat of two sources) -> fp16 NHWC. */
 int sdm_op_groupnorm(sdm_ctx* ctx, const void* in0, const void* in1, int C0, int C1, int in_f32, int N, int HW, int groups,
