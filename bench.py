@@ -125,11 +125,22 @@ def main():
             with open(args.dump_profile, "w") as fh:
                 fh.write(eng.profile_dump())
         roof = None
+        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+        # (profiles/pmc_traffic.json, written by tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE passes, KB units,
+        # FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md); null when no matching profile is committed.
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+                pt = json.load(fh)
+            if pt.get("batch_per_gpu") == B and pt.get("inference_size") == S:
+                traffic = pt.get("conv3x3_bytes_per_launch")
+        except Exception:
+            pass
         if "conv3x3_mfma" in prof:
             c = prof["conv3x3_mfma"]
             ach = c["flops"] / (c["ms"] * 1e-3) / 1e12 if c["ms"] > 0 else 0.0
             roof = {"bound": "mfma", "kernel": "conv_mfma_kernel<9,...> (conv3x3 implicit GEMM)", "achieved": round(ach, 2),
-                    "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None,
+                    "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_PEAK_TFLOPS, 4), "traffic": traffic,
                     "launches_per_step": c["launches"], "avg_launch_us": round(c["ms"] * 1e3 / max(c["launches"], 1), 2),
                     "flops_per_launch": c["flops"] / max(c["launches"], 1)}
         breakdown = {k: {"ms": round(v["ms"], 3), "launches": v["launches"],

@@ -276,8 +276,9 @@ __global__ void __launch_bounds__(512) attn_d512_kernel(AttnParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, l31 = lane & 31;
   const int qgp = wave >> 1, dh = wave & 1;
-  const int b = blockIdx.z;
-  const int q0 = blockIdx.x * 128 + qgp * 32;
+  int b, head_unused, qblk;
+  if (!attn_block_coords(p, blockIdx.x, b, head_unused, qblk)) return;     // XCD-aware 1-D grid (one image per XCD at a time)
+  const int q0 = qblk * 128 + qgp * 32;
 
   f16x8 qf[16];
   {

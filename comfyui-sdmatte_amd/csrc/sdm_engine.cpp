@@ -108,7 +108,6 @@ static int conv_pick_cfg(int ntaps, int stride, const ConvParams& p) {
   for (int i = 0; i < n; ++i) {
     if (!conv_cfg_ok(t[i], p)) continue;
     if (ntaps == 9 && stride == 1 && i == 3) continue;          // variant of cfg 0, substituted below
-    if (ntaps == 1 && i == 0 && p.in_f32) continue;   // 256x128x64 tile + fp32 staging registers would drop to 1 wave/SIMD
     long blocks;
     if (ntaps == 9) {
       if (t[i].TW > 8 && p.Wout < 24) continue;   // 32-wide strips would be mostly padding
@@ -725,7 +724,8 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
     } else {
       SDM_SET_SMEM(attn_d512_kernel, ATTN512_SMEM);
       prof_begin(e, "attn_d512", flops, bytes);
-      SDM_LAUNCH(attn_d512_kernel, dim3(sdm_cdiv(Lq, 128), 1, B), dim3(512), ATTN512_SMEM, e->stream, p);
+      p.batch = B; p.heads = 1; p.nq_blocks = sdm_cdiv(Lq, 128); p.q_chunks = 8;
+      SDM_LAUNCH(attn_d512_kernel, dim3((unsigned)(B * p.q_chunks * sdm_cdiv(p.nq_blocks, p.q_chunks))), dim3(512), ATTN512_SMEM, e->stream, p);
       prof_end(e);
     }
   }
