@@ -64,7 +64,9 @@ struct ConvCfg {
   static constexpr int HPH = (NTAPS == 9) ? (TH - 1) * STRIDE + 3 : TH;
   static constexpr int HPW = (NTAPS == 9) ? (TW - 1) * STRIDE + 3 : TW;
   static constexpr int HP = HPH * HPW;
-  static constexpr int PITCH = KC * 2 + 16;
+  // DB (double-buffered) tiles are stored UNPADDED with an XOR swizzle of the 16-B half (KC == 16: 2 halves per 32-B row):
+  // half h of row r lives at r*32 + ((h ^ ((r >> 3) & 1)) << 4) -> conflict-free ds_read_b128 for 16-lane groups of consecutive rows
+  static constexpr int PITCH = DB ? KC * 2 : KC * 2 + 16;
   static constexpr int KV = KC / 8;
   static constexpr int A_BYTES = HP * PITCH;
   static constexpr int B_BYTES = NTAPS * BN * PITCH;
@@ -73,6 +75,7 @@ struct ConvCfg {
   static constexpr int SMEM = ((DB ? 2 : 1) * TILE_BYTES) > STG_BYTES ? ((DB ? 2 : 1) * TILE_BYTES) : STG_BYTES;
   static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of 32x32");
   static_assert(KC % 16 == 0, "KC multiple of the MFMA K (16)");
+  static_assert(!DB || KC == 16, "swizzled double-buffered tiles assume 2 halves per row");
 };
 
 template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN, int IN_F32, int DB>
@@ -111,15 +114,21 @@ conv_mfma_kernel(ConvParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+  // per-lane fragment bases.  Padded layout: byte offsets.  Swizzled (DB) layout: A keeps the halo ROW (the swizzle bit
+  // depends on the row, which moves with the tap), B the final byte offset (its swizzle bit only depends on co).
   int abase[MT], bbase[NTL];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int m = wm * WTM + i * 32 + (lane & 31);
     const int py = m / TW, px = m % TW;
-    abase[i] = ((NTAPS == 9) ? (py * STRIDE * HPW + px * STRIDE) : m) * PITCH + (lane >> 5) * 16;
+    const int row = (NTAPS == 9) ? (py * STRIDE * HPW + px * STRIDE) : m;
+    abase[i] = DB ? row : row * PITCH + (lane >> 5) * 16;
   }
 #pragma unroll
-  for (int j = 0; j < NTL; ++j) bbase[j] = (wn * WTN + j * 32 + (lane & 31)) * PITCH + (lane >> 5) * 16;
+  for (int j = 0; j < NTL; ++j) {
+    const int co = wn * WTN + j * 32 + (lane & 31);
+    bbase[j] = DB ? co * PITCH + ((((lane >> 5) ^ (co >> 3)) & 1) << 4) : co * PITCH + (lane >> 5) * 16;
+  }
 
   // ---- K-loop invariant staging descriptors.  Vector v = tid + i*NT; everything except the A pixel index is affine in
   //      the (compile-time) unrolled index i.  All global reads are raw BUFFER loads: per-block SGPR descriptors, one
@@ -196,7 +205,8 @@ conv_mfma_kernel(ConvParams p) {
         } else {
           val = __builtin_bit_cast(f16x8, a_raw[i][0]);
         }
-        *(f16x8*)(Ad + (a_hp0 + i * (NT / KV)) * PITCH + (a_part * 2)) = val;
+        const int hp_w = a_hp0 + i * (NT / KV);
+        *(f16x8*)(Ad + hp_w * PITCH + (DB ? ((((a_part >> 3) ^ (hp_w >> 3)) & 1) << 4) : (a_part * 2))) = val;
       }
     }
 #pragma unroll
@@ -206,7 +216,7 @@ conv_mfma_kernel(ConvParams p) {
         const int rest = (2 * BN >= NT) ? (lin / BN) : (b_rest0 + i * (NT / (2 * BN)));
         const int co = (2 * BN >= NT) ? (lin % BN) : b_co;
         const int tap = rest % NTAPS, sc = rest / NTAPS;
-        *(f16x8*)(Bd + (tap * BN + co) * PITCH + (sc * 2 + b_h) * 16) = __builtin_bit_cast(f16x8, b_raw[i]);
+        *(f16x8*)(Bd + (tap * BN + co) * PITCH + (DB ? (((b_h ^ (co >> 3)) & 1) << 4) : ((sc * 2 + b_h) * 16))) = __builtin_bit_cast(f16x8, b_raw[i]);
       }
     }
   };
@@ -230,7 +240,7 @@ conv_mfma_kernel(ConvParams p) {
       if ((p.ablate & 4) && c0 > 0) continue;
     }
     // ---- MFMA over taps and K sub-steps ----
-#if SDM_CONV_PIPE
+#if SDM_CONV_PIPE || 1   /* the non-pipelined loop below does not implement the swizzled layout */
     // Software-pipelined fragment reads with a pinned schedule: B fragments of step s+1 are read at the top of step s
     // (double buffer, 2*NTL regs x4), each A fragment is re-read IN PLACE for step s+1 right after the MFMAs that consumed it.
     // Every ds_read therefore has ~3/4 of a step (6 MFMAs = 192 cycles) of cover instead of none.
@@ -238,6 +248,10 @@ conv_mfma_kernel(ConvParams p) {
     f16x8 fa[MT], fb[2][NTL];
     auto a_addr = [&](int step, int i) {
       const int tap = step / (KC / 16), ks = step % (KC / 16);
+      if (DB) {
+        const int row = abase[i] + ((NTAPS == 9) ? (tap / 3) * HPW + (tap % 3) : 0);
+        return (const f16x8*)(As + row * PITCH + ((((lane >> 5) ^ (row >> 3)) & 1) << 4));
+      }
       const int toff = (NTAPS == 9) ? ((tap / 3) * HPW + (tap % 3)) * PITCH : 0;
       return (const f16x8*)(As + abase[i] + toff + ks * 32);
     };

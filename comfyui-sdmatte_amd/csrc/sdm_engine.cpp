@@ -85,7 +85,7 @@ static void launch_conv_t(const ConvParams& p, void* stream) {
 }
 
 struct ConvCfgInfo { int TH, TW, BN, KC, WM; };
-static const ConvCfgInfo kCfg3s1[] = {{8, 32, 128, 16, 2}, {4, 32, 64, 32, 4}, {8, 8, 64, 16, 2}, {8, 32, 128, 16, 4}};
+static const ConvCfgInfo kCfg3s1[] = {{8, 32, 128, 16, 2}, {4, 32, 64, 32, 4}, {8, 8, 64, 16, 2}, {16, 32, 128, 16, 4}};
 static const ConvCfgInfo kCfg3s2[] = {{4, 32, 64, 16, 4}, {8, 8, 64, 16, 2}};
 static const ConvCfgInfo kCfg1[] = {{8, 32, 128, 64, 2}, {4, 32, 64, 64, 4}, {8, 8, 64, 64, 2}, {8, 8, 64, 16, 2}};
 
@@ -104,7 +104,7 @@ static int conv_pick_cfg(int ntaps, int stride, const ConvParams& p) {
   const int n = conv_num_cfgs(ntaps, stride);
   long best_blocks = -1;
   int best = -1;
-  static const bool use_db = getenv("SDM_CONV_DB") && getenv("SDM_CONV_DB")[0] == '1';   // experiment hook: measured slower (53.6 vs 49.5 ms)
+  static const bool use_db = getenv("SDM_CONV_DB") && getenv("SDM_CONV_DB")[0] == '1';   // A/B hook for the 512x128 double-buffered tile
   for (int i = 0; i < n; ++i) {
     if (!conv_cfg_ok(t[i], p)) continue;
     if (ntaps == 9 && stride == 1 && i == 3) continue;          // variant of cfg 0, substituted below
@@ -116,7 +116,11 @@ static int conv_pick_cfg(int ntaps, int stride, const ConvParams& p) {
       blocks = ((p.M + t[i].TH * t[i].TW - 1) / (t[i].TH * t[i].TW)) * sdm_cdiv(p.Cout_pad, t[i].BN);
     }
     if (best < 0) { best = i; best_blocks = blocks; }
-    if (blocks >= 256) return (use_db && ntaps == 9 && stride == 1 && i == 0 && !p.in_f32) ? 3 : i;   // first (largest) tile that still gives every CU a block
+    if (blocks >= 256) {
+      // cfg 3 (512-pixel tile, 1 block per CU) needs at least ~2 blocks per CU of its own to pay off
+      if (use_db && ntaps == 9 && stride == 1 && i == 0 && (long)p.N * sdm_cdiv(p.Hout, 16) * sdm_cdiv(p.Wout, 32) * sdm_cdiv(p.Cout_pad, 128) >= 512) return 3;
+      return i;
+    }   // first (largest) tile that still gives every CU a block
     if (blocks > best_blocks) { best = i; best_blocks = blocks; }
   }
   return best;
@@ -128,7 +132,7 @@ static int launch_conv(int ntaps, int stride, int cfg, const ConvParams& p, void
       case 0: launch_conv_t<9, 1, 8, 32, 128, 16, 2, 2>(p, stream); return 0;
       case 1: launch_conv_t<9, 1, 4, 32, 64, 32, 4, 1>(p, stream); return 0;
       case 2: launch_conv_t<9, 1, 8, 8, 64, 16, 2, 1>(p, stream); return 0;
-      case 3: launch_conv_t<9, 1, 8, 32, 128, 16, 4, 2, 1>(p, stream); return 0;   // 8 waves, double-buffered LDS tiles
+      case 3: launch_conv_t<9, 1, 16, 32, 128, 16, 4, 2, 1>(p, stream); return 0;   // 512 px x 128 co, 8 waves, swizzled double-buffered LDS tiles
     }
   } else if (ntaps == 9 && stride == 2) {
     switch (cfg) {
