@@ -151,6 +151,43 @@ def test_e2e_pre_post_match_reference_fixture(pkg, golden_dir):
     eng.close()
 
 
+def test_weight_blob_roundtrip_and_rccl_path(pkg):
+    """Multi-GPU plumbing on ONE device: (1) export the packed weight blob from one engine and import it into a second one ->
+    bit-identical alphas (what every non-zero rank does after the RCCL broadcast); (2) the torch.distributed 'nccl' (= RCCL)
+    calls of parallel.py with world_size 1 (broadcast + gather run end to end on the GPU)."""
+    import os
+    import torch.distributed as dist
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    from comfyui_sdmatte_amd.engine import Engine
+    from comfyui_sdmatte_amd.weights import synthetic_state_dict
+    from comfyui_sdmatte_amd.synth import synthetic_inputs
+    from comfyui_sdmatte_amd import parallel
+    cfg = SDMatteConfig.tiny()
+    e0, e1 = Engine(cfg, 0), Engine(cfg, 0)
+    e0.load_state_dict(synthetic_state_dict(cfg, 0))
+    blob = torch.empty(e0.weight_blob_bytes(), dtype=torch.uint8, device="cuda")
+    hblob = torch.empty(e0.host_blob_bytes(), dtype=torch.uint8)
+    e0.export_weights(blob, hblob)
+    e1.import_weights(blob, hblob)
+    img, tri = synthetic_inputs(2, 64, 64)
+    a0 = e0.apply_matte(img.cuda(), tri.cuda(), 64)
+    a1 = e1.apply_matte(img.cuda(), tri.cuda(), 64)
+    assert torch.equal(a0, a1)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        parallel.broadcast_weights(e0, 0, torch.device("cuda", 0))     # world 1: early return
+        t = torch.ones(4, device="cuda")
+        dist.broadcast(t, 0)
+        out = [torch.empty_like(a0)]
+        dist.gather(a0, out, dst=0)
+        assert torch.equal(out[0], a0)
+    finally:
+        dist.destroy_process_group()
+    e0.close(); e1.close()
+
+
 @pytest.mark.slow
 def test_e2e_full_model_512(pkg):
     """BASELINE config #1 size on the real SD-2.1 architecture (synthetic weights): 512x512, B=1, vs the fp32 CPU oracle."""
