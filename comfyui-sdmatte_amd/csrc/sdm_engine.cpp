@@ -175,7 +175,7 @@ struct Slot {
 };
 struct ResB { int norm1 = -1, conv1 = -1, norm2 = -1, conv2 = -1, sc = -1, temb = -1, cin = 0, cout = 0; };
 struct VaeAttnB { int gn = -1, qkv = -1, out = -1, C = 0; };
-struct TfB { int gn, proj_in, ln1, qkv1, o1, ln2, q2, kv2, o2, ln3, ff1, ff2, proj_out, C, heads; };
+struct TfB { int gn, proj_in, ln1, qkv1, o1, ln2, q2, kv2, o2, ln3, ff1, ff2, proj_out, C, heads; size_t k_hoff, v_hoff; };
 struct TembL { size_t w_hoff = 0, b_hoff = 0, cb_hoff = 0; int cout = 0, cout_pad = 0; float* table = nullptr; };
 
 struct T {  // NHWC activation tensor living in the arena
@@ -230,7 +230,7 @@ struct sdm_ctx {
   ResB u_mid0, u_mid1;
   TfB u_midtf;
   std::vector<TembL> tembs;
-  size_t h_time1w, h_time1b, h_time2w, h_time2b, h_bbox1w, h_bbox1b, h_bbox2w, h_bbox2b;
+  size_t h_time1w, h_time1b, h_time2w, h_time2b, h_bbox1w, h_bbox1b, h_bbox2w, h_bbox2b, h_auxw, h_auxb;
   std::vector<Variant> variants;
   int* d_bias_sel = nullptr;   // [max batch]
   int bias_sel_cap = 0;
@@ -370,9 +370,12 @@ struct Builder {
     slot(b + ".attn1.to_v.weight", SLOT_CONV_W, t.qkv1, {C, C}, 2 * C);
     t.o1 = conv_named(b + ".attn1.to_out.0", 1, C, C);
     t.q2 = conv_named(b + ".attn2.to_q", 1, C, C, false);
-    t.kv2 = conv(b + ".attn2.kv", 1, ctx, 2 * C);
-    slot(b + ".attn2.to_k.weight", SLOT_CONV_W, t.kv2, {C, ctx}, 0);
-    slot(b + ".attn2.to_v.weight", SLOT_CONV_W, t.kv2, {C, ctx}, C);
+    // cross-attention K|V: K = W_k (W_aux * z + b_aux) is an affine map of the 3x3 patch of the 4-channel trimap latent z
+    // (exact fold): ONE 3x3 conv 16(4 real)->2C with host-folded weights instead of aux_conv_in
+    // (4->1024) followed by two 1024->C GEMMs.  to_k / to_v / aux_conv_in are kept on the host and folded in finalize.
+    t.kv2 = conv(b + ".attn2.kv_folded", 9, 16, 2 * C);
+    slot(b + ".attn2.to_k.weight", SLOT_HOST, -1, {C, ctx}); t.k_hoff = e->slots[b + ".attn2.to_k.weight"].host_off;
+    slot(b + ".attn2.to_v.weight", SLOT_HOST, -1, {C, ctx}); t.v_hoff = e->slots[b + ".attn2.to_v.weight"].host_off;
     t.o2 = conv_named(b + ".attn2.to_out.0", 1, C, C);
     t.ff1 = conv(b + ".ff.net.0.proj", 1, C, 8 * C, 1);
     slot(b + ".ff.net.0.proj.weight", SLOT_CONV_W, t.ff1, {8 * C, C});
@@ -428,8 +431,10 @@ static void build_model(sdm_ctx* e) {
   const int* uc = c.unet_channels;
   const int te = uc[0] * 4, ctx = c.cross_attention_dim;
   e->u_conv_in = B.conv_named("unet.conv_in", 9, c.unet_in_channels, uc[0]);
-  // aux_conv_in reads the trimap latent from channels 4..7 of the shared 16-channel U-Net input tensor
-  e->u_aux = B.conv_named("unet.aux_conv_in", 9, 4, ctx, true, /*ci_off=*/4, /*Ipad=*/16);
+  // aux_conv_in (4->ctx, utils.py:33-41) only ever feeds the cross-attention K/V projections: folded into them (see transformer())
+  e->u_aux = -1;
+  B.slot("unet.aux_conv_in.weight", SLOT_HOST, -1, {ctx, 4, 3, 3}); e->h_auxw = e->slots["unet.aux_conv_in.weight"].host_off;
+  B.slot("unet.aux_conv_in.bias", SLOT_HOST, -1, {ctx}); e->h_auxb = e->slots["unet.aux_conv_in.bias"].host_off;
   B.slot("unet.time_embedding.linear_1.weight", SLOT_HOST, -1, {te, uc[0]}); e->h_time1w = e->slots["unet.time_embedding.linear_1.weight"].host_off;
   B.slot("unet.time_embedding.linear_1.bias", SLOT_HOST, -1, {te}); e->h_time1b = e->slots["unet.time_embedding.linear_1.bias"].host_off;
   B.slot("unet.time_embedding.linear_2.weight", SLOT_HOST, -1, {te, te}); e->h_time2w = e->slots["unet.time_embedding.linear_2.weight"].host_off;
@@ -813,9 +818,9 @@ static int vae_attention(sdm_ctx* e, const VaeAttnB& a, const T& x, T* out) {
 }
 
 // Transformer2DModel + BasicTransformerBlock (Appendix A.7); bias = level key-bias [N][L] (log2 domain) or null
-static int transformer(sdm_ctx* e, const TfB& t, const T& x, const T& ehs, const float* bias, T* out) {
+static int transformer(sdm_ctx* e, const TfB& t, const T& x, const T& uin, const float* bias, T* out) {
   const int sf = e->cfg.stream_f32;
-  const int C = t.C, L = x.H * x.W, L0 = ehs.H * ehs.W;
+  const int C = t.C, L = x.H * x.W, L0 = uin.H * uin.W;
   T hn, h, n, qkv, ao, h2, q2, kv, f;
   TRY(op_gn(e, e->norms[t.gn], x, nullptr, 0, e->cfg.unet_tf_gn_eps, &hn));
   TRY(linear(e, t.proj_in, hn, &h, C, sf));
@@ -836,7 +841,7 @@ static int transformer(sdm_ctx* e, const TfB& t, const T& x, const T& ehs, const
   TRY(op_ln(e, e->norms[t.ln2], h2, e->cfg.unet_ln_eps, &n));
   TRY(linear(e, t.q2, n, &q2, C, 0));
   tfree(e, n);
-  TRY(linear(e, t.kv2, ehs, &kv, 2 * C, 0));
+  TRY(conv_simple(e, t.kv2, uin, &kv, 2 * C, 0));      // folded aux_conv_in + to_k|to_v: tokens = latent pixels, row-major
   ao = talloc(e, x.N, x.H, x.W, C, 0);
   {
     const half_t* kk = (const half_t*)kv.p;
@@ -980,7 +985,7 @@ static int vae_decode(sdm_ctx* e, const T& z, T* dec) {
   return 0;
 }
 
-static int unet_forward(sdm_ctx* e, const T& uin, const T& ehs, float* const* bias_lvl, T* out) {
+static int unet_forward(sdm_ctx* e, const T& uin, float* const* bias_lvl, T* out) {
   const sdm_config& c = e->cfg;
   const float eps = c.unet_res_eps;
   const int sf = c.stream_f32;
@@ -993,7 +998,7 @@ static int unet_forward(sdm_ctx* e, const T& uin, const T& ehs, float* const* bi
       TRY(resblock(e, e->u_down_res[i][j], h, nullptr, eps, &t));
       if (i < 3) {
         T t2;
-        TRY(transformer(e, e->u_down_tf[i][j], t, ehs, bias_lvl[i], &t2));
+        TRY(transformer(e, e->u_down_tf[i][j], t, uin, bias_lvl[i], &t2));
         tfree(e, t); t = t2;
       }
       h = t;                       // previous h stays alive as a skip
@@ -1007,7 +1012,7 @@ static int unet_forward(sdm_ctx* e, const T& uin, const T& ehs, float* const* bi
   }
   // mid (h aliases the last skip: do not free it here)
   TRY(resblock(e, e->u_mid0, h, nullptr, eps, &t)); h = t;
-  TRY(transformer(e, e->u_midtf, h, ehs, bias_lvl[3], &t)); tfree(e, h); h = t;
+  TRY(transformer(e, e->u_midtf, h, uin, bias_lvl[3], &t)); tfree(e, h); h = t;
   TRY(resblock(e, e->u_mid1, h, nullptr, eps, &t)); tfree(e, h); h = t;
   for (int i = 0; i < 4; ++i) {
     for (size_t j = 0; j < e->u_up_res[i].size(); ++j) {
@@ -1015,7 +1020,7 @@ static int unet_forward(sdm_ctx* e, const T& uin, const T& ehs, float* const* bi
       TRY(resblock(e, e->u_up_res[i][j], h, &s, eps, &t));   // cat([h, skip], dim=1) then ResBlock (replace.py:509-536)
       tfree(e, h); tfree(e, s); h = t;
       if (i > 0) {
-        TRY(transformer(e, e->u_up_tf[i][j], h, ehs, bias_lvl[3 - i], &t));
+        TRY(transformer(e, e->u_up_tf[i][j], h, uin, bias_lvl[3 - i], &t));
         tfree(e, h); h = t;
       }
     }
@@ -1055,12 +1060,11 @@ static int run_model(sdm_ctx* e, const T& x16, const T& plane, int B, int S, T* 
     TRY(op_conv(e, e->convs[e->quant], a));
   }
   tfree(e, moments);
-  // cross-attention context: aux_conv_in(trimap latent) as [B, l*l, ctx] (meta_arch.py:215-218)
-  T ehs;
-  TRY(conv_simple(e, e->u_aux, uin, &ehs, c.cross_attention_dim, 0));
+  // cross-attention context (meta_arch.py:215-218: aux_conv_in(trimap latent) as [B, l*l, ctx]) is never materialised:
+  // every block's K|V comes straight from the latent through the folded 3x3 conv (transformer())
   T lat;
-  TRY(unet_forward(e, uin, ehs, bias_lvl, &lat));
-  tfree(e, uin); tfree(e, ehs);
+  TRY(unet_forward(e, uin, bias_lvl, &lat));
+  tfree(e, uin);
   for (int k = 0; k < 4; ++k) tfree(e, biasbuf[k]);
   // post_quant_conv + decoder (meta_arch.py:255-256)
   T z;
@@ -1324,8 +1328,56 @@ int sdm_load_tensor(sdm_ctx* e, const char* name, int dtype, int ndim, const int
   return 1;
 }
 
+// Exact fold of aux_conv_in into every cross-attention K|V projection; fp64 accumulation on the host.
+static int fold_cross_kv(sdm_ctx* e) {
+  const sdm_config& c = e->cfg;
+  const int ctx = c.cross_attention_dim;
+  const float* H = e->hostblob.data();
+  // Waux transposed to [36][ctx] so that the inner loop is contiguous
+  std::vector<double> wa((size_t)36 * ctx), ba(ctx);
+  for (int m = 0; m < ctx; ++m) {
+    ba[m] = H[e->h_auxb + m];
+    for (int j = 0; j < 36; ++j) wa[(size_t)j * ctx + m] = H[e->h_auxw + (size_t)m * 36 + j];
+  }
+  std::vector<const TfB*> blocks;
+  for (auto& v : e->u_down_tf) for (auto& t : v) blocks.push_back(&t);
+  blocks.push_back(&e->u_midtf);
+  for (auto& v : e->u_up_tf) for (auto& t : v) blocks.push_back(&t);
+  std::vector<float> wf, bf;
+  for (const TfB* t : blocks) {
+    const int C = t->C;
+    ConvL& L = e->convs[t->kv2];
+    wf.assign((size_t)2 * C * 36, 0.f); bf.assign((size_t)2 * C, 0.f);
+    for (int o = 0; o < 2 * C; ++o) {
+      const float* wrow = H + (o < C ? t->k_hoff + (size_t)o * ctx : t->v_hoff + (size_t)(o - C) * ctx);
+      double b = 0.0;
+      for (int m = 0; m < ctx; ++m) b += (double)wrow[m] * ba[m];
+      bf[o] = (float)b;                                            // W_k . b_aux   (to_k / to_v have no bias of their own)
+      for (int j = 0; j < 36; ++j) {                               // j = ci*9 + tap (OIHW order of aux_conv_in.weight)
+        const double* wj = wa.data() + (size_t)j * ctx;
+        double acc = 0.0;
+        for (int m = 0; m < ctx; ++m) acc += (double)wrow[m] * wj[m];
+        wf[(size_t)o * 36 + j] = (float)acc;
+      }
+    }
+    // upload as an OIHW [2C][4][3][3] tensor; the 4 latent channels sit at channels 4..7 of the 16-channel U-Net input
+    if (ensure_buf(e, &e->stage, &e->stage_bytes, std::max(wf.size() * 4, (size_t)1 << 20)) != 0) return SDM_ERR_NOMEM;
+    SDM_CHECK_DEV(e, dev_memset(L.w, 0, (size_t)L.Cin_pad * 9 * L.Cout_pad * 2, e->stream));
+    SDM_CHECK_DEV(e, dev_memcpy_h2d(e->stage, wf.data(), wf.size() * 4, e->stream));
+    const size_t total = (size_t)L.Cin_pad * 9 * L.Cout_pad;
+    SDM_LAUNCH(pack_conv_weight_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 65535)), dim3(256), 0, e->stream, (const float*)e->stage,
+               L.w, 2 * C, 4, 9, L.Cin_pad, L.Cout_pad, 4, 0, 0);
+    SDM_CHECK_DEV(e, dev_sync(e->stream));
+    SDM_CHECK_DEV(e, dev_memcpy_h2d(e->stage, bf.data(), bf.size() * 4, e->stream));
+    SDM_LAUNCH(pack_bias_kernel, dim3(sdm_cdiv(L.Cout_pad, 256)), dim3(256), 0, e->stream, (const float*)e->stage, L.b, 2 * C, L.Cout_pad, 0, 0);
+    SDM_CHECK_DEV(e, dev_sync(e->stream));
+  }
+  return 0;
+}
+
 int sdm_finalize_weights(sdm_ctx* e) {
   if (!e) return SDM_ERR_INVALID;
+  { int rc = fold_cross_kv(e); if (rc) return rc; }
   e->missing.clear();
   for (auto& k : e->slot_order) if (!e->slots[k].loaded) e->missing.push_back(k);
   e->variants.clear();
