@@ -600,9 +600,12 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
     char d[256];
     snprintf(d, sizeof(d), "%s N=%d Hout=%d Wout=%d Cin=%d Cout=%d s=%d up=%d f32in=%d cfg=%d", L.name.c_str(), p.N, p.Hout, p.Wout, L.Cin_pad, L.O, a.stride,
              a.up, p.in_f32, cfg);
-    prof_begin(e, L.ntaps == 9 ? "conv3x3_mfma" : "gemm_mfma", flops, bytes, d);
+    // thin convs (<= 16 real input or output channels: conv_in/conv_out, latent convs, folded cross-attn K|V) are HBM-bound
+    // (SURVEY.md 2.2 "thin convs"); everything else is MFMA-bound
+    const bool thin = (L.ntaps == 9) && (L.I <= 16 || L.O <= 16);
+    prof_begin(e, L.ntaps == 9 ? (thin ? "conv3x3_thin" : "conv3x3_mfma") : "gemm_mfma", flops, bytes, d);
   } else {
-    prof_begin(e, L.ntaps == 9 ? "conv3x3_mfma" : "gemm_mfma", flops, bytes);
+    prof_begin(e, "conv", flops, bytes);
   }
   int rc = 0;
   if (L.ntaps == 1 && p.stats && p.N > 1) {
