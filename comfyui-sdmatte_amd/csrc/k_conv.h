@@ -49,6 +49,9 @@ struct ConvParams {
   const void* res; int res_f32; int res_C;
   int epi;                              // 0: linear, 1: GEGLU (cols come in [u32|g32] groups of 64)
   float out_scale;
+  const float* gn_scale;                // GN template arg: fused GroupNorm apply on load: x*scale[n][c] + shift[n][c] (+SiLU),
+  const float* gn_shift;                // [N][C0+C1] fp32 each (from gn_finalize_*); the table of this image sits in LDS
+  int gn_silu;
   int ablate;                           // debug/bench only (sdm_bench_conv): 1 skip global loads, 2 skip LDS writes, 4 skip MFMA,
                                         // 8 skip the epilogue stores -- after the first K-chunk; always 0 in the engine
   float* stats;                         // optional [N][gridDim.x*WM][Cout_store][2]: per-(image, wave row-tile, channel) partial
@@ -78,7 +81,7 @@ struct ConvCfg {
   static_assert(!DB || KC == 16, "swizzled double-buffered tiles assume 2 halves per row");
 };
 
-template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN, int IN_F32, int DB>
+template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN, int IN_F32, int DB, int GN>
 __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BN == 128) ? 2 : 1)   // big 4-wave tiles: keep 2 blocks/CU resident
 conv_mfma_kernel(ConvParams p) {
   using C = ConvCfg<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN, DB>;
@@ -113,6 +116,16 @@ conv_mfma_kernel(ConvParams p) {
     for (int j = 0; j < NTL; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  // fused GroupNorm apply: scale[Cin] | shift[Cin] of this image, behind the A/B tile region
+  float* gn_tab = (float*)(smem + (DB ? 2 : 1) * C::TILE_BYTES);
+  if (GN) {
+    for (int c = tid; c < Cin; c += NT) {
+      gn_tab[c] = p.gn_scale[(size_t)img * Cin + c];
+      gn_tab[Cin + c] = p.gn_shift[(size_t)img * Cin + c];
+    }
+    // visibility: the first write_lds happens after the __syncthreads() at the top of the K loop
+  }
 
   // per-lane fragment bases.  Padded layout: byte offsets.  Swizzled (DB) layout: A keeps the halo ROW (the swizzle bit
   // depends on the row, which moves with the tap), B the final byte offset (its swizzle bit only depends on co).
@@ -193,12 +206,36 @@ conv_mfma_kernel(ConvParams p) {
       b_raw[i] = sdm_buffer_load16(rsw, voff, (chunk_row0 + (unsigned int)(sc * NTAPS + tap)) * b_row_bytes);
     }
   };
-  auto write_lds = [&](unsigned char* Ad, unsigned char* Bd) {
+  auto write_lds = [&](unsigned char* Ad, unsigned char* Bd, int c0w) {
+    f32x4 gs0, gs1, gh0, gh1;
+    if (GN) {                      // the 8 channels of this thread are the same for every i
+      const float* tb = gn_tab + c0w + a_part;
+      gs0 = *(const f32x4*)tb; gs1 = *(const f32x4*)(tb + 4);
+      gh0 = *(const f32x4*)(tb + Cin); gh1 = *(const f32x4*)(tb + Cin + 4);
+    }
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
       if (tid + i * NT < A_VEC) {
         f16x8 val;
-        if (IN_F32) {
+        if (GN) {
+          float x[8];
+          if (IN_F32) {
+            const f32x4 lo = __builtin_bit_cast(f32x4, a_raw[i][0]), hi4 = __builtin_bit_cast(f32x4, a_raw[i][IN_F32 ? 1 : 0]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { x[e] = lo[e]; x[4 + e] = hi4[e]; }
+          } else {
+            const f16x8 h8 = __builtin_bit_cast(f16x8, a_raw[i][0]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = (float)h8[e];
+          }
+          const bool inside = a_pix[i] >= 0;           // zero padding stays zero AFTER the normalisation
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float y = x[e] * (e < 4 ? gs0[e & 3] : gs1[e & 3]) + (e < 4 ? gh0[e & 3] : gh1[e & 3]);
+            if (p.gn_silu) y = y * sdm_rcp(1.0f + sdm_exp2(-y * SDM_LOG2E));
+            val[e] = inside ? (half_t)y : (half_t)0.0f;
+          }
+        } else if (IN_F32) {
           const f32x4 lo = __builtin_bit_cast(f32x4, a_raw[i][0]), hi4 = __builtin_bit_cast(f32x4, a_raw[i][IN_F32 ? 1 : 0]);
 #pragma unroll
           for (int e = 0; e < 4; ++e) { val[e] = (half_t)lo[e]; val[4 + e] = (half_t)hi4[e]; }
@@ -223,7 +260,8 @@ conv_mfma_kernel(ConvParams p) {
 
   issue_loads(0);
   if (DB) {                      // double-buffered tiles: chunk 0 is staged up front, ONE barrier per K-chunk afterwards
-    write_lds(As, Bs);
+    if (GN) __syncthreads();     // gn_tab filled
+    write_lds(As, Bs, 0);
     __syncthreads();
   }
   for (int c0 = 0; c0 < Cin; c0 += KC) {
@@ -234,7 +272,7 @@ conv_mfma_kernel(ConvParams p) {
       if (c0 + KC < Cin) issue_loads(c0 + KC);       // in flight during the MFMAs below
     } else {
       __syncthreads();            // every wave has finished reading the previous chunk from LDS
-      if (!(p.ablate & 2) || c0 == 0) write_lds(As, Bs);
+      if (!(p.ablate & 2) || c0 == 0) write_lds(As, Bs, c0);
       __syncthreads();
       if (c0 + KC < Cin && !(p.ablate & 1)) issue_loads(c0 + KC);
       if ((p.ablate & 4) && c0 > 0) continue;
@@ -300,7 +338,7 @@ conv_mfma_kernel(ConvParams p) {
     if (DB) {
       if (c0 + KC < Cin) {          // the other half was last read one iteration ago, before the previous barrier
         unsigned char* An = smem + (((c0 / KC) & 1) ^ 1) * C::TILE_BYTES;
-        write_lds(An, An + C::A_BYTES);
+        write_lds(An, An + C::A_BYTES, c0 + KC);
       }
       __syncthreads();
     }

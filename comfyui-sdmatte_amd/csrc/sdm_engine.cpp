@@ -67,18 +67,31 @@ static inline size_t rupz(size_t a, size_t b) { return ((a + b - 1) / b) * b; }
 // ------------------------------------------------------------------------------------------------
 // conv tile configurations
 // ------------------------------------------------------------------------------------------------
-template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN, int DB = 0>
+template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN, int DB = 0, int GNOK = 0>
 static void launch_conv_t(const ConvParams& p, void* stream) {
   using C = ConvCfg<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN, DB>;
   dim3 grid;
   if (NTAPS == 9) grid = dim3(sdm_cdiv(p.Wout, TW) * sdm_cdiv(p.Hout, TH), sdm_cdiv(p.Cout_pad, BN), p.N);
   else grid = dim3((unsigned)((p.M + C::BM - 1) / C::BM), sdm_cdiv(p.Cout_pad, BN), 1);
+  if (GNOK && p.gn_scale) {      // fused GroupNorm apply: the scale|shift table of the image follows the tiles in LDS
+    const size_t smem = (size_t)C::SMEM + (size_t)(p.C0 + p.C1) * 8;
+    if (p.in_f32) {
+      auto k = conv_mfma_kernel<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN, 1, DB, GNOK>;
+      SDM_SET_SMEM(k, C::SMEM + 1024 * 8);
+      SDM_LAUNCH(k, grid, dim3(C::NTHREADS), smem, stream, p);
+    } else {
+      auto k = conv_mfma_kernel<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN, 0, DB, GNOK>;
+      SDM_SET_SMEM(k, C::SMEM + 1024 * 8);
+      SDM_LAUNCH(k, grid, dim3(C::NTHREADS), smem, stream, p);
+    }
+    return;
+  }
   if (p.in_f32) {
-    auto k = conv_mfma_kernel<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN, 1, DB>;
+    auto k = conv_mfma_kernel<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN, 1, DB, 0>;
     SDM_SET_SMEM(k, C::SMEM);
     SDM_LAUNCH(k, grid, dim3(C::NTHREADS), C::SMEM, stream, p);
   } else {
-    auto k = conv_mfma_kernel<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN, 0, DB>;
+    auto k = conv_mfma_kernel<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN, 0, DB, 0>;
     SDM_SET_SMEM(k, C::SMEM);
     SDM_LAUNCH(k, grid, dim3(C::NTHREADS), C::SMEM, stream, p);
   }
@@ -104,6 +117,7 @@ static int conv_pick_cfg(int ntaps, int stride, const ConvParams& p) {
   const int n = conv_num_cfgs(ntaps, stride);
   long best_blocks = -1;
   int best = -1;
+  if (ntaps == 9 && stride == 1 && getenv("SDM_FORCE_CFG0") && conv_cfg_ok(t[0], p)) return 0;   // test hook: exercise the 256x128 tile (+ fused GroupNorm) at tiny sizes
   static const bool use_db = getenv("SDM_CONV_DB") && getenv("SDM_CONV_DB")[0] == '1';   // A/B hook for the 512x128 double-buffered tile
   for (int i = 0; i < n; ++i) {
     if (!conv_cfg_ok(t[i], p)) continue;
@@ -129,7 +143,7 @@ static int conv_pick_cfg(int ntaps, int stride, const ConvParams& p) {
 static int launch_conv(int ntaps, int stride, int cfg, const ConvParams& p, void* stream) {
   if (ntaps == 9 && stride == 1) {
     switch (cfg) {
-      case 0: launch_conv_t<9, 1, 8, 32, 128, 16, 2, 2>(p, stream); return 0;
+      case 0: launch_conv_t<9, 1, 8, 32, 128, 16, 2, 2, 0, 1>(p, stream); return 0;   // the only tile with the fused-GroupNorm variant
       case 1: launch_conv_t<9, 1, 4, 32, 64, 32, 4, 1>(p, stream); return 0;
       case 2: launch_conv_t<9, 1, 8, 8, 64, 16, 2, 1>(p, stream); return 0;
       case 3: launch_conv_t<9, 1, 16, 32, 128, 16, 4, 2, 1>(p, stream); return 0;   // 512 px x 128 co, 8 waves, swizzled double-buffered LDS tiles
@@ -271,6 +285,8 @@ static std::string g_create_err;
     int e_ = (expr);                                                                          \
     if (e_ != 0) SDM_FAIL(ctx, SDM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, dev_errstr(e_), __FILE__, __LINE__); \
   } while (0)
+
+#define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
 // ------------------------------------------------------------------------------------------------
 // model construction (mirrors comfyui-sdmatte_amd/weights.py::weight_schema)
@@ -557,6 +573,7 @@ struct ConvArgs {
   float out_scale = 1.0f;
   const float* bias_override = nullptr; const int* bias_sel = nullptr;
   int force_cfg = -1;
+  const float* gn_scale = nullptr; const float* gn_shift = nullptr; int gn_silu = 0;   // fused GroupNorm apply (tile cfg 0 only)
 };
 
 static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
@@ -576,12 +593,15 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
   p.out_ch_off = a.out_ch_off;
   if (a.res) { p.res = a.res->p; p.res_f32 = a.res->f32; p.res_C = a.res->C; }
   p.epi = L.geglu; p.out_scale = a.out_scale;
+  p.gn_scale = a.gn_scale; p.gn_shift = a.gn_shift; p.gn_silu = a.gn_silu;
   if ((long)a.in0->rows() >= (1L << 31) || p.M >= (1L << 31)) SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: tensor too large for 32-bit pixel indices", L.name.c_str());
   if (p.C0 + p.C1 != L.Cin_pad) SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: input channels %d+%d != %d", L.name.c_str(), p.C0, p.C1, L.Cin_pad);
   if (a.in1 && a.in1->f32 != a.in0->f32) SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: concat sources differ in dtype", L.name.c_str());
   int cfg = a.force_cfg >= 0 ? a.force_cfg : conv_pick_cfg(L.ntaps, a.stride, p);
   if (cfg < 0 || cfg >= conv_num_cfgs(L.ntaps, a.stride) || !conv_cfg_ok(conv_cfg_table(L.ntaps, a.stride)[cfg], p))
     SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: no tile configuration for Cin=%d+%d (cfg %d)", L.name.c_str(), p.C0, p.C1, cfg);
+  if (a.gn_scale && !(L.ntaps == 9 && a.stride == 1 && cfg == 0 && p.C0 + p.C1 <= 1024))
+    SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: fused GroupNorm requested for an unsupported tile configuration", L.name.c_str());
   if (a.out->want_stats) {
     if (L.geglu || a.out_ch_off) SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: fused statistics unsupported with this epilogue", L.name.c_str());
     const ConvCfgInfo& ci = conv_cfg_table(L.ntaps, a.stride)[cfg];
@@ -629,46 +649,64 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
   return 0;
 }
 
-// scratch for GroupNorm statistics: sums (double [N][G][2]) + scale/shift (float [N][C] each), allocated from the arena
-static int op_groupnorm_raw(sdm_ctx* e, const void* in0, const void* in1, int C0, int C1, int in_f32, int N, int HW, int groups,
-                            const float* gamma, const float* beta, float eps, int silu, half_t* out, const float* st0 = nullptr,
-                            int rows0 = 0, const float* st1 = nullptr, int rows1 = 0, bool have_stats = false) {
+// GroupNorm statistics -> per-(image, channel) scale = rstd*gamma and shift = beta - mean*rstd*gamma.
+// scratch layout: [N][max(groups,C)][2] doubles (sums) | scale [N][C] floats | shift [N][C] floats.  The caller frees `scratch`.
+static int gn_scale_shift(sdm_ctx* e, const void* in0, const void* in1, int C0, int C1, int in_f32, int N, int HW, int groups, const float* gamma,
+                          const float* beta, float eps, const float* st0, int rows0, const float* st1, int rows1, bool have_stats, T* scratch,
+                          float** scale_out, float** shift_out) {
   const int C = C0 + C1;
   if (C % 8 || (C / groups) * groups != C || C0 % 8) SDM_FAIL(e, SDM_ERR_INVALID, "groupnorm: bad channels %d+%d", C0, C1);
-  // scratch: [N][groups][2] doubles (stats kernel path) or [N][C][2] doubles (fused path), then scale/shift [N][C] floats each
   const size_t sum_bytes = (size_t)N * std::max(groups, C) * 16;
-  T scratch = talloc(e, 1, 1, 1, (int)((sum_bytes + (size_t)N * C * 8 + 3) / 4), 1);
-  if (!e->dry) {
-    double* sums = (double*)scratch.p;
-    float* scale = (float*)((unsigned char*)scratch.p + sum_bytes);
-    float* shift = scale + (size_t)N * C;
+  *scratch = talloc(e, 1, 1, 1, (int)((sum_bytes + (size_t)N * C * 8 + 3) / 4), 1);
+  *scale_out = nullptr; *shift_out = nullptr;
+  if (e->dry) return 0;
+  double* sums = (double*)scratch->p;
+  float* scale = (float*)((unsigned char*)scratch->p + sum_bytes);
+  float* shift = scale + (size_t)N * C;
+  *scale_out = scale; *shift_out = shift;
+  if (have_stats) {
+    SDM_CHECK_DEV(e, dev_memset(sums, 0, (size_t)N * C * 16, e->stream));
+    double* s0 = sums;
+    double* s1 = sums + (size_t)N * C0 * 2;
+    prof_begin(e, "gn_reduce", 0, ((double)rows0 * C0 + (double)rows1 * C1) * N * 8);
+    SDM_LAUNCH(gn_reduce_partials_kernel, dim3(sdm_cdiv(C0, 32), N, std::max(1, std::min(16, rows0 / 64))), dim3(256), 0, e->stream, st0, s0, rows0, C0);
+    if (C1) SDM_LAUNCH(gn_reduce_partials_kernel, dim3(sdm_cdiv(C1, 32), N, std::max(1, std::min(16, rows1 / 64))), dim3(256), 0, e->stream, st1, s1, rows1, C1);
+    prof_end(e);
+    SDM_LAUNCH(gn_finalize_ch_kernel, dim3(sdm_cdiv(N * C, 256)), dim3(256), 0, e->stream, (const double*)s0, (const double*)s1, C0, C1, gamma, beta,
+               scale, shift, N, groups, (long)HW, eps);
+  } else {
     GnSrc s; s.in0 = in0; s.in1 = in1; s.C0 = C0; s.C1 = C1; s.in_f32 = in_f32; s.HW = HW;
     const int CV = C / 8;
     const int slots = std::max(1, 256 / CV);
     const int threads = rup(CV * slots, 64);
-    int ppb = std::max(slots * 8, sdm_cdiv(HW, 2048 / std::max(1, N)));   // pixels per block
+    int ppb = std::max(slots * 8, sdm_cdiv(HW, 2048 / std::max(1, N)));
     ppb = rup(ppb, slots);
     const int nb = sdm_cdiv(HW, ppb);
-    const double bytes_in = (double)N * HW * C * (in_f32 ? 4 : 2);
-    if (have_stats) {
-      SDM_CHECK_DEV(e, dev_memset(sums, 0, (size_t)N * C * 16, e->stream));
-      double* s0 = sums;
-      double* s1 = sums + (size_t)N * C0 * 2;
-      prof_begin(e, "gn_reduce", 0, ((double)rows0 * C0 + (double)rows1 * C1) * N * 8);
-      SDM_LAUNCH(gn_reduce_partials_kernel, dim3(sdm_cdiv(C0, 32), N, std::max(1, std::min(16, rows0 / 64))), dim3(256), 0, e->stream, st0, s0, rows0, C0);
-      if (C1) SDM_LAUNCH(gn_reduce_partials_kernel, dim3(sdm_cdiv(C1, 32), N, std::max(1, std::min(16, rows1 / 64))), dim3(256), 0, e->stream, st1, s1, rows1, C1);
-      prof_end(e);
-      SDM_LAUNCH(gn_finalize_ch_kernel, dim3(sdm_cdiv(N * C, 256)), dim3(256), 0, e->stream, (const double*)s0, (const double*)s1, C0, C1, gamma, beta,
-                 scale, shift, N, groups, (long)HW, eps);
-    } else {
-      SDM_CHECK_DEV(e, dev_memset(sums, 0, (size_t)N * groups * 16, e->stream));
-      prof_begin(e, "gn_stats", 0, bytes_in);
-      SDM_LAUNCH(gn_stats_kernel, dim3(nb, N), dim3(threads), (size_t)2 * C * 4, e->stream, s, sums, groups, ppb);
-      prof_end(e);
-      SDM_LAUNCH(gn_finalize_kernel, dim3(sdm_cdiv(N * C, 256)), dim3(256), 0, e->stream, (const double*)sums, gamma, beta, scale, shift, N, C,
-                 groups, (long)HW * (C / groups), eps);
-    }
-    prof_begin(e, "gn_apply", 0, bytes_in + (double)N * HW * C * 2);
+    SDM_CHECK_DEV(e, dev_memset(sums, 0, (size_t)N * groups * 16, e->stream));
+    prof_begin(e, "gn_stats", 0, (double)N * HW * C * (in_f32 ? 4 : 2));
+    SDM_LAUNCH(gn_stats_kernel, dim3(nb, N), dim3(threads), (size_t)2 * C * 4, e->stream, s, sums, groups, ppb);
+    prof_end(e);
+    SDM_LAUNCH(gn_finalize_kernel, dim3(sdm_cdiv(N * C, 256)), dim3(256), 0, e->stream, (const double*)sums, gamma, beta, scale, shift, N, C,
+               groups, (long)HW * (C / groups), eps);
+  }
+  return 0;
+}
+
+static int op_groupnorm_raw(sdm_ctx* e, const void* in0, const void* in1, int C0, int C1, int in_f32, int N, int HW, int groups,
+                            const float* gamma, const float* beta, float eps, int silu, half_t* out, const float* st0 = nullptr,
+                            int rows0 = 0, const float* st1 = nullptr, int rows1 = 0, bool have_stats = false) {
+  const int C = C0 + C1;
+  T scratch; float* scale; float* shift;
+  TRY(gn_scale_shift(e, in0, in1, C0, C1, in_f32, N, HW, groups, gamma, beta, eps, st0, rows0, st1, rows1, have_stats, &scratch, &scale, &shift));
+  if (!e->dry) {
+    GnSrc s; s.in0 = in0; s.in1 = in1; s.C0 = C0; s.C1 = C1; s.in_f32 = in_f32; s.HW = HW;
+    const int CV = C / 8;
+    const int slots = std::max(1, 256 / CV);
+    const int threads = rup(CV * slots, 64);
+    int ppb = std::max(slots * 8, sdm_cdiv(HW, 2048 / std::max(1, N)));
+    ppb = rup(ppb, slots);
+    const int nb = sdm_cdiv(HW, ppb);
+    prof_begin(e, "gn_apply", 0, (double)N * HW * C * (in_f32 ? 4 : 2) + (double)N * HW * C * 2);
     SDM_LAUNCH(gn_apply_kernel, dim3(nb, N), dim3(threads), 0, e->stream, s, (const float*)scale, (const float*)shift, out, silu, ppb);
     prof_end(e);
   }
@@ -745,7 +783,6 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
   return 0;
 }
 
-#define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
 // ------------------------------------------------------------------------------------------------
 // blocks
@@ -761,21 +798,56 @@ static int conv_simple(sdm_ctx* e, int layer, const T& in, T* out, int Cout_stor
   return op_conv(e, L, a);
 }
 
+// Would op_conv pick tile cfg 0 (the one that has the fused-GroupNorm variant) for this 3x3 stride-1 conv?
+static bool conv_can_fuse_gn(sdm_ctx* e, const ConvL& L, const T& x, const T* x2) {
+  static const bool off = getenv("SDM_NO_GN_FUSE") != nullptr;        // A/B hook
+  if (off || L.ntaps != 9) return false;
+  const int Cin = x.C + (x2 ? x2->C : 0);
+  if (Cin > 1024 || Cin != L.Cin_pad) return false;
+  ConvParams p;
+  memset(&p, 0, sizeof(p));
+  p.C0 = x.C; p.C1 = x2 ? x2->C : 0; p.in_f32 = x.f32; p.N = x.N; p.Hin = x.H; p.Win = x.W; p.Hout = x.H; p.Wout = x.W; p.Cout_pad = L.Cout_pad;
+  p.M = x.rows();
+  return conv_pick_cfg(9, 1, p) == 0;
+  (void)e;
+}
+
+// GroupNorm(32)(+SiLU) followed by a 3x3 stride-1 conv.  When the conv runs on the 256x128 tile the normalisation is applied
+// inside the conv's operand staging (no normalised copy of the activation is ever written); otherwise the stand-alone apply
+// kernel produces the fp16 operand first.  `a` carries everything except the inputs.
+static int gn_conv(sdm_ctx* e, const NormL& n, const ConvL& L, const T& x, const T* x2, int silu, float eps, ConvArgs a) {
+  const int C = x.C + (x2 ? x2->C : 0);
+  if (C != n.C) SDM_FAIL(e, SDM_ERR_INVALID, "groupnorm: C %d != %d", C, n.C);
+  if (conv_can_fuse_gn(e, L, x, x2)) {
+    const bool hs = x.sbytes && (!x2 || x2->sbytes);
+    T scratch; float* scale; float* shift;
+    TRY(gn_scale_shift(e, x.p, x2 ? x2->p : nullptr, x.C, x2 ? x2->C : 0, x.f32, x.N, x.H * x.W, e->cfg.groups, n.g, n.b, eps, x.stats, x.srows,
+                       x2 ? x2->stats : nullptr, x2 ? x2->srows : 0, hs, &scratch, &scale, &shift));
+    a.in0 = &x; a.in1 = x2;
+    a.gn_scale = e->dry ? (const float*)16 : scale; a.gn_shift = shift; a.gn_silu = silu;
+    a.force_cfg = 0;
+    int rc = op_conv(e, L, a);
+    tfree(e, scratch);
+    return rc;
+  }
+  T h;
+  TRY(op_gn(e, n, x, x2, silu, eps, &h));
+  a.in0 = &h; a.in1 = nullptr;
+  int rc = op_conv(e, L, a);
+  tfree(e, h);
+  return rc;
+}
+
 // ResnetBlock2D (Appendix A.3).  x (+ x2: channel concat) -> new stream tensor; frees nothing.
 static int resblock(sdm_ctx* e, const ResB& r, const T& x, const T* x2, float eps, T* out) {
   const int sf = e->cfg.stream_f32;
-  T h, h1, h2;
-  TRY(op_gn(e, e->norms[r.norm1], x, x2, 1, eps, &h));
-  h1 = talloc(e, x.N, x.H, x.W, r.cout, 0);
+  T h1 = talloc(e, x.N, x.H, x.W, r.cout, 0);
   TRY(tstats(e, h1));
   {
-    ConvArgs a; a.in0 = &h; a.out = &h1;
+    ConvArgs a; a.out = &h1;
     if (r.temb >= 0) { a.bias_override = e->tembs[r.temb].table; a.bias_sel = e->d_bias_sel; }
-    TRY(op_conv(e, e->convs[r.conv1], a));
+    TRY(gn_conv(e, e->norms[r.norm1], e->convs[r.conv1], x, x2, 1, eps, a));
   }
-  tfree(e, h);
-  TRY(op_gn(e, e->norms[r.norm2], h1, nullptr, 1, eps, &h2));
-  tfree(e, h1);
   T xs; const T* resid = &x;
   if (r.sc >= 0) {
     xs = talloc(e, x.N, x.H, x.W, r.cout, sf);
@@ -788,10 +860,10 @@ static int resblock(sdm_ctx* e, const ResB& r, const T& x, const T* x2, float ep
   *out = talloc(e, x.N, x.H, x.W, r.cout, sf);
   TRY(tstats(e, *out));
   {
-    ConvArgs a; a.in0 = &h2; a.out = out; a.res = resid;
-    TRY(op_conv(e, e->convs[r.conv2], a));
+    ConvArgs a; a.out = out; a.res = resid;
+    TRY(gn_conv(e, e->norms[r.norm2], e->convs[r.conv2], h1, nullptr, 1, eps, a));
   }
-  tfree(e, h2);
+  tfree(e, h1);
   if (r.sc >= 0) tfree(e, xs);
   return 0;
 }
@@ -967,8 +1039,9 @@ static int vae_encode(sdm_ctx* e, const T& x16, T* moments) {
   TRY(resblock(e, e->enc_mid0, h, nullptr, eps, &t)); tfree(e, h); h = t;
   TRY(vae_attention(e, e->enc_attn, h, &t)); tfree(e, h); h = t;
   TRY(resblock(e, e->enc_mid1, h, nullptr, eps, &t)); tfree(e, h); h = t;
-  TRY(op_gn(e, e->norms[e->enc_norm_out], h, nullptr, 1, eps, &t)); tfree(e, h); h = t;
-  TRY(conv_simple(e, e->enc_conv_out, h, moments, 16, 0)); tfree(e, h);
+  *moments = talloc(e, h.N, h.H, h.W, 16, 0);
+  { ConvArgs a; a.out = moments; TRY(gn_conv(e, e->norms[e->enc_norm_out], e->convs[e->enc_conv_out], h, nullptr, 1, eps, a)); }
+  tfree(e, h);
   return 0;
 }
 
@@ -983,8 +1056,9 @@ static int vae_decode(sdm_ctx* e, const T& z, T* dec) {
     for (auto& r : e->dec_res[i]) { TRY(resblock(e, r, h, nullptr, eps, &t)); tfree(e, h); h = t; }
     if (i < 3) { TRY(conv_simple(e, e->dec_up[i], h, &t, e->cfg.vae_channels[3 - i], e->cfg.stream_f32, 1, 0, 1, nullptr, 1.0f, true)); tfree(e, h); h = t; }
   }
-  TRY(op_gn(e, e->norms[e->dec_norm_out], h, nullptr, 1, eps, &t)); tfree(e, h); h = t;
-  TRY(conv_simple(e, e->dec_conv_out, h, dec, 4, 1)); tfree(e, h);
+  *dec = talloc(e, h.N, h.H, h.W, 4, 1);
+  { ConvArgs a; a.out = dec; TRY(gn_conv(e, e->norms[e->dec_norm_out], e->convs[e->dec_conv_out], h, nullptr, 1, eps, a)); }
+  tfree(e, h);
   return 0;
 }
 
@@ -1029,9 +1103,10 @@ static int unet_forward(sdm_ctx* e, const T& uin, float* const* bias_lvl, T* out
     }
     if (i < 3) { TRY(conv_simple(e, e->u_up_us[i], h, &t, c.unet_channels[3 - i], sf, 1, 0, 1, nullptr, 1.0f, true)); tfree(e, h); h = t; }
   }
-  TRY(op_gn(e, e->norms[e->u_norm_out], h, nullptr, 1, eps, &t)); tfree(e, h); h = t;
   // label_latent / scaling_factor (meta_arch.py:254) folded into the conv_out epilogue
-  TRY(conv_simple(e, e->u_conv_out, h, out, 16, 0, 1, 0, 0, nullptr, 1.0f / c.vae_scaling_factor)); tfree(e, h);
+  *out = talloc(e, h.N, h.H, h.W, 16, 0);
+  { ConvArgs a; a.out = out; a.out_scale = 1.0f / c.vae_scaling_factor; TRY(gn_conv(e, e->norms[e->u_norm_out], e->convs[e->u_conv_out], h, nullptr, 1, eps, a)); }
+  tfree(e, h);
   return 0;
 }
 

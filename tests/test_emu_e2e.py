@@ -58,6 +58,27 @@ def test_emu_full_forward_matches_oracle(pkg):
     eng2.close()
 
 
+def test_emu_fused_groupnorm_path(pkg, monkeypatch):
+    """Force the 256x128 conv tile so that GroupNorm+SiLU is applied inside the conv operand staging (the production path at
+    real sizes) and compare with the oracle and with the un-fused path."""
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    from comfyui_sdmatte_amd.weights import synthetic_state_dict
+    from comfyui_sdmatte_amd.synth import synthetic_inputs
+    from oracle import sdmatte_oracle as O
+    cfg = SDMatteConfig.tiny()
+    w = synthetic_state_dict(cfg, 0)
+    img, tri = synthetic_inputs(1, 64, 64)
+    ref, _ = O.apply_matte(w, cfg.as_dict(), img, tri, 64, mask_refine=False)
+    eng = _emu_engine(cfg)
+    eng.load_state_dict(w)
+    monkeypatch.setenv("SDM_FORCE_CFG0", "1")
+    eng.profile(True)
+    a = eng.apply_matte(img, tri, 64)
+    d = (a - ref).abs()
+    assert d.max().item() < 1e-2 and d.mean().item() < 1.5e-3, (d.max().item(), d.mean().item())
+    eng.close()
+
+
 def _dp_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
