@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
 #define ATTN512_X_BYTES (8 * 16 * 64 * 4)
 #define ATTN512_SMEM (ATTN512_KS_BYTES + ATTN512_VS_BYTES + ATTN512_X_BYTES)
 
-__global__ void __launch_bounds__(512) attn_d512_kernel(AttnParams p) {
+__global__ void __launch_bounds__(512) attn_d512_sync_kernel(AttnParams p) {
   SDM_DYN_SMEM(smem);
   constexpr int PKK = ATTN512_PKK, PKV = ATTN512_PKV;
   unsigned char* Ks = smem;
@@ -381,6 +381,173 @@ __global__ void __launch_bounds__(512) attn_d512_kernel(AttnParams p) {
   l_i += __shfl_xor(l_i, 32);
   const float inv = 1.0f / l_i;
   // epilogue: two passes of 4 d-tiles (128 d) through per-wave LDS staging [32 q][128 d] fp16, pitch 272
+  constexpr int PS = 272;
+  unsigned char* stg = smem + wave * (32 * PS);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();
+#pragma unroll
+    for (int d4 = 0; d4 < 4; ++d4) {
+      const int dt = half * 4 + d4;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f16x4 h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = (half_t)(o[dt][4 * g + e] * inv);
+        *(f16x4*)(stg + l31 * PS + (d4 * 32 + 8 * g + 4 * hi) * 2) = h;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+      const int row = pass * 4 + (lane >> 4), part = lane & 15;
+      const int qg = q0 + row;
+      if (qg < p.Lq)
+        *(f16x8*)(p.o + (size_t)b * p.o_bs + (size_t)qg * p.ldo + dh * 256 + half * 128 + part * 8) =
+            *(const f16x8*)(stg + row * PS + part * 16);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// d = 512, pipelined: same work split as attn_d512_sync_kernel (8 waves = 4 query groups x 2 d-halves), but the K and
+// V^T tiles arrive by LDS-DMA into DOUBLE-BUFFERED, unpadded, XOR-swizzled LDS images, so tile t+1 streams in while
+// tile t is multiplied (the synchronous kernel spends ~4/5 of its time waiting on load -> LDS write -> barrier chains;
+// there are no registers left to prefetch through).  LDS: 2 x 32 KB K + 2 x 32 KB V^T + 32 KB exchange = all 160 KB.
+//   K image  [32 rows][64 chunks of 16 B]: row rho holds key k0 + pi(rho), chunk position c' holds source chunk
+//            c' ^ (rho & 15)  -> conflict-free ds_read_b128 down a column of 16 rows.
+//   V^T image [512 d][4 chunks]: position c' of row r holds source chunk c' ^ ((r >> 2) & 3).
+//   pi swaps bits 2 and 3 of the MFMA row index, so that the 8 S^T values a lane owns per 16-key step are 8
+//   CONSECUTIVE keys and the matching V^T fragment is ONE aligned ds_read_b128 (was two ds_read_b64).
+// ------------------------------------------------------------------------------------------------
+#define ATTN512P_K_BYTES (32 * 1024)
+#define ATTN512P_V_BYTES (512 * 64)
+#define ATTN512P_X_OFF (2 * ATTN512P_K_BYTES + 2 * ATTN512P_V_BYTES)
+#define ATTN512P_SMEM (ATTN512P_X_OFF + ATTN512_X_BYTES)
+
+__global__ void __launch_bounds__(512) attn_d512_kernel(AttnParams p) {
+  SDM_DYN_SMEM(smem);
+  float* Xs = (float*)(smem + ATTN512P_X_OFF);
+  const int tid = threadIdx.x, lane = tid & 63, wave = SDM_UNIFORM_I(tid >> 6);
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int qgp = wave >> 1, dh = wave & 1;
+  int b, head_unused, qblk;
+  if (!attn_block_coords(p, blockIdx.x, b, head_unused, qblk)) return;
+  const int q0 = qblk * 128 + qgp * 32;
+
+  f16x8 qf[16];
+  {
+    int qrow = q0 + l31;
+    if (qrow > p.Lq - 1) qrow = p.Lq - 1;
+    const half_t* qp = p.q + (size_t)b * p.q_bs + (size_t)qrow * p.ldq + dh * 256 + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) qf[ks] = *(const f16x8*)(qp + ks * 16);
+  }
+  f32x16 o[8];
+#pragma unroll
+  for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.0f;
+  float m_i = SDM_NEG_BIG, l_i = 0.0f;
+
+  const half_t* kbase = p.k + (size_t)b * p.k_bs;
+  const half_t* vbase = p.vt + (size_t)b * p.vt_bs;
+  const int ntiles = (p.Lk + 31) / 32;
+
+  // DMA descriptors of this wave: 4 K rows (rho = 4*wave + i) and 4 V^T row groups (16 d-rows each, g = 4*wave + i).
+  // Buffer form: SGPR descriptors + one 32-bit per-lane offset; row/tile offsets are wave-uniform (SGPR).
+  const sdm_rsrc rsK = sdm_make_rsrc(kbase, (unsigned int)((size_t)p.Lk * p.ldk * 2));
+  const sdm_rsrc rsV = sdm_make_rsrc(vbase, (unsigned int)((size_t)512 * p.ldvt * 2));
+  const unsigned int v_voff = (unsigned int)((lane >> 2) * p.ldvt * 2 + (((lane & 3) ^ ((lane >> 4) & 3)) * 16));   // ((16g + (lane>>2)) >> 2) & 3 == (lane >> 4) & 3
+  auto issue_tile = [&](int t, int buf) {
+    const int k0 = t * 32;
+    unsigned char* Kd = smem + buf * ATTN512P_K_BYTES;
+    unsigned char* Vd = smem + 2 * ATTN512P_K_BYTES + buf * ATTN512P_V_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rho = 4 * wave + i;
+      const int pi = (rho & 16) | (((rho >> 2) & 1) << 3) | (((rho >> 3) & 1) << 2) | (rho & 3);
+      int kr = k0 + pi;
+      if (kr > p.Lk - 1) kr = p.Lk - 1;                              // keys >= Lk are masked after QK^T
+      sdm_glds16_buf(rsK, (unsigned int)((lane ^ (rho & 15)) * 16), (unsigned int)kr * (unsigned int)(p.ldk * 2), Kd + rho * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int g = 4 * wave + i;
+      sdm_glds16_buf(rsV, v_voff, (unsigned int)((16 * g * p.ldvt + k0) * 2), Vd + g * 1024);
+    }
+  };
+  // read-side swizzles (the same involutions as on the source side)
+  int kx = (l31 * 1024 + dh * 512) ^ ((hi ^ (l31 & 15)) * 16);      // K: byte offset of chunk (2*ks + hi) ^ (rho & 15) = kx ^ (ks * 32)
+  int vx = (dh * 256 + l31) * 64 + ((hi ^ ((l31 >> 2) & 3)) * 16);   // V^T: chunk (2*u + hi) ^ ((r >> 2) & 3) -> vx ^ (u * 32)
+
+  issue_tile(0, 0);
+  SDM_WAIT_VMCNT0();
+  SDM_RAW_BARRIER();
+  for (int t = 0; t < ntiles; ++t) {
+    const int k0 = t * 32, cur = t & 1;
+    const unsigned char* Ks = smem + cur * ATTN512P_K_BYTES;
+    const unsigned char* Vs = smem + 2 * ATTN512P_K_BYTES + cur * ATTN512P_V_BYTES;
+    if (t + 1 < ntiles) issue_tile(t + 1, cur ^ 1);                  // in flight during everything below
+    SDM_OPAQUE_I(kx);
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const f16x8 a = *(const f16x8*)(Ks + (kx ^ (ks * 32)));
+      s = SDM_MFMA_32x32x16_F16(a, qf[ks], s);
+    }
+    float* xme = Xs + wave * (16 * 64);
+    const float* xpt = Xs + (wave ^ 1) * (16 * 64);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xme[r * 64 + lane] = s[r];
+    SDM_WAIT_LGKMCNT0();
+    SDM_RAW_BARRIER();
+    float mx = SDM_NEG_BIG;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + 16 * (r >> 3) + 8 * hi + (r & 7);          // pi-permuted row -> actual key
+      float x = (s[r] + xpt[r * 64 + lane]) * p.scale_log2e;
+      if (key >= p.Lk) x = SDM_NEG_BIG;
+      s[r] = x;
+      mx = fmaxf(mx, x);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mnew = fmaxf(m_i, mx);
+    const float alpha = sdm_exp2(m_i - mnew);
+    m_i = mnew;
+    float rs = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pv = sdm_exp2(s[r] - mnew);
+      s[r] = pv;
+      rs += pv;
+    }
+    l_i = l_i * alpha + rs;
+    if (__any(alpha != 1.0f)) {
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      f16x8 pf;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pf[j] = (half_t)s[8 * u + j];
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) {
+        const f16x8 vf = *(const f16x8*)(Vs + (vx ^ (u * 32)) + dt * 2048);
+        o[dt] = SDM_MFMA_32x32x16_F16(vf, pf, o[dt]);
+      }
+    }
+    SDM_WAIT_VMCNT0();          // this wave's pieces of tile t+1 have landed ...
+    SDM_RAW_BARRIER();          // ... and so have everyone else's; every wave is done with tile t and the exchange buffer
+  }
+
+  l_i += __shfl_xor(l_i, 32);
+  const float inv = 1.0f / l_i;
   constexpr int PS = 272;
   unsigned char* stg = smem + wave * (32 * PS);
 #pragma unroll

@@ -25,6 +25,9 @@
 #pragma once
 #include "sdm_common.h"
 
+#ifndef SDM_CONV_VREUSE
+#define SDM_CONV_VREUSE 1   /* vertical A-fragment reuse across taps (A/B switch for experiments) */
+#endif
 #ifndef SDM_CONV_PIPE
 #define SDM_CONV_PIPE 1
 #endif
@@ -297,6 +300,47 @@ conv_mfma_kernel(ConvParams p) {
       const int tap = step / (KC / 16), ks = step % (KC / 16);
       return (const f16x8*)(Bs + tap * BN * PITCH + bbase[j] + ks * 32);
     };
+    // Vertical operand reuse (3x3, stride 1, 32-pixel-wide tiles): the A fragment of output row i at tap (dy,dx) is halo row
+    // i+dy shifted by dx - the SAME LDS data for every (i,dy) with equal i+dy.  Sweeping halo rows r = 0..MT+1 per dx reads
+    // 3*(MT+2) A fragments per K16 step instead of 9*MT (18 vs 36 at MT=4); the three B fragments (dy) of the current dx
+    // stay in registers and are re-read in place for dx+1 right after their last use.  LDS read traffic per MFMA drops by 1/3
+    // (the tile is otherwise LDS-bandwidth-bound: 54 ds_read_b128 per 72 MFMAs ~ 0.9 of the CU's LDS cycles).
+    constexpr bool VREUSE = SDM_CONV_VREUSE && (NTAPS == 9) && (STRIDE == 1) && (TW == 32) && (MT >= 2) && !DB;
+    if (VREUSE) {
+      constexpr int NR = MT + 2, NS = 3 * NR;
+#pragma unroll
+      for (int ks = 0; ks < KC / 16; ++ks) {
+        f16x8 fav[2], fbv[3][NTL];
+        auto av = [&](int s) { return *(const f16x8*)(As + abase[0] + ((s % NR) * HPW + (s / NR)) * PITCH + ks * 32); };
+        auto bv = [&](int dy, int dx, int j) { return *(const f16x8*)(Bs + (dy * 3 + dx) * BN * PITCH + bbase[j] + ks * 32); };
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int j = 0; j < NTL; ++j) fbv[dy][j] = bv(dy, 0, j);
+        fav[0] = av(0);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          const int dx = s / NR, r = s % NR;
+          if (s + 1 < NS) fav[(s + 1) & 1] = av(s + 1);
+          SDM_SCHED_FENCE();
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy) {
+            const int i = r - dy;
+            if (i >= 0 && i < MT) {
+#pragma unroll
+              for (int j = 0; j < NTL; ++j) acc[i][j] = SDM_MFMA_32x32x16_F16(fav[s & 1], fbv[dy][j], acc[i][j]);
+            }
+          }
+          SDM_SCHED_FENCE();
+          const int dyl = r - (MT - 1);          // the B fragments of this dy were used for the last time in this dx phase
+          if (dyl >= 0 && dyl < 3 && dx + 1 < 3) {
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) fbv[dyl][j] = bv(dyl, dx + 1, j);
+          }
+          SDM_SCHED_FENCE();
+        }
+      }
+    } else {
 #pragma unroll
     for (int j = 0; j < NTL; ++j) fb[0][j] = *b_addr(0, j);
 #pragma unroll
@@ -316,6 +360,7 @@ conv_mfma_kernel(ConvParams p) {
         if (step + 1 < NSTEP) fa[i] = *a_addr(step + 1, i);
         SDM_SCHED_FENCE();
       }
+    }
     }
 #else
 #pragma unroll

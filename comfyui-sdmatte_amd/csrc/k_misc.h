@@ -145,3 +145,20 @@ __global__ void scale_copy_kernel(const float* __restrict__ in, float* __restric
 __global__ void fill_zero_kernel(uint32_t* __restrict__ p, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = 0u;
 }
+
+// bench helpers only: pseudo-random fill (realistic operand toggling; constant data lets the chip clock ~25 % higher
+// than it does on real activations, which makes micro-benchmarks lie)
+__global__ void fill_random_f16_kernel(half_t* __restrict__ p, long n, unsigned int seed, float amp) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    unsigned int h = (unsigned int)i * 2654435761u + seed;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+    p[i] = (half_t)(((float)(h & 0xFFFF) * (1.0f / 32768.0f) - 1.0f) * amp);
+  }
+}
+__global__ void fill_random_f32_kernel(float* __restrict__ p, long n, unsigned int seed, float amp) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    unsigned int h = (unsigned int)i * 2654435761u + seed;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+    p[i] = ((float)(h & 0xFFFF) * (1.0f / 32768.0f) - 1.0f) * amp;
+  }
+}

@@ -79,6 +79,40 @@ __device__ __forceinline__ u32x2 sdm_buffer_load8(sdm_rsrc r, unsigned int voff,
 }
 #endif
 
+// ---- LDS-DMA (global -> LDS without staging registers): every lane supplies its own 16-B source address, the
+//      destination is the wave-uniform `lds_base` + lane*16.  Completion is counted on vmcnt: SDM_WAIT_VMCNT0() then a
+//      barrier orders the data for every reader.  SDM_RAW_BARRIER() is s_barrier without the vmcnt(0) drain that
+//      __syncthreads() implies, so a DMA issued earlier may stay in flight across it.
+#ifdef SDM_EMU
+static inline void sdm_glds16(const void* gsrc, unsigned char* lds_base) { memcpy(lds_base + (threadIdx.x & 63) * 16, gsrc, 16); }
+static inline void sdm_glds16_buf(sdm_rsrc r, unsigned int voff, unsigned int soff, unsigned char* lds_base) {
+  const u32x4 v = sdm_buffer_load16(r, voff, soff);
+  memcpy(lds_base + (threadIdx.x & 63) * 16, &v, 16);
+}
+#define SDM_UNIFORM_I(x) (x)
+#define SDM_OPAQUE_I(x) ((void)0)
+#define SDM_WAIT_VMCNT0() ((void)0)
+#define SDM_WAIT_LGKMCNT0() ((void)0)
+#define SDM_RAW_BARRIER() __syncthreads()
+#else
+__device__ __forceinline__ void sdm_glds16(const void* gsrc, unsigned char* lds_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
+// buffer form: SGPR descriptor + 32-bit per-lane byte offset + uniform byte offset (no 64-bit address VGPRs; OOB -> 0)
+__device__ __forceinline__ void sdm_glds16_buf(sdm_rsrc r, unsigned int voff, unsigned int soff, unsigned char* lds_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_base, 16, (int)voff, (int)soff, 0, 0);
+}
+// value known to be wave-uniform (e.g. threadIdx.x >> 6): lets the compiler keep everything derived from it in SGPRs
+#define SDM_UNIFORM_I(x) __builtin_amdgcn_readfirstlane(x)
+// make a loop-invariant VGPR value opaque at this point, so that the compiler recomputes cheap address arithmetic derived
+// from it inside the loop instead of hoisting N precomputed addresses into N long-lived registers
+#define SDM_OPAQUE_I(x) asm volatile("" : "+v"(x))
+#define SDM_WAIT_VMCNT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define SDM_WAIT_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define SDM_RAW_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+#endif
+
 #define SDM_LOG2E 1.4426950408889634f
 
 SDM_DEV_INLINE float sdm_silu(float x) {

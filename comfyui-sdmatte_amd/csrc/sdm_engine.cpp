@@ -772,10 +772,17 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
       else { SDM_LAUNCH(attn_d64_kernel<1>, dim3(nblk, 1, 1), dim3(256), ATTN64_SMEM, e->stream, p); }
       prof_end(e);
     } else {
-      SDM_SET_SMEM(attn_d512_kernel, ATTN512_SMEM);
+      static const bool sync512 = getenv("SDM_ATTN512_SYNC") != nullptr;    // A/B hook: the synchronous-staging kernel
       prof_begin(e, "attn_d512", flops, bytes);
       p.batch = B; p.heads = 1; p.nq_blocks = sdm_cdiv(Lq, 128); p.q_chunks = 8;
-      SDM_LAUNCH(attn_d512_kernel, dim3((unsigned)(B * p.q_chunks * sdm_cdiv(p.nq_blocks, p.q_chunks))), dim3(512), ATTN512_SMEM, e->stream, p);
+      const unsigned nblk = (unsigned)(B * p.q_chunks * sdm_cdiv(p.nq_blocks, p.q_chunks));
+      if (sync512) {
+        SDM_SET_SMEM(attn_d512_sync_kernel, ATTN512_SMEM);
+        SDM_LAUNCH(attn_d512_sync_kernel, dim3(nblk), dim3(512), ATTN512_SMEM, e->stream, p);
+      } else {
+        SDM_SET_SMEM(attn_d512_kernel, ATTN512P_SMEM);
+        SDM_LAUNCH(attn_d512_kernel, dim3(nblk), dim3(512), ATTN512P_SMEM, e->stream, p);
+      }
       prof_end(e);
     }
   }
@@ -1612,7 +1619,10 @@ float sdm_bench_conv(sdm_ctx* e, int N, int H, int W, int Cin, int Cout, int nta
   const size_t wbytes = (size_t)L.Cin_pad * ntaps * L.Cout_pad * 2, inb = (size_t)N * H * W * L.Cin_pad * (in_f32 ? 4 : 2),
                outb = (size_t)N * Ho * Wo * L.Cout_pad * 2;
   if (dev_malloc(&wp, wbytes) || dev_malloc(&bp, (size_t)L.Cout_pad * 4) || dev_malloc(&in, inb) || dev_malloc(&out, outb)) return -2.f;
-  dev_memset(wp, 0x11, wbytes, e->stream); dev_memset(bp, 0, (size_t)L.Cout_pad * 4, e->stream); dev_memset(in, 0x11, inb, e->stream);
+  dev_memset(bp, 0, (size_t)L.Cout_pad * 4, e->stream);
+  SDM_LAUNCH(fill_random_f16_kernel, dim3(2048), dim3(256), 0, e->stream, (half_t*)wp, (long)(wbytes / 2), 17u, 0.05f);
+  if (in_f32) SDM_LAUNCH(fill_random_f32_kernel, dim3(4096), dim3(256), 0, e->stream, (float*)in, (long)(inb / 4), 5u, 1.0f);
+  else SDM_LAUNCH(fill_random_f16_kernel, dim3(4096), dim3(256), 0, e->stream, (half_t*)in, (long)(inb / 2), 5u, 1.0f);
   L.w = (half_t*)wp; L.b = (float*)bp;
   T tin, tout;
   tin.p = in; tin.N = N; tin.H = H; tin.W = W; tin.C = L.Cin_pad; tin.f32 = in_f32;
