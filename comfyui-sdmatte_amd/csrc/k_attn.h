@@ -74,17 +74,30 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
     const half_t* qp = p.q + (size_t)b * p.q_bs + (size_t)qrow * p.ldq + head * 64 + hi * 8;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[qt][ks] = *(const f16x8*)(qp + ks * 16);
+    // The logit scale d^-1/2 * log2(e) lives in Q.  The engine folds it into the to_q weights at load time (exact: one fp16
+    // rounding of the GEMM result either way) and passes scale_log2e == 1; the stand-alone operator entry scales Q here.
+    if (p.scale_log2e != 1.0f) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[qt][ks][j] = (half_t)((float)qf[qt][ks][j] * p.scale_log2e);
+    }
   }
-  f32x16 o[QT][2];
-  float m_i[QT], l_i[QT];
+  f32x16 o[QT][2], ls[QT];        // ls: running softmax denominators, accumulated on the matrix pipe (ones . P^T)
+  float m_i[QT];
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
-    m_i[qt] = SDM_NEG_BIG; l_i[qt] = 0.0f;
+    m_i[qt] = SDM_NEG_BIG;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ls[qt][r] = 0.0f;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[qt][dt][r] = 0.0f;
   }
+  f16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (half_t)1.0f;
 
   const half_t* kbase = p.k + (size_t)b * p.k_bs + head * 64;
   const half_t* vbase = p.vt + (size_t)b * p.vt_bs + (size_t)head * p.vt_hs;
@@ -93,6 +106,9 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
 
   f16x8 kreg[2], vreg[2];
   float breg = 0.0f;
+  bool binr = true;
+  // without a bias the load still happens (from the K tensor: >= Lk readable floats) and its value is discarded by a select
+  const float* bsrc = bbase ? bbase : (const float*)(p.k + (size_t)b * p.k_bs);
   // all prefetch loads are UNCONDITIONAL (clamped rows): a conditional load makes hipcc wait vmcnt(0) per element.
   // Keys >= Lk are neutralised by the -1e30 bias (K rows) and by the zero padding of V^T.
   auto prefetch = [&](int t) {
@@ -106,11 +122,13 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
       kreg[i] = *(const f16x8*)(kbase + (size_t)kr * p.ldk + part * 8);
       vreg[i] = *(const f16x8*)(vbase + (size_t)row * p.ldvt + k0 + part * 8);
     }
+    // bias: UNCONDITIONAL raw load, consumed only in stage() after the MFMAs.  (`bbase ? bbase[kb] : 0` followed by a select
+    // made hipcc branch around the load and wait vmcnt(0) right here - which also drains the four K / V^T prefetch loads
+    // issued just above, i.e. every tile paid the full global-load latency.)
     int kb = k0 + (tid & 63);
-    const bool inr = kb < p.Lk;
-    if (!inr) kb = p.Lk - 1;
-    const float bv = bbase ? bbase[kb] : 0.0f;
-    breg = inr ? bv : SDM_NEG_BIG;
+    binr = kb < p.Lk;
+    if (!binr) kb = p.Lk - 1;
+    breg = bsrc[kb];
   };
   auto stage = [&](int buf) {
     unsigned char* base = smem + buf * ATTN64_BUF;
@@ -126,7 +144,7 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
       *(f16x4*)(base + 64 * PK + row * PV + part * 16) = lo;
       *(f16x4*)(base + 64 * PK + row * PV + part * 16 + 8) = hi4;
     }
-    if (tid < 64) ((float*)(base + 64 * PK + 64 * PV))[tid] = breg;
+    if (tid < 64) ((float*)(base + 64 * PK + 64 * PV))[tid] = binr ? (bbase ? breg : 0.0f) : SDM_NEG_BIG;
   };
   prefetch(0);
   stage(0);
@@ -138,14 +156,20 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
     const float* Bs = (const float*)(Ks + 64 * PK + 64 * PV);
     if (t + 1 < ntiles && !(p.ablate & 8)) prefetch(t + 1);
 
-    // S^T[key][q] for 2 key tiles of 32 (x QT query tiles)
+    // S^T[key][q] for 2 key tiles of 32 (x QT query tiles).  The accumulators START from the per-key additive bias (read
+    // straight from LDS in accumulator layout: rows 8g+4hi..+3 = registers 4g..4g+3), so the MFMA chain delivers the final
+    // logit x = q'.k + bias and no VALU pass is needed for scale/bias (this kernel is bound by the VALU pipe: exp, max, sub).
     f32x16 s[QT][2];
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt)
+    for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 b4 = *(const f32x4*)(Bs + kt * 32 + 8 * g + 4 * hi);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[qt][kt][r] = 0.0f;
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s[qt][kt][4 * g + e] = b4[e];
+      }
     if (!(p.ablate & 4)) {
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
@@ -156,11 +180,6 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
         for (int qt = 0; qt < QT; ++qt) s[qt][kt] = SDM_MFMA_32x32x16_F16(a, qf[qt][ks], s[qt][kt]);
       }
     }
-    f32x4 bb[2][4];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) bb[kt][g] = *(const f32x4*)(Bs + kt * 32 + 8 * g + 4 * hi);
     if (!(p.ablate & 1)) {
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
@@ -168,29 +187,19 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float x = s[qt][kt][4 * g + e] * p.scale_log2e + bb[kt][g][e];
-            s[qt][kt][4 * g + e] = x;
-            mx = fmaxf(mx, x);
-          }
+        for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s[qt][kt][r]), s[qt][kt][r + 1]);      // v_max3_f32
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       const float mnew = fmaxf(m_i[qt], mx);
       const float alpha = sdm_exp2(m_i[qt] - mnew);
       m_i[qt] = mnew;
-      float rs = 0.0f;
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float pv = sdm_exp2(s[qt][kt][r] - mnew);
-          s[qt][kt][r] = pv;
-          rs += pv;
-        }
-      l_i[qt] = l_i[qt] * alpha + rs;
-      // the running max stops moving after the first tiles: skip the O rescale when no lane of the wave needs it
+        for (int r = 0; r < 16; ++r) s[qt][kt][r] = sdm_exp2(s[qt][kt][r] - mnew);
+      // the running max stops moving after the first tiles: skip the O / denominator rescale when no lane of the wave needs it
       if (__any(alpha != 1.0f)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ls[qt][r] *= alpha;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -210,6 +219,8 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
         for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
           for (int j = 0; j < 8; ++j) pf[qt][j] = (half_t)s[qt][kt][8 * u + j];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) ls[qt] = SDM_MFMA_32x32x16_F16(ones, pf[qt], ls[qt]);      // every row = sum_k P[k][q]
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           const unsigned char* vp = Vs + (dt * 32 + l31) * PV + (kt * 32 + 16 * u + 4 * hi) * 2;
@@ -231,8 +242,7 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
   unsigned char* stg = smem + wave * (32 * PK);
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
-    float l = l_i[qt];
-    l += __shfl_xor(l, 32);
+    const float l = ls[qt][0];      // all 32 rows of the ones.P^T tile hold the same sum over every key (both lane halves included)
     const float inv = 1.0f / l;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)

@@ -57,7 +57,8 @@ struct ConvParams {
   int gn_silu;
   int ablate;                           // debug/bench only (sdm_bench_conv): 1 skip global loads, 2 skip LDS writes, 4 skip MFMA,
                                         // 8 skip the epilogue stores -- after the first K-chunk; always 0 in the engine
-  float* stats;                         // optional [N][gridDim.x*WM][Cout_store][2]: per-(image, wave row-tile, channel) partial
+  int tiles_m, tiles_n, xcd_chunk;      // 1-D XCD-aware grid (set by launch_conv_t): M tiles per image (9 taps) or in total (1 tap), N tiles, M tiles per XCD
+  float* stats;                         // optional [N][tiles_m*WM][Cout_store][2]: per-(image, wave row-tile, channel) partial
                                         // sum / sum of squares of the stored values = fused GroupNorm statistics of the NEXT
                                         // layer (reduced by gn_reduce_partials_kernel); NTAPS==9 or one image per launch
 };
@@ -98,16 +99,30 @@ conv_mfma_kernel(ConvParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int n0 = blockIdx.y * BN;
-  int img = 0, oy0 = 0, ox0 = 0;
+  // XCD-aware 1-D grid.  The dispatcher places block id on XCD id % 8 (speed only, never needed for correctness).  XCD x owns
+  // the contiguous M-tile range [x*chunk, (x+1)*chunk) and walks it in order, running the tiles_n output-channel tiles of
+  // one M tile back to back: the A operand (halo tile / GEMM rows) is fetched from HBM once and re-read from that XCD's L2
+  // by the other N tiles and by the spatial neighbours that share its halo (a (x, y, z) grid re-reads it tiles_n times from
+  // HBM / Infinity Cache, on a different XCD each time).
+  int mt, n0, img = 0, oy0 = 0, ox0 = 0;
   long m0 = 0;
-  if (NTAPS == 9) {
-    const int npx = (p.Wout + TW - 1) / TW;
-    img = blockIdx.z;
-    oy0 = (blockIdx.x / npx) * TH;
-    ox0 = (blockIdx.x % npx) * TW;
-  } else {
-    m0 = (long)blockIdx.x * C::BM;
+  {
+    const int bid = blockIdx.x;
+    const int j = bid >> 3;
+    const int ml = j / p.tiles_n;
+    const int mlin = (bid & 7) * p.xcd_chunk + ml;
+    if (mlin >= p.tiles_m * ((NTAPS == 9) ? p.N : 1)) return;      // padding block of the last XCD range
+    mt = mlin;
+    if (NTAPS == 9) { img = mlin / p.tiles_m; mt = mlin - img * p.tiles_m; }
+    const int nt = j - ml * p.tiles_n;
+    if (NTAPS == 9) {
+      const int npx = (p.Wout + TW - 1) / TW;
+      oy0 = (mt / npx) * TH;
+      ox0 = (mt % npx) * TW;
+    } else {
+      m0 = (long)mt * C::BM;
+    }
+    n0 = nt * BN;
   }
   const int Cin = p.C0 + p.C1;
   const int Hl = p.Hin << p.up, Wl = p.Win << p.up;
@@ -535,7 +550,7 @@ conv_mfma_kernel(ConvParams p) {
       for (int m = LPR; m < 64; m <<= 1) { ssum[e] += __shfl_xor(ssum[e], m); ssq[e] += __shfl_xor(ssq[e], m); }
     }
     if (lane < LPR && colok && oc < p.Cout_valid) {
-      const size_t prow = (size_t)img * (gridDim.x * WM) + (size_t)blockIdx.x * WM + wm;
+      const size_t prow = (size_t)img * (p.tiles_m * WM) + (size_t)mt * WM + wm;
       float* st = p.stats + (prow * p.Cout_store + p.out_ch_off + oc) * 2;
       f32x4 o0, o1;
       o0[0] = ssum[0]; o0[1] = ssq[0]; o0[2] = ssum[1]; o0[3] = ssq[1];
@@ -563,7 +578,7 @@ SDM_DEV_INLINE int pack_src_row(int co, int O, int co_off, int geglu) {
 }
 
 __global__ void pack_conv_weight_kernel(const float* __restrict__ w, half_t* __restrict__ wp, int O, int I, int ntaps, int Cin_pad,
-                                        int Cout_pad, int ci_off, int co_off, int geglu) {
+                                        int Cout_pad, int ci_off, int co_off, int geglu, float scale) {
   const size_t total = (size_t)Cin_pad * ntaps * Cout_pad;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int k = idx % 16;
@@ -576,7 +591,7 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, half_t* __r
     if (o < 0) continue;
     float v = 0.0f;
     if (ci >= 0 && ci < I) v = w[((size_t)o * I + ci) * ntaps + tap];
-    wp[idx] = (half_t)v;
+    wp[idx] = (half_t)(v * scale);
   }
 }
 

@@ -68,11 +68,14 @@ static inline size_t rupz(size_t a, size_t b) { return ((a + b - 1) / b) * b; }
 // conv tile configurations
 // ------------------------------------------------------------------------------------------------
 template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN, int DB = 0, int GNOK = 0>
-static void launch_conv_t(const ConvParams& p, void* stream) {
+static void launch_conv_t(const ConvParams& p_in, void* stream) {
   using C = ConvCfg<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN, DB>;
-  dim3 grid;
-  if (NTAPS == 9) grid = dim3(sdm_cdiv(p.Wout, TW) * sdm_cdiv(p.Hout, TH), sdm_cdiv(p.Cout_pad, BN), p.N);
-  else grid = dim3((unsigned)((p.M + C::BM - 1) / C::BM), sdm_cdiv(p.Cout_pad, BN), 1);
+  ConvParams p = p_in;
+  p.tiles_m = (NTAPS == 9) ? sdm_cdiv(p.Wout, TW) * sdm_cdiv(p.Hout, TH) : (int)((p.M + C::BM - 1) / C::BM);
+  p.tiles_n = sdm_cdiv(p.Cout_pad, BN);
+  const long total_m = (long)p.tiles_m * ((NTAPS == 9) ? p.N : 1);
+  p.xcd_chunk = (int)((total_m + 7) / 8);
+  const dim3 grid((unsigned)(8L * p.xcd_chunk * p.tiles_n), 1, 1);      // 1-D, XCD-aware mapping in the kernel
   if (GNOK && p.gn_scale) {      // fused GroupNorm apply: the scale|shift table of the image follows the tiles in LDS
     const size_t smem = (size_t)C::SMEM + (size_t)(p.C0 + p.C1) * 8;
     if (p.in_f32) {
@@ -183,6 +186,7 @@ struct NormL {
 enum SlotKind { SLOT_CONV_W, SLOT_CONV_B, SLOT_NORM_G, SLOT_NORM_B, SLOT_HOST };
 struct Slot {
   int kind = 0, layer = -1, co_off = 0, ci_off = 0;
+  float w_scale = 1.0f;    // SLOT_CONV_W: constant folded into the weight before the fp16 rounding (attention logit scale in to_q)
   std::vector<int64_t> shape;
   size_t host_off = 0;     // SLOT_HOST: float offset in the host blob
   bool loaded = false;
@@ -386,6 +390,9 @@ struct Builder {
     slot(b + ".attn1.to_v.weight", SLOT_CONV_W, t.qkv1, {C, C}, 2 * C);
     t.o1 = conv_named(b + ".attn1.to_out.0", 1, C, C);
     t.q2 = conv_named(b + ".attn2.to_q", 1, C, C, false);
+    // softmax(q.k^T * d^-1/2) is evaluated as 2^(q'.k^T - max) with q' = q * d^-1/2 * log2(e): the constant goes into the
+    // to_q weights (no bias in these projections), so the attention kernel needs no per-logit multiply
+    e->slots[b + ".attn1.to_q.weight"].w_scale = e->slots[b + ".attn2.to_q.weight"].w_scale = 0.125f * SDM_LOG2E;
     // cross-attention K|V: K = W_k (W_aux * z + b_aux) is an affine map of the 3x3 patch of the 4-channel trimap latent z
     // (exact fold): ONE 3x3 conv 16(4 real)->2C with host-folded weights instead of aux_conv_in
     // (4->1024) followed by two 1024->C GEMMs.  to_k / to_v / aux_conv_in are kept on the host and folded in finalize.
@@ -737,7 +744,7 @@ static int op_ln(sdm_ctx* e, const NormL& n, const T& x, float eps, T* out) {
 
 // q/k/v are views into fp16 row-major buffers; v is transposed into an arena scratch first
 static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* k, int ldk, const half_t* v, int ldv, const float* bias_l2,
-                            int B, int heads, int Lq, int Lk, int D, half_t* out, int ldo) {
+                            int B, int heads, int Lq, int Lk, int D, half_t* out, int ldo, bool q_prescaled = false) {
   if (!(D == 64 || (D == 512 && heads == 1))) SDM_FAIL(e, SDM_ERR_INVALID, "attention: unsupported head dim %d x %d heads", D, heads);
   if ((ldq | ldk | ldv | ldo) % 8) SDM_FAIL(e, SDM_ERR_INVALID, "attention: row strides must be multiples of 8");
   const int ldvt = rup(Lk, 64);
@@ -756,7 +763,7 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
     p.bias = bias_l2; p.bias_bs = Lk;
     p.o = out; p.o_bs = (long)Lq * ldo; p.ldo = ldo;
     p.Lq = Lq; p.Lk = Lk;
-    p.scale_log2e = (1.0f / sqrtf((float)D)) * SDM_LOG2E;
+    p.scale_log2e = q_prescaled ? 1.0f : (1.0f / sqrtf((float)D)) * SDM_LOG2E;      // engine: folded into the to_q weights (d = 64 only)
     const double flops = 4.0 * B * heads * (double)Lq * Lk * D;
     const double bytes = 2.0 * B * heads * D * (2.0 * Lq + 2.0 * Lk);
     if (D == 64) {
@@ -914,7 +921,7 @@ static int transformer(sdm_ctx* e, const TfB& t, const T& x, const T& uin, const
   ao = talloc(e, x.N, x.H, x.W, C, 0);
   {
     const half_t* q = (const half_t*)qkv.p;
-    TRY(op_attention_raw(e, q, 3 * C, q ? q + C : nullptr, 3 * C, q ? q + 2 * C : nullptr, 3 * C, bias, x.N, t.heads, L, L, 64, (half_t*)ao.p, C));
+    TRY(op_attention_raw(e, q, 3 * C, q ? q + C : nullptr, 3 * C, q ? q + 2 * C : nullptr, 3 * C, bias, x.N, t.heads, L, L, 64, (half_t*)ao.p, C, true));
   }
   tfree(e, qkv);
   TRY(linear(e, t.o1, ao, &h2, C, sf, &h));
@@ -927,7 +934,7 @@ static int transformer(sdm_ctx* e, const TfB& t, const T& x, const T& uin, const
   ao = talloc(e, x.N, x.H, x.W, C, 0);
   {
     const half_t* kk = (const half_t*)kv.p;
-    TRY(op_attention_raw(e, (const half_t*)q2.p, C, kk, 2 * C, kk ? kk + C : nullptr, 2 * C, nullptr, x.N, t.heads, L, L0, 64, (half_t*)ao.p, C));
+    TRY(op_attention_raw(e, (const half_t*)q2.p, C, kk, 2 * C, kk ? kk + C : nullptr, 2 * C, nullptr, x.N, t.heads, L, L0, 64, (half_t*)ao.p, C, true));
   }
   tfree(e, q2); tfree(e, kv);
   TRY(linear(e, t.o2, ao, &h, C, sf, &h2));
@@ -1398,7 +1405,7 @@ int sdm_load_tensor(sdm_ctx* e, const char* name, int dtype, int ndim, const int
       const int O = (int)s.shape[0], I = (int)s.shape[1];
       const size_t total = (size_t)L.Cin_pad * L.ntaps * L.Cout_pad;
       SDM_LAUNCH(pack_conv_weight_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 65535)), dim3(256), 0, e->stream,
-                 (const float*)e->stage, L.w, O, I, L.ntaps, L.Cin_pad, L.Cout_pad, s.ci_off, s.co_off, L.geglu);
+                 (const float*)e->stage, L.w, O, I, L.ntaps, L.Cin_pad, L.Cout_pad, s.ci_off, s.co_off, L.geglu, s.w_scale);
     } else if (s.kind == SLOT_CONV_B) {
       ConvL& L = e->convs[s.layer];
       SDM_LAUNCH(pack_bias_kernel, dim3(sdm_cdiv(L.Cout_pad, 256)), dim3(256), 0, e->stream, (const float*)e->stage, L.b, (int)s.shape[0],
@@ -1451,7 +1458,7 @@ static int fold_cross_kv(sdm_ctx* e) {
     SDM_CHECK_DEV(e, dev_memcpy_h2d(e->stage, wf.data(), wf.size() * 4, e->stream));
     const size_t total = (size_t)L.Cin_pad * 9 * L.Cout_pad;
     SDM_LAUNCH(pack_conv_weight_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 65535)), dim3(256), 0, e->stream, (const float*)e->stage,
-               L.w, 2 * C, 4, 9, L.Cin_pad, L.Cout_pad, 4, 0, 0);
+               L.w, 2 * C, 4, 9, L.Cin_pad, L.Cout_pad, 4, 0, 0, 1.0f);
     SDM_CHECK_DEV(e, dev_sync(e->stream));
     SDM_CHECK_DEV(e, dev_memcpy_h2d(e->stage, bf.data(), bf.size() * 4, e->stream));
     SDM_LAUNCH(pack_bias_kernel, dim3(sdm_cdiv(L.Cout_pad, 256)), dim3(256), 0, e->stream, (const float*)e->stage, L.b, 2 * C, L.Cout_pad, 0, 0);
@@ -1586,7 +1593,7 @@ int sdm_op_conv(sdm_ctx* e, const void* in0, const void* in1, int C0, int C1, in
   L.w = (half_t*)wp; L.b = (float*)bp;
   const size_t total = (size_t)L.Cin_pad * ntaps * L.Cout_pad;
   SDM_LAUNCH(pack_conv_weight_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 65535)), dim3(256), 0, e->stream, w, L.w, O, L.I, ntaps,
-             L.Cin_pad, L.Cout_pad, 0, 0, geglu);
+             L.Cin_pad, L.Cout_pad, 0, 0, geglu, 1.0f);
   if (bias) SDM_LAUNCH(pack_bias_kernel, dim3(sdm_cdiv(L.Cout_pad, 256)), dim3(256), 0, e->stream, bias, L.b, O, L.Cout_pad, 0, geglu);
   int Ho = Hin << up, Wo = Win << up;
   if (stride == 2) { Ho /= 2; Wo /= 2; }
@@ -1658,8 +1665,9 @@ float sdm_bench_attn(sdm_ctx* e, int B, int heads, int Lq, int Lk, int qt, int a
   void *q = nullptr, *k = nullptr, *vt = nullptr, *o = nullptr;
   if (dev_malloc(&q, (size_t)B * Lq * C * 2) || dev_malloc(&k, (size_t)B * Lk * C * 2) || dev_malloc(&vt, (size_t)B * heads * 64 * ldvt * 2) ||
       dev_malloc(&o, (size_t)B * Lq * C * 2)) return -2.f;
-  dev_memset(q, 0x2c, (size_t)B * Lq * C * 2, e->stream); dev_memset(k, 0x2d, (size_t)B * Lk * C * 2, e->stream);
-  dev_memset(vt, 0x2e, (size_t)B * heads * 64 * ldvt * 2, e->stream);
+  SDM_LAUNCH(fill_random_f16_kernel, dim3(4096), dim3(256), 0, e->stream, (half_t*)q, (long)B * Lq * C, 3u, 1.0f);
+  SDM_LAUNCH(fill_random_f16_kernel, dim3(4096), dim3(256), 0, e->stream, (half_t*)k, (long)B * Lk * C, 7u, 1.0f);
+  SDM_LAUNCH(fill_random_f16_kernel, dim3(4096), dim3(256), 0, e->stream, (half_t*)vt, (long)B * heads * 64 * ldvt, 11u, 1.0f);
   AttnParams p;
   memset(&p, 0, sizeof(p));
   p.q = (const half_t*)q; p.q_bs = (long)Lq * C; p.ldq = C; p.k = (const half_t*)k; p.k_bs = (long)Lk * C; p.ldk = C;

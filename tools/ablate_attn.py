@@ -7,9 +7,9 @@ from comfyui_sdmatte_amd.engine import Engine
 from comfyui_sdmatte_amd.config import SDMatteConfig
 eng = Engine(SDMatteConfig.tiny(), 0)
 names = {0: "full", 1: "no softmax", 2: "no PV", 4: "no QK", 8: "no prefetch", 3: "QK only", 6: "softmax only", 7: "staging+barrier only", 15: "LDS staging+barrier only"}
-for (B, h, Lq, Lk) in [(2, 5, 16384, 16384), (2, 10, 4096, 16384)]:
+for (B, h, Lq, Lk) in [(4, 5, 16384, 16384), (4, 10, 4096, 16384)]:
     fl = 4.0 * B * h * Lq * Lk * 64
-    for qt in (1, 2):
+    for qt in (1,):
         print(f"B={B} h={h} Lq={Lq} Lk={Lk} QT={qt}")
         for ab in (0, 1, 2, 4, 8, 3, 6, 7, 15):
             ms = eng.bench_attn(B, h, Lq, Lk, qt=qt, ablate=ab, iters=5)
