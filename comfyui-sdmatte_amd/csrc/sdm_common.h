@@ -16,6 +16,7 @@ typedef _Float16 half_t;
 typedef half_t f16x8 __attribute__((ext_vector_type(8)));
 typedef half_t f16x4 __attribute__((ext_vector_type(4)));
 typedef half_t f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -28,6 +29,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define SDM_DEV_INLINE static inline
 #define SDM_WAVE_SYNC() emu::wave_barrier()
 #define SDM_SCHED_FENCE() ((void)0)
+#define SDM_SCHED_GROUP(mask, n, id) ((void)0)
 static inline float sdm_exp2(float x) { return exp2f(x); }
 static inline float sdm_rcp(float x) { return 1.0f / x; }
 #else
@@ -42,6 +44,8 @@ static inline float sdm_rcp(float x) { return 1.0f / x; }
 #define SDM_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 // pin the instruction schedule at this point (used to keep hand-pipelined LDS fragment reads ahead of the MFMAs)
 #define SDM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// compile-time interleave request: the next `n` instructions of class `mask` (0x8 MFMA, 0x2 VALU, 0x400 TRANS, 0x100 DS read)
+#define SDM_SCHED_GROUP(mask, n, id) __builtin_amdgcn_sched_group_barrier((mask), (n), (id))
 __device__ __forceinline__ float sdm_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float sdm_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 #endif
@@ -91,6 +95,7 @@ static inline void sdm_glds16_buf(sdm_rsrc r, unsigned int voff, unsigned int so
 }
 #define SDM_UNIFORM_I(x) (x)
 #define SDM_OPAQUE_I(x) ((void)0)
+#define SDM_PIN_HERE_V4(a, b, c, d) ((void)0)
 #define SDM_WAIT_VMCNT0() ((void)0)
 #define SDM_WAIT_LGKMCNT0() ((void)0)
 #define SDM_RAW_BARRIER() __syncthreads()
@@ -108,6 +113,9 @@ __device__ __forceinline__ void sdm_glds16_buf(sdm_rsrc r, unsigned int voff, un
 // make a loop-invariant VGPR value opaque at this point, so that the compiler recomputes cheap address arithmetic derived
 // from it inside the loop instead of hoisting N precomputed addresses into N long-lived registers
 #define SDM_OPAQUE_I(x) asm volatile("" : "+v"(x))
+// force four 128-bit register values to be fully computed at this point (stops the optimiser from sinking their producers
+// below a later branch, out of the block whose instruction interleave is being pinned)
+#define SDM_PIN_HERE_V4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
 #define SDM_WAIT_VMCNT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define SDM_WAIT_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define SDM_RAW_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
