@@ -24,11 +24,20 @@ struct AttnParams {
   half_t* o; long o_bs; int ldo;                           // o [b][row][head*D + d]
   int Lq, Lk;
   float scale_log2e;
+  // Active key tiles (d = 64 only; null = all tiles).  tiles[b*tiles_bs] = n, tiles[b*tiles_bs + 1 + i] = index of the i-th 64-key tile of
+  // image b that contains at least one key whose bias is within SDM_ATTN_SKIP_MARGIN of the image's largest bias.  Every other key has
+  // bias <= max - margin, so its probability 2^(x - rowmax) underflows to EXACTLY 0 in fp32 - in the reference too (trimap keys carry
+  // (1-m)*-10000: replace.py:401-403) - and its tile is not loaded at all.
+  const int* tiles; int tiles_bs;
   int batch, heads, nq_blocks, q_chunks;   // XCD-aware 1-D grid (attn_d64): see attn_block_coords
   int ablate;   // bench only (sdm_bench_attn): 1 skip softmax VALU, 2 skip PV MFMAs, 4 skip QK^T MFMAs, 8 skip K/V global prefetch; 0 in the engine
 };
 
 #define SDM_NEG_BIG (-1.0e30f)
+// log2-domain margin below the largest key bias at which a key is dropped: 2^(x_k - rowmax) == 0 in fp32 needs x_k - rowmax < -149,
+// i.e. the margin minus the spread of the raw logits q.k*scale*log2e (which would have to exceed 1850 to matter; the reference's own
+// fp16 path overflows long before).  The trimap biases are 0 / -7213 / -14427 in this domain.
+#define SDM_ATTN_SKIP_MARGIN 2000.0f
 
 // ------------------------------------------------------------------------------------------------
 // d = 64, any number of heads (grid.y).  4 waves per block, QT x 32 queries per wave (QT = 2 halves the K / V^T fragment
@@ -146,15 +155,19 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
     }
     if (tid < 64) ((float*)(base + 64 * PK + 64 * PV))[tid] = binr ? (bbase ? breg : 0.0f) : SDM_NEG_BIG;
   };
-  prefetch(0);
+  // tile walk: all ntiles tiles, or the active-tile list of this image (wave-uniform scalar loads)
+  const int* tl = p.tiles ? p.tiles + (size_t)b * p.tiles_bs : nullptr;
+  const int nwalk = tl ? tl[0] : ntiles;
+  auto tile_at = [&](int i) { return tl ? tl[1 + i] : i; };
+  prefetch(tile_at(0));
   stage(0);
   __syncthreads();
 
-  for (int t = 0; t < ntiles; ++t) {
+  for (int t = 0; t < nwalk; ++t) {
     const unsigned char* Ks = smem + (t & 1) * ATTN64_BUF;
     const unsigned char* Vs = Ks + 64 * PK;
     const float* Bs = (const float*)(Ks + 64 * PK + 64 * PV);
-    if (t + 1 < ntiles && !(p.ablate & 8)) prefetch(t + 1);
+    if (t + 1 < nwalk && !(p.ablate & 8)) prefetch(tile_at(t + 1));
 
     // S^T[key][q] for 2 key tiles of 32 (x QT query tiles).  The accumulators START from the per-key additive bias (read
     // straight from LDS in accumulator layout: rows 8g+4hi..+3 = registers 4g..4g+3), so the MFMA chain delivers the final
@@ -234,7 +247,7 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
         }
       }
     }
-    if (t + 1 < ntiles) stage((t + 1) & 1);     // the other buffer: nobody reads it during this iteration
+    if (t + 1 < nwalk) stage((t + 1) & 1);      // the other buffer: nobody reads it during this iteration
     __syncthreads();
   }
 
@@ -584,6 +597,41 @@ __global__ void __launch_bounds__(512) attn_d512_kernel(AttnParams p) {
             *(const f16x8*)(stg + row * PS + part * 16);
     }
   }
+}
+
+// Active key tiles of every image (see AttnParams::tiles): one block per image.  bias is the log2-domain key bias [B][Lk].
+__global__ void __launch_bounds__(256) attn_active_tiles_kernel(const float* __restrict__ bias, int Lk, int ntiles, int* __restrict__ out,
+                                                                int out_bs, float margin) {
+  SDM_SHARED float red[256];
+  SDM_SHARED unsigned char flag[4096];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* bb = bias + (size_t)b * Lk;
+  float mx = SDM_NEG_BIG;
+  for (int k = tid; k < Lk; k += 256) mx = fmaxf(mx, bb[k]);
+  red[tid] = mx;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (tid < st) red[tid] = fmaxf(red[tid], red[tid + st]);
+    __syncthreads();
+  }
+  const float lim = red[0] - margin;
+  int* o = out + (size_t)b * out_bs;
+  int n = 0;                                   // meaningful in thread 0 only
+  for (int t0 = 0; t0 < ntiles; t0 += 4096) {  // chunks of 4096 tiles (one pass for every size the engine uses)
+    const int nt = (ntiles - t0) < 4096 ? (ntiles - t0) : 4096;
+    for (int t = tid; t < nt; t += 256) {
+      float tm = SDM_NEG_BIG;
+      const int k0 = (t0 + t) * 64, k1 = (k0 + 64 < Lk) ? k0 + 64 : Lk;
+      for (int k = k0; k < k1; ++k) tm = fmaxf(tm, bb[k]);
+      flag[t] = tm >= lim ? 1 : 0;
+    }
+    __syncthreads();
+    if (tid == 0)
+      for (int t = 0; t < nt; ++t)
+        if (flag[t]) o[1 + n++] = t0 + t;
+    __syncthreads();
+  }
+  if (tid == 0) o[0] = n;
 }
 
 // V [b][key][head*D + d]  ->  V^T [b][head][d][key] (key padded to ldvt with zeros). 64x64 tiles.

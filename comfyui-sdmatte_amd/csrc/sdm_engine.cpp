@@ -744,12 +744,24 @@ static int op_ln(sdm_ctx* e, const NormL& n, const T& x, float eps, T* out) {
 
 // q/k/v are views into fp16 row-major buffers; v is transposed into an arena scratch first
 static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* k, int ldk, const half_t* v, int ldv, const float* bias_l2,
-                            int B, int heads, int Lq, int Lk, int D, half_t* out, int ldo, bool q_prescaled = false) {
+                            int B, int heads, int Lq, int Lk, int D, half_t* out, int ldo, bool q_prescaled = false, const int* tiles = nullptr) {
   if (!(D == 64 || (D == 512 && heads == 1))) SDM_FAIL(e, SDM_ERR_INVALID, "attention: unsupported head dim %d x %d heads", D, heads);
   if ((ldq | ldk | ldv | ldo) % 8) SDM_FAIL(e, SDM_ERR_INVALID, "attention: row strides must be multiples of 8");
   const int ldvt = rup(Lk, 64);
   T vt = talloc(e, B, heads, D, ldvt, 0);
+  // key tiles whose bias underflows the softmax are skipped (exact, AttnParams::tiles); the engine passes one list per U-Net
+  // level, the stand-alone operator entry builds it here.  SDM_ATTN_DENSE=1 walks every tile (A/B hook).
+  const bool dense_attn = getenv("SDM_ATTN_DENSE") != nullptr;
+  const int ntiles64 = sdm_cdiv(Lk, 64);
+  T tl_own;
+  const bool own_list = (D == 64) && bias_l2 && !tiles && !dense_attn;
+  if (own_list) tl_own = talloc(e, B, 1, 1, ntiles64 + 1, 1);
   if (!e->dry) {
+    if (own_list) {
+      SDM_LAUNCH(attn_active_tiles_kernel, dim3(B), dim3(256), 0, e->stream, bias_l2, Lk, ntiles64, (int*)tl_own.p, ntiles64 + 1, SDM_ATTN_SKIP_MARGIN);
+      tiles = (const int*)tl_own.p;
+    }
+    if (dense_attn || D != 64 || !bias_l2) tiles = nullptr;
     const long vt_hs = (long)D * ldvt, vt_bs = (long)heads * vt_hs;
     prof_begin(e, "transpose_v", 0, (double)B * Lk * heads * D * 4);
     SDM_LAUNCH(transpose_v_kernel, dim3(ldvt / 64, heads * (D / 64), B), dim3(256), 0, e->stream, v, (long)Lk * ldv, ldv, (half_t*)vt.p, vt_bs,
@@ -761,13 +773,28 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
     p.k = k; p.k_bs = (long)Lk * ldk; p.ldk = ldk;
     p.vt = (const half_t*)vt.p; p.vt_bs = vt_bs; p.vt_hs = vt_hs; p.ldvt = ldvt;
     p.bias = bias_l2; p.bias_bs = Lk;
+    p.tiles = tiles; p.tiles_bs = ntiles64 + 1;
     p.o = out; p.o_bs = (long)Lq * ldo; p.ldo = ldo;
     p.Lq = Lq; p.Lk = Lk;
     p.scale_log2e = q_prescaled ? 1.0f : (1.0f / sqrtf((float)D)) * SDM_LOG2E;      // engine: folded into the to_q weights (d = 64 only)
-    const double flops = 4.0 * B * heads * (double)Lq * Lk * D;
+    double flops = 4.0 * B * heads * (double)Lq * Lk * D;
     const double bytes = 2.0 * B * heads * D * (2.0 * Lq + 2.0 * Lk);
+    std::string adesc = "B=" + std::to_string(B) + " h=" + std::to_string(heads) + " Lq=" + std::to_string(Lq) + " Lk=" + std::to_string(Lk);
+    if (e->prof_on && tiles) {      // profiling only: report EXECUTED flops - needs the tile counts on the host
+      std::vector<int> hl((size_t)B * (ntiles64 + 1));
+      (void)dev_sync(e->stream);
+      (void)dev_memcpy_d2h(hl.data(), tiles, hl.size() * sizeof(int), e->stream);
+      (void)dev_sync(e->stream);
+      long act = 0;
+      for (int bi = 0; bi < B; ++bi) act += hl[(size_t)bi * (ntiles64 + 1)];
+      const double frac = (double)act / ((double)B * ntiles64);
+      flops *= frac;
+      char fb[48];
+      snprintf(fb, sizeof(fb), " active_key_tiles=%.3f", frac);
+      adesc += fb;
+    }
     if (D == 64) {
-      prof_begin(e, "attn_d64", flops, bytes, "B=" + std::to_string(B) + " h=" + std::to_string(heads) + " Lq=" + std::to_string(Lq) + " Lk=" + std::to_string(Lk));
+      prof_begin(e, "attn_d64", flops, bytes, adesc);
       // 64 queries per wave when that still leaves >= 2 blocks per CU, else 32
       const char* force_qt = getenv("SDM_ATTN_QT");       // test hook: force the 64-query-per-wave variant (measured slower)
       const bool qt2 = force_qt && force_qt[0] == '2';
@@ -793,6 +820,7 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
       prof_end(e);
     }
   }
+  if (own_list) tfree(e, tl_own);
   tfree(e, vt);
   return 0;
 }
@@ -907,7 +935,7 @@ static int vae_attention(sdm_ctx* e, const VaeAttnB& a, const T& x, T* out) {
 }
 
 // Transformer2DModel + BasicTransformerBlock (Appendix A.7); bias = level key-bias [N][L] (log2 domain) or null
-static int transformer(sdm_ctx* e, const TfB& t, const T& x, const T& uin, const float* bias, T* out) {
+static int transformer(sdm_ctx* e, const TfB& t, const T& x, const T& uin, const float* bias, const int* tiles, T* out) {
   const int sf = e->cfg.stream_f32;
   const int C = t.C, L = x.H * x.W, L0 = uin.H * uin.W;
   T hn, h, n, qkv, ao, h2, q2, kv, f;
@@ -921,7 +949,7 @@ static int transformer(sdm_ctx* e, const TfB& t, const T& x, const T& uin, const
   ao = talloc(e, x.N, x.H, x.W, C, 0);
   {
     const half_t* q = (const half_t*)qkv.p;
-    TRY(op_attention_raw(e, q, 3 * C, q ? q + C : nullptr, 3 * C, q ? q + 2 * C : nullptr, 3 * C, bias, x.N, t.heads, L, L, 64, (half_t*)ao.p, C, true));
+    TRY(op_attention_raw(e, q, 3 * C, q ? q + C : nullptr, 3 * C, q ? q + 2 * C : nullptr, 3 * C, bias, x.N, t.heads, L, L, 64, (half_t*)ao.p, C, true, tiles));
   }
   tfree(e, qkv);
   TRY(linear(e, t.o1, ao, &h2, C, sf, &h));
@@ -1076,7 +1104,7 @@ static int vae_decode(sdm_ctx* e, const T& z, T* dec) {
   return 0;
 }
 
-static int unet_forward(sdm_ctx* e, const T& uin, float* const* bias_lvl, T* out) {
+static int unet_forward(sdm_ctx* e, const T& uin, float* const* bias_lvl, int* const* tiles_lvl, T* out) {
   const sdm_config& c = e->cfg;
   const float eps = c.unet_res_eps;
   const int sf = c.stream_f32;
@@ -1089,7 +1117,7 @@ static int unet_forward(sdm_ctx* e, const T& uin, float* const* bias_lvl, T* out
       TRY(resblock(e, e->u_down_res[i][j], h, nullptr, eps, &t));
       if (i < 3) {
         T t2;
-        TRY(transformer(e, e->u_down_tf[i][j], t, uin, bias_lvl[i], &t2));
+        TRY(transformer(e, e->u_down_tf[i][j], t, uin, bias_lvl[i], tiles_lvl[i], &t2));
         tfree(e, t); t = t2;
       }
       h = t;                       // previous h stays alive as a skip
@@ -1103,7 +1131,7 @@ static int unet_forward(sdm_ctx* e, const T& uin, float* const* bias_lvl, T* out
   }
   // mid (h aliases the last skip: do not free it here)
   TRY(resblock(e, e->u_mid0, h, nullptr, eps, &t)); h = t;
-  TRY(transformer(e, e->u_midtf, h, uin, bias_lvl[3], &t)); tfree(e, h); h = t;
+  TRY(transformer(e, e->u_midtf, h, uin, bias_lvl[3], tiles_lvl[3], &t)); tfree(e, h); h = t;
   TRY(resblock(e, e->u_mid1, h, nullptr, eps, &t)); tfree(e, h); h = t;
   for (int i = 0; i < 4; ++i) {
     for (size_t j = 0; j < e->u_up_res[i].size(); ++j) {
@@ -1111,7 +1139,7 @@ static int unet_forward(sdm_ctx* e, const T& uin, float* const* bias_lvl, T* out
       TRY(resblock(e, e->u_up_res[i][j], h, &s, eps, &t));   // cat([h, skip], dim=1) then ResBlock (replace.py:509-536)
       tfree(e, h); tfree(e, s); h = t;
       if (i > 0) {
-        TRY(transformer(e, e->u_up_tf[i][j], h, uin, bias_lvl[3 - i], &t));
+        TRY(transformer(e, e->u_up_tf[i][j], h, uin, bias_lvl[3 - i], tiles_lvl[3 - i], &t));
         tfree(e, h); h = t;
       }
     }
@@ -1128,15 +1156,21 @@ static int run_model(sdm_ctx* e, const T& x16, const T& plane, int B, int S, T* 
   const sdm_config& c = e->cfg;
   const int l = S / 8;
   // attention key bias at the 4 U-Net levels (meta_arch.py:200-204, replace.py:401-403,56-63)
-  T biasbuf[4];
+  T biasbuf[4], tilebuf[4];
   float* bias_lvl[4];
+  int* tiles_lvl[4];            // per level: the key tiles that can contribute to the softmax (AttnParams::tiles), built once per forward
   for (int k = 0; k < 4; ++k) {
-    const int lk = l >> k;
+    const int lk = l >> k, nt = sdm_cdiv(lk * lk, 64);
     biasbuf[k] = talloc(e, B, 1, 1, lk * lk, 1);
+    tilebuf[k] = talloc(e, B, 1, 1, nt + 1, 1);
     bias_lvl[k] = (float*)biasbuf[k].p;
-    if (!e->dry)
+    tiles_lvl[k] = (int*)tilebuf[k].p;
+    if (!e->dry) {
       SDM_LAUNCH(mask_bias_kernel, dim3(sdm_cdiv(B * lk * lk, 256)), dim3(256), 0, e->stream, (const float*)plane.p, bias_lvl[k], B, S, k,
                  c.attn_mask_value, SDM_LOG2E);
+      SDM_LAUNCH(attn_active_tiles_kernel, dim3(B), dim3(256), 0, e->stream, (const float*)bias_lvl[k], lk * lk, nt, tiles_lvl[k], nt + 1,
+                 SDM_ATTN_SKIP_MARGIN);
+    }
   }
   // VAE encode of rgb and trimap as one batch (meta_arch.py:139-145, 209-212)
   T moments;
@@ -1155,9 +1189,9 @@ static int run_model(sdm_ctx* e, const T& x16, const T& plane, int B, int S, T* 
   // cross-attention context (meta_arch.py:215-218: aux_conv_in(trimap latent) as [B, l*l, ctx]) is never materialised:
   // every block's K|V comes straight from the latent through the folded 3x3 conv (transformer())
   T lat;
-  TRY(unet_forward(e, uin, bias_lvl, &lat));
+  TRY(unet_forward(e, uin, bias_lvl, tiles_lvl, &lat));
   tfree(e, uin);
-  for (int k = 0; k < 4; ++k) tfree(e, biasbuf[k]);
+  for (int k = 3; k >= 0; --k) { tfree(e, tilebuf[k]); tfree(e, biasbuf[k]); }
   // post_quant_conv + decoder (meta_arch.py:255-256)
   T z;
   TRY(conv_simple(e, e->post_quant, lat, &z, 16, 0)); tfree(e, lat);

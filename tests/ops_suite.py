@@ -106,7 +106,7 @@ def check_layernorm(eng, dev, rows, C, in_f32=True, seed=0, atol=4e-3):
     return err
 
 
-def check_attention(eng, dev, B, heads, Lq, Lk, D, use_bias, seed=0, atol=3e-3, fused_stride=False, spike=False):
+def check_attention(eng, dev, B, heads, Lq, Lk, D, use_bias, seed=0, atol=3e-3, fused_stride=False, spike=False, blocks=False):
     g = _g(seed)
     q = h16(torch.randn(B, Lq, heads * D, generator=g))
     k = h16(torch.randn(B, Lk, heads * D, generator=g))
@@ -119,6 +119,17 @@ def check_attention(eng, dev, B, heads, Lq, Lk, D, use_bias, seed=0, atol=3e-3, 
         keep = (torch.rand(B, Lk, generator=g) > 0.5).float()
         keep[:, Lk // 3] = 1.0
         bias = (1 - keep) * -10000.0
+        if blocks:
+            # trimap-like three-level bias with whole 64-key tiles at -5000 / -10000 (the engine never loads those tiles: their
+            # probabilities underflow to exactly 0, as in the reference); image 0: a few scattered foreground runs, last image:
+            # no foreground key at all (every key at -10000 -> the bias cancels and nothing may be skipped)
+            bias = torch.full((B, Lk), -10000.0)
+            bias[:, Lk // 2:] = -5000.0
+            for b in range(B - 1 if B > 1 else B):
+                for t0 in range(64 * (1 + b), Lk, 64 * 5):
+                    bias[b, t0 + 7:min(t0 + 40, Lk)] = 0.0
+            if B > 1:
+                bias[B - 1] = -10000.0
     scale = D ** -0.5
     qh = q.view(B, Lq, heads, D).permute(0, 2, 1, 3)
     kh = k.view(B, Lk, heads, D).permute(0, 2, 1, 3)

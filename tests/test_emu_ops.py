@@ -76,6 +76,23 @@ def test_attention_d64(emu_engine):
     S.check_attention(emu_engine, DEV, 1, 1, 32, 192, 64, use_bias=False, spike=True, seed=3)
 
 
+def test_attention_d64_skips_underflowing_key_tiles(emu_engine, monkeypatch):
+    # trimap-like bias with whole key tiles at -5000 / -10000: those tiles are never loaded; the result must equal the fp32
+    # reference (where their probabilities underflow to 0) AND be bit-identical to walking every tile
+    S.check_attention(emu_engine, DEV, 3, 2, 40, 500, 64, use_bias=True, blocks=True, seed=7)
+    import torch
+    g = torch.Generator().manual_seed(11)
+    q, k, v = (torch.randn(2, n, 64, generator=g).half() for n in (50, 320, 320))
+    bias = torch.full((2, 320), -10000.0)
+    bias[0, 130:150] = 0.0
+    bias[1, 5:9] = 0.0
+    bias[1, 200:] = -5000.0
+    sparse = emu_engine.op_attention(q, k, v, 1, bias)
+    monkeypatch.setenv("SDM_ATTN_DENSE", "1")
+    dense = emu_engine.op_attention(q, k, v, 1, bias)
+    assert torch.equal(sparse, dense)
+
+
 def test_attention_d64_64q_per_wave(emu_engine, monkeypatch):
     monkeypatch.setenv("SDM_ATTN_QT", "2")
     S.check_attention(emu_engine, DEV, 1, 2, 150, 200, 64, use_bias=True, fused_stride=True, seed=5)

@@ -76,6 +76,24 @@ def test_attention_d64(eng):
     S.check_attention(eng, DEV, 1, 1, 64, 4096, 64, use_bias=False, spike=True, seed=3)            # forced rescale branch
 
 
+def test_attention_d64_skips_underflowing_key_tiles(eng, monkeypatch):
+    # trimap-like bias with whole key tiles at -5000 / -10000: never loaded; equal to the fp32 reference and bit-identical to
+    # walking every tile (SDM_ATTN_DENSE)
+    S.check_attention(eng, DEV, 3, 5, 1000, 4096, 64, use_bias=True, blocks=True, seed=7)
+    import torch
+    g = torch.Generator().manual_seed(11)
+    q, k, v = (torch.randn(2, n, 128, generator=g).half().to(DEV) for n in (300, 1500, 1500))
+    bias = torch.full((2, 1500), -10000.0)
+    bias[0, 130:150] = 0.0
+    bias[0, 1400:1410] = 0.0
+    bias[1, 5:9] = 0.0
+    bias[1, 700:] = -5000.0
+    sparse = eng.op_attention(q, k, v, 2, bias.to(DEV)).cpu()
+    monkeypatch.setenv("SDM_ATTN_DENSE", "1")
+    dense = eng.op_attention(q, k, v, 2, bias.to(DEV)).cpu()
+    assert torch.equal(sparse, dense)
+
+
 def test_attention_d64_64q_per_wave(eng, monkeypatch):
     monkeypatch.setenv("SDM_ATTN_QT", "2")
     S.check_attention(eng, DEV, 1, 2, 150, 200, 64, use_bias=True, fused_stride=True, seed=5)

@@ -6,7 +6,7 @@ load_package()
 from comfyui_sdmatte_amd.engine import Engine
 from comfyui_sdmatte_amd.config import SDMatteConfig
 eng = Engine(SDMatteConfig.tiny(), 0)
-shapes = [("128->128 @1024^2 N=2", (2, 1024, 1024, 128, 128, 9)), ("512->512 @256^2 N=2", (2, 256, 256, 512, 512, 9)),
+shapes = [("128->128 @1024^2 N=8", (8, 1024, 1024, 128, 128, 9)), ("512->512 @256^2 N=8", (8, 256, 256, 512, 512, 9)),
           ("gemm 1024->2560 M=32768", (2, 128, 128, 1024, 2560, 1)), ("gemm 320->320 M=32768", (2, 128, 128, 320, 320, 1))]
 names = {0: "full", 1: "no global loads", 2: "no LDS writes", 3: "no loads+writes", 4: "no MFMA phase", 8: "no epilogue stores", 7: "barriers only", 15: "nothing"}
 for label, (N, H, W, ci, co, nt) in shapes:
