@@ -101,11 +101,11 @@ static void launch_conv_t(const ConvParams& p_in, void* stream) {
 }
 
 struct ConvCfgInfo { int TH, TW, BN, KC, WM; };
-static const ConvCfgInfo kCfg3s1[] = {{8, 32, 128, 16, 2}, {4, 32, 64, 32, 4}, {8, 8, 64, 16, 2}, {16, 32, 128, 16, 4}};
-static const ConvCfgInfo kCfg3s2[] = {{4, 32, 64, 16, 4}, {8, 8, 64, 16, 2}};
+static const ConvCfgInfo kCfg3s1[] = {{8, 32, 128, 16, 2}, {4, 32, 64, 32, 4}, {8, 8, 64, 16, 2}, {16, 32, 128, 16, 4}, {8, 32, 32, 16, 4}};
+static const ConvCfgInfo kCfg3s2[] = {{4, 32, 64, 16, 4}, {8, 8, 64, 16, 2}, {4, 32, 128, 16, 2}, {8, 32, 128, 16, 4}};
 static const ConvCfgInfo kCfg1[] = {{8, 32, 128, 64, 2}, {4, 32, 64, 64, 4}, {8, 8, 64, 64, 2}, {8, 8, 64, 16, 2}};
 
-static int conv_num_cfgs(int ntaps, int stride) { return ntaps == 9 ? (stride == 1 ? 4 : 2) : 4; }
+static int conv_num_cfgs(int ntaps, int stride) { return ntaps == 9 ? (stride == 1 ? 5 : 4) : 4; }
 static const ConvCfgInfo* conv_cfg_table(int ntaps, int stride) { return ntaps == 9 ? (stride == 1 ? kCfg3s1 : kCfg3s2) : kCfg1; }
 
 static bool conv_cfg_ok(const ConvCfgInfo& c, const ConvParams& p) {
@@ -124,7 +124,8 @@ static int conv_pick_cfg(int ntaps, int stride, const ConvParams& p) {
   static const bool use_db = getenv("SDM_CONV_DB") && getenv("SDM_CONV_DB")[0] == '1';   // A/B hook for the 512x128 double-buffered tile
   for (int i = 0; i < n; ++i) {
     if (!conv_cfg_ok(t[i], p)) continue;
-    if (ntaps == 9 && stride == 1 && i == 3) continue;          // variant of cfg 0, substituted below
+    if (ntaps == 9 && stride == 1 && i >= 3) continue;          // cfg 3 / 4: variants of cfg 0, substituted below
+    if (ntaps == 9 && stride == 2 && i >= 2) continue;          // cfg 2: forced only; cfg 3: substituted below
     long blocks;
     if (ntaps == 9) {
       if (t[i].TW > 8 && p.Wout < 24) continue;   // 32-wide strips would be mostly padding
@@ -136,6 +137,13 @@ static int conv_pick_cfg(int ntaps, int stride, const ConvParams& p) {
     if (blocks >= 256) {
       // cfg 3 (512-pixel tile, 1 block per CU) needs at least ~2 blocks per CU of its own to pay off
       if (use_db && ntaps == 9 && stride == 1 && i == 0 && (long)p.N * sdm_cdiv(p.Hout, 16) * sdm_cdiv(p.Wout, 32) * sdm_cdiv(p.Cout_pad, 128) >= 512) return 3;
+      // thin outputs (conv_out layers, Cout <= 32): the same 256-pixel tile with 32 output channels instead of 128 (HBM-bound
+      // layers: 128 -> 3 @1024^2 1.33 -> 0.63 ms)
+      if (ntaps == 9 && stride == 1 && i == 0 && p.Cout_pad <= 32 && conv_cfg_ok(t[4], p)) return 4;
+      // stride 2: 256 pixels x 128 channels on 8 waves halves the input re-reads per output channel (+25 % on the VAE
+      // down-samplers) once there is a block for every CU
+      if (ntaps == 9 && stride == 2 && i == 0 && conv_cfg_ok(t[3], p) &&
+          (long)p.N * sdm_cdiv(p.Hout, 8) * sdm_cdiv(p.Wout, 32) * sdm_cdiv(p.Cout_pad, 128) >= 256) return 3;
       return i;
     }   // first (largest) tile that still gives every CU a block
     if (blocks > best_blocks) { best = i; best_blocks = blocks; }
@@ -150,11 +158,14 @@ static int launch_conv(int ntaps, int stride, int cfg, const ConvParams& p, void
       case 1: launch_conv_t<9, 1, 4, 32, 64, 32, 4, 1>(p, stream); return 0;
       case 2: launch_conv_t<9, 1, 8, 8, 64, 16, 2, 1>(p, stream); return 0;
       case 3: launch_conv_t<9, 1, 16, 32, 128, 16, 4, 2, 1>(p, stream); return 0;   // 512 px x 128 co, 8 waves, swizzled double-buffered LDS tiles
+      case 4: launch_conv_t<9, 1, 8, 32, 32, 16, 4, 1, 0, 1>(p, stream); return 0;   // 256 px x 32 co: thin-output convs (conv_out), fused GroupNorm
     }
   } else if (ntaps == 9 && stride == 2) {
     switch (cfg) {
       case 0: launch_conv_t<9, 2, 4, 32, 64, 16, 4, 1>(p, stream); return 0;
       case 1: launch_conv_t<9, 2, 8, 8, 64, 16, 2, 1>(p, stream); return 0;
+      case 2: launch_conv_t<9, 2, 4, 32, 128, 16, 2, 2>(p, stream); return 0;
+      case 3: launch_conv_t<9, 2, 8, 32, 128, 16, 4, 2>(p, stream); return 0;
     }
   } else if (ntaps == 1) {
     switch (cfg) {
@@ -607,7 +618,7 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
   int cfg = a.force_cfg >= 0 ? a.force_cfg : conv_pick_cfg(L.ntaps, a.stride, p);
   if (cfg < 0 || cfg >= conv_num_cfgs(L.ntaps, a.stride) || !conv_cfg_ok(conv_cfg_table(L.ntaps, a.stride)[cfg], p))
     SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: no tile configuration for Cin=%d+%d (cfg %d)", L.name.c_str(), p.C0, p.C1, cfg);
-  if (a.gn_scale && !(L.ntaps == 9 && a.stride == 1 && cfg == 0 && p.C0 + p.C1 <= 1024))
+  if (a.gn_scale && !(L.ntaps == 9 && a.stride == 1 && (cfg == 0 || cfg == 4) && p.C0 + p.C1 <= 1024))
     SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: fused GroupNorm requested for an unsupported tile configuration", L.name.c_str());
   if (a.out->want_stats) {
     if (L.geglu || a.out_ch_off) SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: fused statistics unsupported with this epilogue", L.name.c_str());
@@ -850,7 +861,8 @@ static bool conv_can_fuse_gn(sdm_ctx* e, const ConvL& L, const T& x, const T* x2
   memset(&p, 0, sizeof(p));
   p.C0 = x.C; p.C1 = x2 ? x2->C : 0; p.in_f32 = x.f32; p.N = x.N; p.Hin = x.H; p.Win = x.W; p.Hout = x.H; p.Wout = x.W; p.Cout_pad = L.Cout_pad;
   p.M = x.rows();
-  return conv_pick_cfg(9, 1, p) == 0;
+  const int cfg = conv_pick_cfg(9, 1, p);
+  return cfg == 0 || cfg == 4;        // the two 256-pixel tiles that carry the fused-GroupNorm variant
   (void)e;
 }
 
@@ -867,8 +879,7 @@ static int gn_conv(sdm_ctx* e, const NormL& n, const ConvL& L, const T& x, const
                        x2 ? x2->stats : nullptr, x2 ? x2->srows : 0, hs, &scratch, &scale, &shift));
     a.in0 = &x; a.in1 = x2;
     a.gn_scale = e->dry ? (const float*)16 : scale; a.gn_shift = shift; a.gn_silu = silu;
-    a.force_cfg = 0;
-    int rc = op_conv(e, L, a);
+    int rc = op_conv(e, L, a);          // picks the same tile conv_can_fuse_gn saw
     tfree(e, scratch);
     return rc;
   }

@@ -26,17 +26,21 @@ def emu_engine(pkg):
 DEV = "cpu"
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
 def test_conv3x3_s1_all_tile_cfgs(emu_engine, cfg):
     cin = 32 if cfg == 1 else 16
     S.check_conv(emu_engine, DEV, 1, 9, 35, cin, 40, tile_cfg=cfg, seed=cfg)
+
+
+def test_conv3x3_thin_output_tile(emu_engine):
+    S.check_conv(emu_engine, DEV, 2, 10, 33, 32, 3, in_f32=True, tile_cfg=4, seed=9)          # conv_out shape: Cout 3 -> one 32-wide tile
 
 
 def test_conv3x3_s1_multi_chunk_and_batch(emu_engine):
     S.check_conv(emu_engine, DEV, 2, 12, 12, 64, 96, tile_cfg=2, res="f32", out_f32=True, seed=5)
 
 
-@pytest.mark.parametrize("cfg", [0, 1])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
 @pytest.mark.parametrize("pad_mode", [0, 1])
 def test_conv3x3_s2(emu_engine, cfg, pad_mode):
     S.check_conv(emu_engine, DEV, 1, 16, 40, 16, 32, stride=2, pad_mode=pad_mode, tile_cfg=cfg, seed=7 + cfg)

@@ -23,12 +23,13 @@ def eng(pkg):
 
 
 @pytest.mark.parametrize("cfg,cin,cout,H,W", [(0, 128, 128, 40, 96), (0, 16, 128, 33, 70), (1, 320, 320, 16, 64), (2, 640, 200, 16, 16),
-                                              (2, 16, 1024, 16, 16), (-1, 256, 256, 64, 64), (-1, 1280, 1280, 8, 8), (3, 128, 128, 40, 96), (3, 512, 200, 24, 40)])
+                                              (2, 16, 1024, 16, 16), (-1, 256, 256, 64, 64), (-1, 1280, 1280, 8, 8), (3, 128, 128, 40, 96), (3, 512, 200, 24, 40),
+                                              (4, 128, 3, 70, 100), (4, 512, 8, 33, 40)])
 def test_conv3x3_s1(eng, cfg, cin, cout, H, W):
     S.check_conv(eng, DEV, 2, H, W, cin, cout, tile_cfg=cfg, seed=cfg + 5)
 
 
-@pytest.mark.parametrize("cfg,pad_mode", [(0, 0), (0, 1), (1, 0), (1, 1), (-1, 1)])
+@pytest.mark.parametrize("cfg,pad_mode", [(0, 0), (0, 1), (1, 0), (1, 1), (2, 1), (3, 0), (3, 1), (-1, 1)])
 def test_conv3x3_s2(eng, cfg, pad_mode):
     S.check_conv(eng, DEV, 2, 32, 64, 128, 128, stride=2, pad_mode=pad_mode, tile_cfg=cfg, seed=40 + cfg)
 
