@@ -8,11 +8,10 @@ from comfyui_sdmatte_amd.engine import Engine
 from comfyui_sdmatte_amd.config import SDMatteConfig
 eng = Engine(SDMatteConfig.tiny(), 0)
 label = sys.argv[1] if len(sys.argv) > 1 else ""
-shapes = [(8, 1024, 1024, 128, 128, 9, 1, 0, (0, 5)), (8, 512, 512, 256, 256, 9, 1, 0, (0, 5)), (8, 256, 256, 512, 512, 9, 1, 1, (0, 5)),
-          (4, 128, 128, 320, 320, 9, 1, 0, (0, 5)), (4, 64, 64, 640, 640, 9, 1, 0, (-1, 0, 5)), (4, 32, 32, 1280, 1280, 9, 1, 0, (-1, 5)),
-          (4, 128, 128, 320, 320, 1, 1, 0, (0, 4)), (4, 128, 128, 320, 320, 1, 1, 1, (0, 4)), (4, 128, 128, 320, 2560, 1, 1, 0, (0, 4)),
-          (4, 128, 128, 1280, 320, 1, 1, 0, (0, 4)), (4, 64, 64, 640, 640, 1, 1, 0, (-1, 0, 4)), (4, 32, 32, 1280, 1280, 1, 1, 0, (-1, 4)),
-          (8, 128, 128, 512, 1536, 1, 1, 0, (0, 4)), (4, 1024, 1024, 256, 128, 1, 1, 1, (0, 4))]
+shapes = [(8, 1024, 1024, 128, 128, 9, 1, 0, (-1,)), (8, 1024, 1024, 128, 128, 9, 1, 1, (-1,)), (8, 512, 512, 256, 256, 9, 1, 0, (-1,)),
+          (8, 256, 256, 512, 512, 9, 1, 0, (-1,)), (8, 256, 256, 512, 512, 9, 1, 1, (-1,)), (4, 128, 128, 320, 320, 9, 1, 0, (-1,)),
+          (4, 64, 64, 640, 640, 9, 1, 0, (-1,)), (8, 1024, 1024, 128, 128, 9, 2, 1, (-1,)), (4, 1024, 1024, 128, 3, 9, 1, 1, (-1,)),
+          (4, 128, 128, 320, 320, 1, 1, 0, (-1,)), (4, 128, 128, 1280, 1280, 1, 1, 0, (-1,)), (4, 1024, 1024, 256, 128, 1, 1, 1, (-1,))]
 for (N, H, W, ci, co, nt, st, f32, cfgs) in shapes:
     fl = 2.0 * N * (H // st) * (W // st) * ci * co * nt
     for cfg in cfgs:
