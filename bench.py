@@ -119,6 +119,16 @@ def main():
     value = world * B * args.steps / elapsed
 
     result = None
+    b1 = None
+    if rank == 0 and world == 1 and B > 1:
+        # BASELINE configs[1] is quoted at one image per call: report that latency next to the batched throughput
+        a1 = torch.empty(1, S, S, dtype=torch.float32, device=dev)
+        eng.apply_matte(img_d[:1], tri_d[:1], S, False, out=a1, sync=True)
+        ms1 = []
+        for _ in range(3):
+            eng.apply_matte(img_d[:1], tri_d[:1], S, False, out=a1, sync=True)
+            ms1.append(eng.last_forward_ms())
+        b1 = {"batch": 1, "ms_per_image": round(sum(ms1) / len(ms1), 3), "images_per_s": round(1e3 * len(ms1) / sum(ms1), 3)}
     if rank == 0:
         # ---- roofline of the dominant kernel: per-launch HIP events on the engine stream (separate pass, 1 step) ----
         eng.profile(True)
@@ -181,7 +191,7 @@ def main():
                        "key tiles whose (1-m)*-10000 bias underflows the fp32 softmax are not loaded (exact; --dense-attention disables)"},
             "gpu_ms_per_step_events": round(gpu_ms / max(args.steps, 1), 3),
             "tflops_per_gpu": round(FLOPS_PER_IMAGE.get(S, 0) * B / (ms_per_step * 1e-3) / 1e12, 1),
-            "weight_load_s": round(load_s, 1),
+            "weight_load_s": round(load_s, 1), "single_image": b1,
             "roofline": roof, "cpu_baseline": cpu, "kernel_breakdown_ms": breakdown,
         }
         print(json.dumps(result))

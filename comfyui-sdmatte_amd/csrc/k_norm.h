@@ -124,6 +124,83 @@ __global__ void gn_finalize_ch_kernel(const double* __restrict__ st0, const doub
   shift[i] = beta[c] - (float)mean * a;
 }
 
+// One launch per norm: per-(tile, wave-row) partial {sum, sumsq} rows written by the producing conv epilogues (k_conv.h `stats`;
+// st0 / st1 = [N][rows0|rows1][C0|C1][2] fp32 for the two concat sources) -> scale / shift of every channel.  One block of
+// 1024 threads per (group, image); 16-byte loads (two channels' {sum, sumsq}), four independent fp64 accumulator pairs per
+// thread; no memset, no atomics, no separate finalize pass (was three launches per norm, 113 norms per forward).  A group may
+// straddle the concat boundary.
+#define GN_PSS_THREADS 1024
+// VEC = 2: two channels' {sum, sumsq} per 16-byte load (even channel ranges); VEC = 1: one channel per 8-byte load
+template <int VEC>
+SDM_DEV_INLINE void gn_pss_accumulate(const float* __restrict__ st, size_t img_off, int rows, int Csrc, int a, int nch, int tid, double (&acc)[4][2]) {
+  const int nv = nch / VEC;
+  const long items = (long)rows * nv;
+  auto load = [&](long it, float (&v)[4]) {
+    const long r = it / nv;
+    const int c = a + VEC * (int)(it - r * nv);
+    const float* pp = st + (img_off + (size_t)r * Csrc + c) * 2;
+    if (VEC == 2) { const f32x4 t = *(const f32x4*)pp; v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
+    else { const f32x2 t = *(const f32x2*)pp; v[0] = t[0]; v[1] = t[1]; v[2] = 0.0f; v[3] = 0.0f; }
+  };
+  long i = tid;
+  for (; i + 3L * GN_PSS_THREADS < items; i += 4L * GN_PSS_THREADS) {
+    float v[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) load(i + (long)u * GN_PSS_THREADS, v[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { acc[u][0] += (double)v[u][0] + (double)v[u][2]; acc[u][1] += (double)v[u][1] + (double)v[u][3]; }
+  }
+  for (; i < items; i += GN_PSS_THREADS) {
+    float v[4];
+    load(i, v);
+    acc[0][0] += (double)v[0] + (double)v[2]; acc[0][1] += (double)v[1] + (double)v[3];
+  }
+}
+__global__ void __launch_bounds__(GN_PSS_THREADS) gn_partials_scale_shift_kernel(const float* __restrict__ st0, int rows0, const float* __restrict__ st1,
+                                                                                 int rows1, int C0, int C1, const float* __restrict__ gamma,
+                                                                                 const float* __restrict__ beta, float* __restrict__ scale,
+                                                                                 float* __restrict__ shift, int groups, long hw, float eps) {
+  SDM_SHARED double red[GN_PSS_THREADS][2];
+  const int C = C0 + C1, cpg = C / groups;
+  const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  const int c_lo = g * cpg, c_hi = c_lo + cpg;
+  const bool vec2 = !(cpg & 1) && !(C0 & 1);      // group and concat boundaries on even channels (every layer of the real model)
+  double acc[4][2];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { acc[u][0] = 0.0; acc[u][1] = 0.0; }
+  {   // source 0: concat channels [c_lo, min(c_hi, C0))
+    const int a = c_lo < C0 ? c_lo : C0, b = c_hi < C0 ? c_hi : C0;
+    if (b > a) {
+      if (vec2) gn_pss_accumulate<2>(st0, (size_t)n * rows0 * C0, rows0, C0, a, b - a, tid, acc);
+      else gn_pss_accumulate<1>(st0, (size_t)n * rows0 * C0, rows0, C0, a, b - a, tid, acc);
+    }
+  }
+  if (C1 > 0) {   // source 1: concat channels [max(c_lo, C0), c_hi) -> local channels - C0
+    const int a = (c_lo > C0 ? c_lo : C0) - C0, b = (c_hi > C0 ? c_hi : C0) - C0;
+    if (b > a) {
+      if (vec2) gn_pss_accumulate<2>(st1, (size_t)n * rows1 * C1, rows1, C1, a, b - a, tid, acc);
+      else gn_pss_accumulate<1>(st1, (size_t)n * rows1 * C1, rows1, C1, a, b - a, tid, acc);
+    }
+  }
+  red[tid][0] = (acc[0][0] + acc[1][0]) + (acc[2][0] + acc[3][0]);
+  red[tid][1] = (acc[0][1] + acc[1][1]) + (acc[2][1] + acc[3][1]);
+  __syncthreads();
+  for (int st = GN_PSS_THREADS / 2; st > 0; st >>= 1) {
+    if (tid < st) { red[tid][0] += red[tid + st][0]; red[tid][1] += red[tid + st][1]; }
+    __syncthreads();
+  }
+  const double cnt = (double)hw * cpg;
+  const double mean = red[0][0] / cnt;
+  double var = red[0][1] / cnt - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  for (int c = c_lo + tid; c < c_hi; c += GN_PSS_THREADS) {
+    const float a = rstd * gamma[c];
+    scale[(size_t)n * C + c] = a;
+    shift[(size_t)n * C + c] = beta[c] - (float)mean * a;
+  }
+}
+
 // y = act(x*scale + shift) -> fp16 NHWC with C channels (concat materialised)
 __global__ void __launch_bounds__(512) gn_apply_kernel(GnSrc s, const float* __restrict__ scale, const float* __restrict__ shift,
                                                        half_t* __restrict__ out, int silu, int pix_per_block) {

@@ -683,15 +683,10 @@ static int gn_scale_shift(sdm_ctx* e, const void* in0, const void* in1, int C0, 
   float* shift = scale + (size_t)N * C;
   *scale_out = scale; *shift_out = shift;
   if (have_stats) {
-    SDM_CHECK_DEV(e, dev_memset(sums, 0, (size_t)N * C * 16, e->stream));
-    double* s0 = sums;
-    double* s1 = sums + (size_t)N * C0 * 2;
     prof_begin(e, "gn_reduce", 0, ((double)rows0 * C0 + (double)rows1 * C1) * N * 8);
-    SDM_LAUNCH(gn_reduce_partials_kernel, dim3(sdm_cdiv(C0, 32), N, std::max(1, std::min(16, rows0 / 64))), dim3(256), 0, e->stream, st0, s0, rows0, C0);
-    if (C1) SDM_LAUNCH(gn_reduce_partials_kernel, dim3(sdm_cdiv(C1, 32), N, std::max(1, std::min(16, rows1 / 64))), dim3(256), 0, e->stream, st1, s1, rows1, C1);
+    SDM_LAUNCH(gn_partials_scale_shift_kernel, dim3(groups, N), dim3(GN_PSS_THREADS), 0, e->stream, st0, rows0, st1, rows1, C0, C1, gamma, beta, scale, shift,
+               groups, (long)HW, eps);
     prof_end(e);
-    SDM_LAUNCH(gn_finalize_ch_kernel, dim3(sdm_cdiv(N * C, 256)), dim3(256), 0, e->stream, (const double*)s0, (const double*)s1, C0, C1, gamma, beta,
-               scale, shift, N, groups, (long)HW, eps);
   } else {
     GnSrc s; s.in0 = in0; s.in1 = in1; s.C0 = C0; s.C1 = C1; s.in_f32 = in_f32; s.HW = HW;
     const int CV = C / 8;
