@@ -60,7 +60,7 @@ struct ConvParams {
   int tiles_m, tiles_n, xcd_chunk;      // 1-D XCD-aware grid (set by launch_conv_t): M tiles per image (9 taps) or in total (1 tap), N tiles, M tiles per XCD
   float* stats;                         // optional [N][tiles_m*WM][Cout_store][2]: per-(image, wave row-tile, channel) partial
                                         // sum / sum of squares of the stored values = fused GroupNorm statistics of the NEXT
-                                        // layer (reduced by gn_reduce_partials_kernel); NTAPS==9 or one image per launch
+                                        // layer (reduced by gn_partials_scale_shift_kernel); NTAPS==9 or one image per launch
 };
 
 template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN, int DB = 0>

@@ -76,54 +76,6 @@ __global__ void gn_finalize_kernel(const double* __restrict__ sums, const float*
   shift[i] = beta[c] - (float)mean * a;
 }
 
-// partial[n][rows][C][2] (fp32, written by the conv epilogues) -> sums[n][C][2] (fp64, zero-initialised by the caller).
-// grid (ceil(C/32), N, splits), 256 threads = 8 row-lanes x 32 channels; `splits` fp64 atomics per address.
-__global__ void __launch_bounds__(256) gn_reduce_partials_kernel(const float* __restrict__ part, double* __restrict__ sums, int rows, int C) {
-  SDM_SHARED double red[8][32][2];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + tx, n = blockIdx.y;
-  const int per = (rows + gridDim.z - 1) / gridDim.z;
-  const int r0 = blockIdx.z * per, r1 = min(r0 + per, rows);
-  double s = 0.0, q = 0.0;
-  if (c < C)
-    for (int r = r0 + ty; r < r1; r += 8) {
-      const float* p = part + (((size_t)n * rows + r) * C + c) * 2;
-      s += (double)p[0];
-      q += (double)p[1];
-    }
-  red[ty][tx][0] = s; red[ty][tx][1] = q;
-  __syncthreads();
-  if (ty == 0 && c < C) {
-    for (int k = 1; k < 8; ++k) { s += red[k][tx][0]; q += red[k][tx][1]; }
-    atomicAdd(&sums[((size_t)n * C + c) * 2 + 0], s);
-    atomicAdd(&sums[((size_t)n * C + c) * 2 + 1], q);
-  }
-}
-
-// Same, but from per-(image, channel) sums produced by the conv epilogues of the producer(s) (k_conv.h `stats`):
-// st0/st1 are [N][C0|C1][2] doubles for the two concat sources; a group may straddle the concat boundary.
-__global__ void gn_finalize_ch_kernel(const double* __restrict__ st0, const double* __restrict__ st1, int C0, int C1,
-                                      const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ scale,
-                                      float* __restrict__ shift, int N, int groups, long hw, float eps) {
-  const int C = C0 + C1;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N * C) return;
-  const int n = i / C, c = i % C, cpg = C / groups, g = c / cpg;
-  double s = 0.0, q = 0.0;
-  for (int j = g * cpg; j < (g + 1) * cpg; ++j) {
-    const double* p = (j < C0) ? st0 + ((size_t)n * C0 + j) * 2 : st1 + ((size_t)n * C1 + (j - C0)) * 2;
-    s += p[0]; q += p[1];
-  }
-  const double cnt = (double)hw * cpg;
-  const double mean = s / cnt;
-  double var = q / cnt - mean * mean;
-  if (var < 0.0) var = 0.0;
-  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-  const float a = rstd * gamma[c];
-  scale[i] = a;
-  shift[i] = beta[c] - (float)mean * a;
-}
-
 // One launch per norm: per-(tile, wave-row) partial {sum, sumsq} rows written by the producing conv epilogues (k_conv.h `stats`;
 // st0 / st1 = [N][rows0|rows1][C0|C1][2] fp32 for the two concat sources) -> scale / shift of every channel.  One block of
 // 1024 threads per (group, image); 16-byte loads (two channels' {sum, sumsq}), four independent fp64 accumulator pairs per
