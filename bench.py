@@ -42,6 +42,9 @@ def main():
     ap.add_argument("--cpu-sample-size", type=int, default=512)
     ap.add_argument("--dump-profile", type=str, default=None, help="write the per-launch profile CSV here")
     ap.add_argument("--fp16-stream", action="store_true", help="keep the residual stream in fp16 instead of fp32")
+    ap.add_argument("--single-image", action="store_true",
+                    help="also time B=1 calls (BASELINE configs[1] latency); off by default so that the default command launches one "
+                         "kernel population only (the rocprofv3 summaries in profiles/ are of the default command)")
     ap.add_argument("--dense-attention", action="store_true",
                     help="walk every key tile in the trimap-biased self-attention instead of skipping the tiles whose bias underflows the softmax")
     args = ap.parse_args()
@@ -120,7 +123,7 @@ def main():
 
     result = None
     b1 = None
-    if rank == 0 and world == 1 and B > 1:
+    if rank == 0 and world == 1 and B > 1 and args.single_image:
         # BASELINE configs[1] is quoted at one image per call: report that latency next to the batched throughput
         a1 = torch.empty(1, S, S, dtype=torch.float32, device=dev)
         eng.apply_matte(img_d[:1], tri_d[:1], S, False, out=a1, sync=True)
