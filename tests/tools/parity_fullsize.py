@@ -2,7 +2,7 @@
 #2 1024x1024 B=1 alpha_only (engine forward vs fp32 CPU oracle), #4 768x768 through the node post-processing
 (mask_refine, trimap_constraint 0.8).  GPU box only (bench helper)."""
 import sys, os, time, json, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from __graft_entry__ import load_package
 load_package()
 from comfyui_sdmatte_amd.engine import Engine

@@ -1,6 +1,6 @@
 """fp32 vs fp16 residual stream: parity vs the fp32 oracle on the full architecture at 512^2 (GPU box only; bench helper)."""
 import sys, os, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from __graft_entry__ import load_package
 load_package()
 from comfyui_sdmatte_amd.engine import Engine
