@@ -143,7 +143,10 @@ int sdm_op_layernorm(sdm_ctx* ctx, const void* x, int in_f32, long rows, int C, 
                      float eps, void* out_f16);
 /* softmax(q k^T * scale + bias) v per (batch, head): q [B,Lq,heads*D], k,v [B,Lk,heads*D] fp16 with row
  * strides ldq/ldk/ldv, bias fp32 [B,Lk] or NULL (natural-log domain, as in the reference), out [B,Lq,heads*D].
- * D = 64 (any heads) or 512 (heads = 1). */
+ * D = 64 (any heads) or 512 (heads = 1).  With a bias (D = 64), 64-key tiles in which every key's bias lies more than
+ * 2000*ln(2) below the image's largest bias are not loaded: their probabilities underflow to exactly 0 in fp32, as they do in
+ * the reference's softmax (trimap keys carry (1-m)*-10000, replace.py:401-403).  The result is bit-identical to walking
+ * every tile; setting the environment variable SDM_ATTN_DENSE disables the skip. */
 int sdm_op_attention(sdm_ctx* ctx, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* bias,
                      int B, int heads, int Lq, int Lk, int D, void* out, int ldo);
 /* Antialiased bilinear resize of fp32 planes [P, Hin, Win] -> [P, Hout, Wout] (torchvision Resize). */
