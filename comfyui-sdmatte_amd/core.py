@@ -4,16 +4,22 @@ Mirrors the constructor / `load_state_dict` / `eval` / `to` / `__call__(data)` s
 (/root/reference/src/modeling/SDMatte/meta_arch.py:30-77,127) as used by the node
 (/root/reference/sdmatte_nodes.py:286-296,321-323,358), but owns no torch modules: weights go straight
 from the checkpoint tensors into the engine's packed fp16 arena (HIP pack kernels), and the forward is
-one C-ABI call.  The configuration the node uses (trimap aux input, trimap-latent cross-attention
-context, trimap key mask, no noise) is the one implemented; the other prompt types of the reference
-core (point/bbox/mask) are "next" scope and raise NotImplementedError.
+one C-ABI call.  All prompt types of the reference core are served by the same engine graph
+(meta_arch.py:22-28,131-206): the aux image `data[aux_input]` ("trimap", "bbox_mask", "mask", "auto_mask",
+"point_mask") is VAE-encoded and used as cross-attention context; its coordinates go through
+bbox_embedding (4 values) or, for point prompts, point_embedding; the aux key mask of the self-attention
+is applied when `aux_input` is listed in `attn_mask_aux_input`.  What stays unsupported raises
+NotImplementedError: noise / multi-step inference, the CLIP text context, random prompt choice
+(aux_input=None), partial attention-mask / context stage lists.
 """
 import torch
 
 from .config import SDMatteConfig
 from .engine import Engine
 
-_TRIMAP_LISTS = ["point_mask", "bbox_mask", "mask", "trimap"]
+# meta_arch.py:22-28: prompt image key -> coordinate key of `data`
+AUX_INPUT_DIT = {"auto_mask": "auto_coords", "point_mask": "point_coords", "bbox_mask": "bbox_coords", "mask": "mask_coords",
+                 "trimap": "trimap_coords"}
 
 
 class SDMatte:
@@ -27,20 +33,23 @@ class SDMatte:
         # the constants are embedded (config.py), so it is accepted and ignored.
         self.pretrained_model_name_or_path = pretrained_model_name_or_path
         unsupported = []
-        if aux_input != "trimap" or not use_aux_input:
-            unsupported.append(f"aux_input={aux_input!r}/use_aux_input={use_aux_input} (only the trimap prompt is implemented)")
+        if aux_input not in AUX_INPUT_DIT:
+            unsupported.append(f"aux_input={aux_input!r} (expected one of {sorted(AUX_INPUT_DIT)}; random choice per call is a training feature)")
+        if not use_aux_input:
+            unsupported.append("use_aux_input=False (the reference itself cannot run it: torch.cat([rgb_latent, None]), meta_arch.py:244)")
         if add_noise or num_inference_steps != 1:
             unsupported.append("add_noise / multi-step inference")
         if not use_encoder_hidden_states or not all(use_encoder_hidden_states_list):
             unsupported.append("text-encoder context (use_encoder_hidden_states=False)")
-        if not use_attention_mask or not all(use_attention_mask_list) or "trimap" not in attn_mask_aux_input:
-            unsupported.append("attention without the trimap key mask")
+        if not all(use_attention_mask_list):
+            unsupported.append("per-stage attention-mask lists other than [True]*3")
         if use_encoder_attention_mask:
             unsupported.append("encoder attention mask")
-        if not use_coor_input:
-            unsupported.append("use_coor_input=False")
         if unsupported:
             raise NotImplementedError("SDMatte (MI355X engine): unsupported configuration: " + "; ".join(unsupported))
+        self.use_coor_input = bool(use_coor_input)
+        # meta_arch.py:199-206: the aux image masks the self-attention keys only for the listed prompt types
+        self.use_attention_mask = bool(use_attention_mask) and aux_input in tuple(attn_mask_aux_input)
         self.aux_input = aux_input
         self.config = config or SDMatteConfig.full()
         self.stream_f32 = stream_f32
@@ -86,13 +95,23 @@ class SDMatte:
 
     @torch.no_grad()
     def forward(self, data):
-        """data: {"image" [B,3,S,S] in [-1,1], "trimap" [B,1,S,S] in [-1,1], "is_trans" int [B],
-        "trimap_coords" [B,4] (optional), "caption" ignored} -> alpha [B,1,S,S] fp32 (meta_arch.py:127-261)."""
+        """data: {"image" [B,3,S,S] in [-1,1], data[aux_input] [B,1,S,S] in [-1,1], "is_trans" int [B],
+        data[AUX_INPUT_DIT[aux_input]] coordinates ([B,4], or [B,N] for point prompts), "caption" ignored}
+        -> alpha [B,1,S,S] fp32 (meta_arch.py:127-261)."""
         if self.engine is None:
             raise RuntimeError("SDMatte: call .to('cuda') (and load_state_dict) before forward")
-        img, tri = data["image"], data["trimap"]
+        img, aux = data["image"], data[self.aux_input]
         it = data.get("is_trans")
         it = it.detach().cpu().numpy() if torch.is_tensor(it) else it
-        co = data.get("trimap_coords")
+        coor_name = AUX_INPUT_DIT[self.aux_input]
+        co = data.get(coor_name)
         co = co.detach().cpu().float().numpy() if torch.is_tensor(co) else co
-        return self.engine.forward(img, tri, is_trans=it, coords=co)
+        if coor_name == "point_coords":
+            if co is None:
+                raise KeyError("point prompt: data['point_coords'] is required (meta_arch.py:151)")
+            if not self.use_coor_input:
+                co = co * 0.0                                   # meta_arch.py:160,170-176: zero coordinates, same padding
+            return self.engine.forward(img, aux, is_trans=it, point_coords=co, use_attention_mask=self.use_attention_mask)
+        if not self.use_coor_input:
+            co = None                                           # meta_arch.py:188-197: default box [0,0,1,1]
+        return self.engine.forward(img, aux, is_trans=it, coords=co, use_attention_mask=self.use_attention_mask)

@@ -219,7 +219,13 @@ struct T {  // NHWC activation tensor living in the arena
 };
 
 static const int kMaxVariants = 8;
-struct Variant { int trans; float c[4]; };
+// conditioning of one image: opacity class + either 4 box coordinates (kind 0: bbox_embedding) or N point coordinates
+// (kind 1: point_embedding), meta_arch.py:147-197 / replace.py:446-457
+struct Variant {
+  int trans = 0, kind = 0;
+  std::vector<float> c;
+  bool operator==(const Variant& o) const { return trans == o.trans && kind == o.kind && c == o.c; }
+};
 
 struct ProfRec { std::string name, desc; double flops, bytes;
 #ifndef SDM_EMU
@@ -260,6 +266,7 @@ struct sdm_ctx {
   TfB u_midtf;
   std::vector<TembL> tembs;
   size_t h_time1w, h_time1b, h_time2w, h_time2b, h_bbox1w, h_bbox1b, h_bbox2w, h_bbox2b, h_auxw, h_auxb;
+  size_t h_point1w, h_point1b, h_point2w, h_point2b;
   std::vector<Variant> variants;
   int* d_bias_sel = nullptr;   // [max batch]
   int bias_sel_cap = 0;
@@ -478,6 +485,12 @@ static void build_model(sdm_ctx* e) {
   B.slot("unet.bbox_embedding.linear_1.bias", SLOT_HOST, -1, {te}); e->h_bbox1b = e->slots["unet.bbox_embedding.linear_1.bias"].host_off;
   B.slot("unet.bbox_embedding.linear_2.weight", SLOT_HOST, -1, {te, te}); e->h_bbox2w = e->slots["unet.bbox_embedding.linear_2.weight"].host_off;
   B.slot("unet.bbox_embedding.linear_2.bias", SLOT_HOST, -1, {te}); e->h_bbox2b = e->slots["unet.bbox_embedding.linear_2.bias"].host_off;
+  // point prompts (replace.py:198,446-450): TimestepEmbedding(point_embeddings_input_dim -> 1280), host-side like bbox_embedding
+  const int pd = c.point_embeddings_input_dim;
+  B.slot("unet.point_embedding.linear_1.weight", SLOT_HOST, -1, {te, pd}); e->h_point1w = e->slots["unet.point_embedding.linear_1.weight"].host_off;
+  B.slot("unet.point_embedding.linear_1.bias", SLOT_HOST, -1, {te}); e->h_point1b = e->slots["unet.point_embedding.linear_1.bias"].host_off;
+  B.slot("unet.point_embedding.linear_2.weight", SLOT_HOST, -1, {te, te}); e->h_point2w = e->slots["unet.point_embedding.linear_2.weight"].host_off;
+  B.slot("unet.point_embedding.linear_2.bias", SLOT_HOST, -1, {te}); e->h_point2b = e->slots["unet.point_embedding.linear_2.bias"].host_off;
   e->u_down_res.resize(4); e->u_down_tf.resize(4);
   cprev = uc[0];
   for (int i = 0; i < 4; ++i) {
@@ -997,6 +1010,15 @@ static void sincos_embed(float t, int dim, float* out) {  // get_timestep_embedd
     out[i] = cosf(a);
     out[half + i] = sinf(a);
   }
+  if (dim & 1) out[dim - 1] = 0.0f;                       // odd dim: diffusers pads one zero column
+}
+// meta_arch.py:153-162: N point coordinates are zero-padded to the first i >= N that divides the point-embedding input
+// dim P (1680 in the reference), each padded value is embedded with P / i channels.  Returns 0 if no such i < P exists
+// (the reference's loop would fall through with unbound variables).
+static int point_pad_len(int N, int P) {
+  for (int i = N; i < P; ++i)
+    if (i > 0 && P % i == 0) return i;
+  return 0;
 }
 static void host_linear(const float* W, const float* b, const float* x, int O, int I, float* y) {
   for (int o = 0; o < O; ++o) {
@@ -1018,10 +1040,19 @@ static int compute_variant_tables(sdm_ctx* e, int vidx) {
   host_linear(H + e->h_time1w, H + e->h_time1b, tp.data(), te, c0, t1.data());
   for (auto& x : t1) x = host_silu(x);
   host_linear(H + e->h_time2w, H + e->h_time2b, t1.data(), te, te, op.data());
-  for (int k = 0; k < 4; ++k) sincos_embed(v.c[k], bd / 4, ce.data() + k * (bd / 4));
-  host_linear(H + e->h_bbox1w, H + e->h_bbox1b, ce.data(), te, bd, b1.data());
-  for (auto& x : b1) x = host_silu(x);
-  host_linear(H + e->h_bbox2w, H + e->h_bbox2b, b1.data(), te, te, aug.data());
+  if (v.kind == 0) {          // box prompt: 4 coordinates x (bd/4) channels -> bbox_embedding (meta_arch.py:178-187, replace.py:451-455)
+    for (int k = 0; k < 4; ++k) sincos_embed(v.c[k], bd / 4, ce.data() + k * (bd / 4));
+    host_linear(H + e->h_bbox1w, H + e->h_bbox1b, ce.data(), te, bd, b1.data());
+    for (auto& x : b1) x = host_silu(x);
+    host_linear(H + e->h_bbox2w, H + e->h_bbox2b, b1.data(), te, te, aug.data());
+  } else {                    // point prompt: padded coordinates x (P/i) channels -> point_embedding (meta_arch.py:153-176, replace.py:446-450)
+    const int P = c.point_embeddings_input_dim, npad = point_pad_len((int)v.c.size(), P), ch = P / npad;
+    std::vector<float> pe((size_t)P, 0.0f);
+    for (int k = 0; k < npad; ++k) sincos_embed(k < (int)v.c.size() ? v.c[k] : 0.0f, ch, pe.data() + (size_t)k * ch);
+    host_linear(H + e->h_point1w, H + e->h_point1b, pe.data(), te, P, b1.data());
+    for (auto& x : b1) x = host_silu(x);
+    host_linear(H + e->h_point2w, H + e->h_point2b, b1.data(), te, te, aug.data());
+  }
   for (int i = 0; i < te; ++i) se[i] = host_silu(op[i] + aug[i]);
   std::vector<float> row;
   for (auto& t : e->tembs) {
@@ -1034,17 +1065,29 @@ static int compute_variant_tables(sdm_ctx* e, int vidx) {
   return 0;
 }
 
-static int prepare_variants(sdm_ctx* e, int B, const int32_t* is_trans, const float* coords) {
+static int prepare_variants(sdm_ctx* e, int B, const int32_t* is_trans, const float* cond, int cond_dim, int cond_kind) {
   std::vector<int> sel(B);
   std::vector<Variant> want(B);
+  if (cond_kind == 1) {
+    if (!cond || cond_dim <= 0 || point_pad_len(cond_dim, e->cfg.point_embeddings_input_dim) == 0)
+      SDM_FAIL(e, SDM_ERR_INVALID, "point prompt: %d coordinates cannot be padded to a divisor of %d", cond_dim, e->cfg.point_embeddings_input_dim);
+  } else if (cond && cond_dim != 4) {
+    SDM_FAIL(e, SDM_ERR_INVALID, "box prompt: expected 4 coordinates per image, got %d", cond_dim);
+  }
   for (int b = 0; b < B; ++b) {
     want[b].trans = 1 - (is_trans ? (int)is_trans[b] : 0);        // meta_arch.py:237-238
-    const float def[4] = {0.f, 0.f, 1.f, 1.f};                    // sdmatte_nodes.py:353
-    for (int k = 0; k < 4; ++k) want[b].c[k] = coords ? coords[b * 4 + k] : def[k];
+    want[b].kind = cond_kind;
+    if (cond_kind == 1) {
+      want[b].c.assign(cond + (size_t)b * cond_dim, cond + (size_t)(b + 1) * cond_dim);
+    } else {
+      const float def[4] = {0.f, 0.f, 1.f, 1.f};                  // sdmatte_nodes.py:353 / meta_arch.py:189-190
+      want[b].c.assign(4, 0.0f);
+      for (int k = 0; k < 4; ++k) want[b].c[k] = cond ? cond[b * 4 + k] : def[k];
+    }
   }
   auto find = [&](const Variant& v) {
     for (size_t i = 0; i < e->variants.size(); ++i)
-      if (e->variants[i].trans == v.trans && !memcmp(e->variants[i].c, v.c, sizeof(v.c))) return (int)i;
+      if (e->variants[i] == v) return (int)i;
     return -1;
   };
   for (int attempt = 0; attempt < 2; ++attempt) {
@@ -1060,7 +1103,7 @@ static int prepare_variants(sdm_ctx* e, int B, const int32_t* is_trans, const fl
       sel[b] = f;
     }
     if (!overflow) break;
-    if (attempt == 1) SDM_FAIL(e, SDM_ERR_INVALID, "more than %d distinct (is_trans, coords) combinations in one batch", kMaxVariants);
+    if (attempt == 1) SDM_FAIL(e, SDM_ERR_INVALID, "more than %d distinct (is_trans, coordinates) combinations in one batch", kMaxVariants);
     e->variants.clear();   // cache full of stale combinations: start over for this batch
   }
   if (B > e->bias_sel_cap) {
@@ -1158,7 +1201,7 @@ static int unet_forward(sdm_ctx* e, const T& uin, float* const* bias_lvl, int* c
   return 0;
 }
 
-static int run_model(sdm_ctx* e, const T& x16, const T& plane, int B, int S, T* alpha) {
+static int run_model(sdm_ctx* e, const T& x16, const T& plane, int B, int S, bool use_mask, T* alpha) {
   const sdm_config& c = e->cfg;
   const int l = S / 8;
   // attention key bias at the 4 U-Net levels (meta_arch.py:200-204, replace.py:401-403,56-63)
@@ -1171,12 +1214,14 @@ static int run_model(sdm_ctx* e, const T& x16, const T& plane, int B, int S, T* 
     tilebuf[k] = talloc(e, B, 1, 1, nt + 1, 1);
     bias_lvl[k] = (float*)biasbuf[k].p;
     tiles_lvl[k] = (int*)tilebuf[k].p;
-    if (!e->dry) {
+    if (!e->dry && use_mask) {
       SDM_LAUNCH(mask_bias_kernel, dim3(sdm_cdiv(B * lk * lk, 256)), dim3(256), 0, e->stream, (const float*)plane.p, bias_lvl[k], B, S, k,
                  c.attn_mask_value, SDM_LOG2E);
       SDM_LAUNCH(attn_active_tiles_kernel, dim3(B), dim3(256), 0, e->stream, (const float*)bias_lvl[k], lk * lk, nt, tiles_lvl[k], nt + 1,
                  SDM_ATTN_SKIP_MARGIN);
     }
+    // prompt types outside attn_mask_aux_input run the self-attention without a key mask (meta_arch.py:199-206)
+    if (!use_mask) { bias_lvl[k] = nullptr; tiles_lvl[k] = nullptr; }
   }
   // VAE encode of rgb and trimap as one batch (meta_arch.py:139-145, 209-212)
   T moments;
@@ -1224,7 +1269,7 @@ static int ensure_buf(sdm_ctx* e, void** p, size_t* cap, size_t need) {
 
 // mode 0: core API (NCHW preprocessed, S x S); mode 1: node API (BHWC image + BHW trimap at H x W)
 static int forward_impl(sdm_ctx* e, int mode, const float* image, const float* trimap, int B, int H, int W, int S, const int32_t* is_trans,
-                        const float* coords, float* out, int ptr_kind, void* stream_arg) {
+                        const float* cond, int cond_dim, int cond_kind, bool use_mask, float* out, int ptr_kind, void* stream_arg) {
   if (!e->finalized) SDM_FAIL(e, SDM_ERR_STATE, "weights not finalised: call sdm_load_tensor(...) and sdm_finalize_weights first");
   if (B <= 0 || S <= 0 || S % 64) SDM_FAIL(e, SDM_ERR_INVALID, "inference size must be a positive multiple of 64 (got %d)", S);
   if (mode == 1 && (H <= 0 || W <= 0)) SDM_FAIL(e, SDM_ERR_INVALID, "bad image size %dx%d", H, W);
@@ -1240,7 +1285,7 @@ static int forward_impl(sdm_ctx* e, int mode, const float* image, const float* t
     SDM_CHECK_DEV(e, dev_memcpy_h2d((unsigned char*)e->io_in + in_img, trimap, in_tri, e->stream));
     d_img = (const float*)e->io_in; d_tri = (const float*)((unsigned char*)e->io_in + in_img); d_out = (float*)e->io_out;
   }
-  TRY(prepare_variants(e, B, is_trans, coords));
+  TRY(prepare_variants(e, B, is_trans, cond, cond_dim, cond_kind));
   for (int pass = 0; pass < 2; ++pass) {
     e->dry = (pass == 0);
     arena_reset(e);
@@ -1268,7 +1313,7 @@ static int forward_impl(sdm_ctx* e, int mode, const float* image, const float* t
       }
     }
     T alpha;
-    int rc = run_model(e, x16, plane, B, S, &alpha);
+    int rc = run_model(e, x16, plane, B, S, use_mask, &alpha);
     if (rc) { e->dry = false; return rc; }
     if (!e->dry) {
       if (mode == 0) {
@@ -1324,7 +1369,7 @@ void sdm_default_config(sdm_config* c) {
   for (int i = 0; i < 4; ++i) { c->vae_channels[i] = vc[i]; c->unet_channels[i] = uc[i]; c->unet_heads[i] = uh[i]; }
   c->vae_layers_per_block = 2; c->unet_layers_per_block = 2;
   c->cross_attention_dim = 1024; c->unet_in_channels = 8; c->unet_out_channels = 4;
-  c->bbox_embeddings_input_dim = 1280; c->groups = 32;
+  c->bbox_embeddings_input_dim = 1280; c->point_embeddings_input_dim = 1680; c->groups = 32;
   c->vae_eps = 1e-6f; c->unet_res_eps = 1e-5f; c->unet_tf_gn_eps = 1e-6f; c->unet_ln_eps = 1e-5f;
   c->vae_scaling_factor = 0.18215f; c->attn_mask_value = -10000.0f;
   c->stream_f32 = 1;
@@ -1344,6 +1389,7 @@ int sdm_create(sdm_ctx** out, int device_id, const sdm_config* cfg) {
 #endif
   sdm_ctx* e = new sdm_ctx();
   if (cfg) e->cfg = *cfg; else sdm_default_config(&e->cfg);
+  if (e->cfg.point_embeddings_input_dim <= 0) e->cfg.point_embeddings_input_dim = 1680;
   e->device = device_id;
   const sdm_config& c = e->cfg;
   for (int i = 0; i < 4; ++i) {
@@ -1562,14 +1608,21 @@ int sdm_import_host_blob(sdm_ctx* e, const void* src) {
 int sdm_forward(sdm_ctx* e, const float* image, const float* trimap, int B, int S, const int32_t* is_trans, const float* coords, float* alpha,
                 int ptr_kind, void* stream) {
   if (!e || !image || !trimap || !alpha) return SDM_ERR_INVALID;
-  return forward_impl(e, 0, image, trimap, B, S, S, S, is_trans, coords, alpha, ptr_kind, stream);
+  return forward_impl(e, 0, image, trimap, B, S, S, S, is_trans, coords, 4, 0, true, alpha, ptr_kind, stream);
+}
+
+int sdm_forward_ex(sdm_ctx* e, const float* image, const float* aux, int B, int S, const int32_t* is_trans, const float* cond, int cond_dim,
+                   int cond_kind, int use_attention_mask, float* alpha, int ptr_kind, void* stream) {
+  if (!e || !image || !aux || !alpha) return SDM_ERR_INVALID;
+  if (cond_kind != SDM_COND_BOX && cond_kind != SDM_COND_POINTS) SDM_FAIL(e, SDM_ERR_INVALID, "unknown conditioning kind %d", cond_kind);
+  return forward_impl(e, 0, image, aux, B, S, S, S, is_trans, cond, cond_dim, cond_kind, use_attention_mask != 0, alpha, ptr_kind, stream);
 }
 
 int sdm_apply_matte(sdm_ctx* e, const float* image, const float* trimap, int B, int H, int W, int S, int is_transparent, float* alpha,
                     int ptr_kind, void* stream) {
   if (!e || !image || !trimap || !alpha) return SDM_ERR_INVALID;
   std::vector<int32_t> it((size_t)std::max(B, 1), is_transparent ? 1 : 0);
-  return forward_impl(e, 1, image, trimap, B, H, W, S, it.data(), nullptr, alpha, ptr_kind, stream);
+  return forward_impl(e, 1, image, trimap, B, H, W, S, it.data(), nullptr, 4, 0, true, alpha, ptr_kind, stream);
 }
 
 int sdm_synchronize(sdm_ctx* e) {

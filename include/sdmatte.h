@@ -54,7 +54,8 @@ typedef struct sdm_config {
   float vae_scaling_factor;
   float attn_mask_value;
   int32_t stream_f32;      /* 1: residual stream tensors kept in fp32 (default), 0: fp16 */
-  int32_t reserved[7];
+  int32_t point_embeddings_input_dim;   /* 1680 (meta_arch.py:107-108); 0 = default */
+  int32_t reserved[6];
 } sdm_config;
 
 /* Fill `cfg` with the SD-2.1-base / SDMatte constants. */
@@ -97,6 +98,17 @@ int sdm_import_host_blob(sdm_ctx* ctx, const void* host_src);
  * is_trans / coords are always HOST pointers (tiny).  `stream` is a hipStream_t (NULL = engine stream). */
 int sdm_forward(sdm_ctx* ctx, const float* image_b3ss, const float* trimap_b1ss, int B, int S, const int32_t* is_trans,
                 const float* coords_b4, float* alpha_b1ss, int ptr_kind, void* stream);
+
+/* The other prompt types of the reference core (meta_arch.py:22-28,131-206): `aux` is data[aux_input]
+ * ("trimap", "bbox_mask", "mask", "auto_mask" or "point_mask": [B,1,S,S] in [-1,1], encoded and used exactly like the trimap),
+ * `cond` the matching coordinates: SDM_COND_BOX = data["*_coords"] [B,4] -> bbox_embedding (NULL -> [0,0,1,1], which is also
+ * what use_coor_input=False feeds); SDM_COND_POINTS = data["point_coords"] [B,cond_dim] -> zero-padded to the first divisor of
+ * point_embeddings_input_dim, sinusoid-embedded and sent through point_embedding (pass zeros for use_coor_input=False).
+ * use_attention_mask = 0 runs the self-attention without the aux key mask (aux_input not in attn_mask_aux_input).
+ * sdm_forward(...) == sdm_forward_ex(..., coords, 4, SDM_COND_BOX, 1, ...). */
+enum sdm_cond_kind { SDM_COND_BOX = 0, SDM_COND_POINTS = 1 };
+int sdm_forward_ex(sdm_ctx* ctx, const float* image_b3ss, const float* aux_b1ss, int B, int S, const int32_t* is_trans,
+                   const float* cond, int cond_dim, int cond_kind, int use_attention_mask, float* alpha_b1ss, int ptr_kind, void* stream);
 
 /* Node-level call.  Replaces the device part of SDMatteApply.apply_matte (sdmatte_nodes.py:339-363):
  *   image fp32 [B,H,W,3] in [0,1], trimap fp32 [B,H,W] in [0,1]  ->  antialiased resize to SxS, normalise,

@@ -233,18 +233,19 @@ def vae_decoder(w, cfg: dict, z: Tensor) -> Tensor:
 # ----------------------------------------------------------------------------------------------
 # U-Net (CustomUNet.forward, replace.py:379-549)
 # ----------------------------------------------------------------------------------------------
-def unet_embedding(w, cfg: dict, trans: Tensor, coords_emb: Tensor) -> Tensor:
-    """replace.py:419-459: emb = time_embedding(time_proj(trans)) + bbox_embedding(coords)."""
+def unet_embedding(w, cfg: dict, trans: Tensor, coords_emb: Tensor, cond_key: str = "bbox_mask_coords") -> Tensor:
+    """replace.py:419-459: emb = time_embedding(time_proj(trans)) + bbox_embedding(coords) (or point_embedding for
+    added_cond_kwargs["point_coords"], replace.py:446-450)."""
     B = trans.shape[0]
     op = get_timestep_embedding(trans, cfg["unet_channels"][0], True, 0.0)       # replace.py:432
     op = timestep_embedding_mlp(w, "unet.time_embedding", op)                     # replace.py:435
     ce = coords_emb.reshape(B, -1)                                                # replace.py:453
-    aug = timestep_embedding_mlp(w, "unet.bbox_embedding", ce)                    # replace.py:455
+    aug = timestep_embedding_mlp(w, "unet.point_embedding" if cond_key == "point_coords" else "unet.bbox_embedding", ce)  # :450,455
     return op + aug                                                               # replace.py:459
 
 
 def unet_forward(w, cfg: dict, sample: Tensor, trans: Tensor, ehs: Tensor, coords_emb: Tensor,
-                 attention_mask: Optional[Tensor], taps: Optional[dict] = None) -> Tensor:
+                 attention_mask: Optional[Tensor], taps: Optional[dict] = None, cond_key: str = "bbox_mask_coords") -> Tensor:
     uc = cfg["unet_channels"]
     heads = cfg["unet_heads"]
     g = cfg["unet_groups"]
@@ -254,7 +255,7 @@ def unet_forward(w, cfg: dict, sample: Tensor, trans: Tensor, ehs: Tensor, coord
     if attention_mask is not None:                                                # replace.py:401-403
         bias = (1 - attention_mask.to(sample.dtype)) * cfg["attn_mask_value"]
         bias = bias.unsqueeze(1)
-    emb = unet_embedding(w, cfg, trans, coords_emb)
+    emb = unet_embedding(w, cfg, trans, coords_emb, cond_key)
     h = F.conv2d(sample, w["unet.conv_in.weight"], w["unet.conv_in.bias"], padding=1)   # :462
     if taps is not None:
         taps["unet.conv_in"] = h
@@ -296,19 +297,47 @@ def unet_forward(w, cfg: dict, sample: Tensor, trans: Tensor, ehs: Tensor, coord
 
 
 # ----------------------------------------------------------------------------------------------
-# SDMatte.forward (meta_arch.py:127-261), trimap path as configured by sdmatte_nodes.py:286-296
+# SDMatte.forward (meta_arch.py:127-261).  Defaults = the trimap path configured by sdmatte_nodes.py:286-296;
+# the keyword arguments restate the constructor options that select the other prompt types (meta_arch.py:31-77).
 # ----------------------------------------------------------------------------------------------
+AUX_INPUT_DIT = {"auto_mask": "auto_coords", "point_mask": "point_coords", "bbox_mask": "bbox_coords", "mask": "mask_coords",
+                 "trimap": "trimap_coords"}                                       # meta_arch.py:22-28
+
+
+def point_coords_embedding(coor: Tensor, P: int, use_coor_input: bool = True) -> Tensor:
+    """meta_arch.py:152-176: pad the N point coordinates with zeros to the first i in [N, P) that divides P (P = 1680 in the
+    reference, = point_embeddings_input_dim), embed every padded value with P // i channels."""
+    B, N = coor.shape
+    for i in range(N, P):
+        if P % i == 0:
+            coor = torch.cat([coor, torch.zeros(B, i - N, dtype=coor.dtype)], dim=1)
+            if not use_coor_input:
+                coor = torch.zeros_like(coor)                                     # :160,170-176
+            return get_timestep_embedding(coor.flatten(), P // i, True, 0.0)
+    raise ValueError(f"point prompt: {N} coordinates cannot be padded to a divisor of {P}")
+
+
 @torch.no_grad()
-def sdmatte_forward(w: Dict[str, Tensor], cfg: dict, data: dict, taps: Optional[dict] = None) -> Tensor:
+def sdmatte_forward(w: Dict[str, Tensor], cfg: dict, data: dict, taps: Optional[dict] = None, aux_input: str = "trimap",
+                    use_coor_input: bool = True, use_attention_mask: bool = True,
+                    attn_mask_aux_input=("point_mask", "bbox_mask", "mask", "trimap")) -> Tensor:
     rgb = data["image"].float()                                                   # :128
     B = rgb.shape[0]
-    aux = data["trimap"].float().repeat(1, 3, 1, 1)                               # :140-141
+    aux = data[aux_input].float().repeat(1, 3, 1, 1)                              # :140-141
     aux_latent = vae_encode_latent(w, cfg, aux)                                   # :142-145
-    coor = data["trimap_coords"].float()                                          # :151
-    coor = get_timestep_embedding(coor.flatten(), cfg["bbox_embeddings_input_dim"] // 4, True, 0.0)  # :181-186
-    m = (data["trimap"].float() + 1) / 2                                          # :201-202
-    m = F.interpolate(m, scale_factor=1 / 8, mode="nearest")                      # :203
-    attention_mask = m.flatten(start_dim=1)                                       # :204
+    coor_name = AUX_INPUT_DIT[aux_input]                                          # :150
+    cond_key = "bbox_mask_coords"
+    if coor_name == "point_coords":                                               # :152-176
+        coor = point_coords_embedding(data[coor_name].float(), cfg["point_embeddings_input_dim"], use_coor_input)
+        cond_key = "point_coords"
+    else:                                                                         # :177-197
+        coor = data[coor_name].float() if use_coor_input else torch.tensor([[0.0, 0.0, 1.0, 1.0]] * B)
+        coor = get_timestep_embedding(coor.flatten(), cfg["bbox_embeddings_input_dim"] // 4, True, 0.0)  # :181-186
+    attention_mask = None
+    if use_attention_mask and aux_input in attn_mask_aux_input:                   # :200
+        m = (data[aux_input].float() + 1) / 2                                     # :201-202
+        m = F.interpolate(m, scale_factor=1 / 8, mode="nearest")                  # :203
+        attention_mask = m.flatten(start_dim=1)                                   # :204
     rgb_latent = vae_encode_latent(w, cfg, rgb)                                   # :209-212
     ehs = F.conv2d(aux_latent, w["unet.aux_conv_in.weight"], w["unet.aux_conv_in.bias"], padding=1)  # :216
     ehs = ehs.view(B, cfg["cross_attention_dim"], -1).permute(0, 2, 1)            # :217-218
@@ -317,7 +346,7 @@ def sdmatte_forward(w: Dict[str, Tensor], cfg: dict, data: dict, taps: Optional[
     if taps is not None:
         taps["aux_latent"], taps["rgb_latent"], taps["ehs"] = aux_latent, rgb_latent, ehs
         taps["attention_mask"] = attention_mask
-    lat = unet_forward(w, cfg, unet_in, trans, ehs, coor, attention_mask, taps)   # :245-253
+    lat = unet_forward(w, cfg, unet_in, trans, ehs, coor, attention_mask, taps, cond_key)   # :245-253
     if taps is not None:
         taps["unet_out"] = lat
     lat = lat / cfg["vae_scaling_factor"]                                         # :254

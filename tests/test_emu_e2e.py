@@ -28,7 +28,7 @@ def test_emu_full_forward_matches_oracle(pkg):
     w = synthetic_state_dict(cfg, 0)
     eng = _emu_engine(cfg)
     missing, ignored = eng.load_state_dict(w)
-    assert missing == [] and ignored == 4          # point_embedding.* is unused on the trimap path
+    assert missing == [] and ignored == 0          # every tensor of the checkpoint schema has a consumer (point_embedding.* too)
     img, tri = synthetic_inputs(1, 64, 64)
     data = O.preprocess(img, tri, 64, False)
     ref = O.sdmatte_forward(w, cfg.as_dict(), data)
@@ -136,3 +136,64 @@ def test_data_parallel_two_ranks_gloo(pkg):
     assert sorted(i for p in plan for v in p.values() for i in v) == list(range(24))
     loads = [sum(parallel.FLOPS_PER_IMAGE[s] * len(v) for s, v in p.items()) for p in plan]
     assert max(loads) / min(loads) < 1.35
+
+
+def test_emu_other_prompt_types_match_oracle(pkg):
+    """The other prompt types of the reference core (meta_arch.py:22-28,131-206) through the core API on
+    the emulator: box prompt with per-image coordinates, mask prompt without the key mask, point prompts (point_embedding,
+    padded coordinate count incl. an odd channel count), use_coor_input=False."""
+    import dataclasses
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    from comfyui_sdmatte_amd.core import SDMatte
+    from comfyui_sdmatte_amd.weights import synthetic_state_dict
+    from comfyui_sdmatte_amd.synth import synthetic_inputs
+    from oracle import sdmatte_oracle as O
+
+    def run(cfg, aux_input, data, **kw):
+        w = synthetic_state_dict(cfg, 3)
+        m = SDMatte(None, use_aux_input=True, aux_input=aux_input, load_weight=False, config=cfg, **kw)
+        m.load_state_dict(w, strict=False)
+        m.engine = _emu_engine(cfg)
+        m._upload()
+        out = m(data)
+        okw = {k: v for k, v in kw.items() if k in ("use_coor_input", "use_attention_mask", "attn_mask_aux_input")}
+        ref = O.sdmatte_forward(w, cfg.as_dict(), data, aux_input=aux_input, **okw)
+        d = (out - ref).abs()
+        m.engine.close()
+        assert d.max().item() < 1e-2 and d.mean().item() < 1.5e-3, (aux_input, kw, d.max().item(), d.mean().item())
+        return out
+
+    cfg = SDMatteConfig.tiny()
+    img, tri = synthetic_inputs(2, 64, 64, seed=5)
+    base = O.preprocess(img, tri, 64, False)
+    g = torch.Generator().manual_seed(9)
+    # box prompt: two different boxes in one batch (two conditioning variants), key mask from the box mask
+    data = {"image": base["image"], "is_trans": torch.tensor([0, 1]), "bbox_mask": base["trimap"],
+            "bbox_coords": torch.tensor([[0.1, 0.2, 0.7, 0.9], [0.0, 0.3, 0.5, 1.0]])}
+    a = run(cfg, "bbox_mask", data, attn_mask_aux_input=("point_mask", "bbox_mask", "mask"))
+    # the same inputs with the default box (use_coor_input=False) must differ: the coordinates really reach the network
+    b = run(cfg, "bbox_mask", data, attn_mask_aux_input=("point_mask", "bbox_mask", "mask"), use_coor_input=False)
+    assert (a - b).abs().max().item() > 1e-4
+    # mask prompt outside attn_mask_aux_input: no key mask
+    data = {"image": base["image"], "is_trans": torch.tensor([0, 0]), "mask": base["trimap"],
+            "mask_coords": torch.tensor([[0.0, 0.0, 1.0, 1.0]] * 2)}
+    run(cfg, "mask", data, attn_mask_aux_input=("point_mask", "bbox_mask"))
+    # point prompts: 5 coordinates -> padded to 8 x 8 channels (P = 64); zeroed coordinates with use_coor_input=False
+    data = {"image": base["image"], "is_trans": torch.tensor([1, 0]), "point_mask": base["trimap"],
+            "point_coords": torch.rand(2, 5, generator=g)}
+    c = run(cfg, "point_mask", data, attn_mask_aux_input=("point_mask", "bbox_mask", "mask"))
+    d0 = run(cfg, "point_mask", data, attn_mask_aux_input=("point_mask", "bbox_mask", "mask"), use_coor_input=False)
+    assert (c - d0).abs().max().item() > 1e-4
+    # P = 60: 11 coordinates -> padded to 12 x 5 channels (odd channel count: one zero column per coordinate)
+    cfg60 = dataclasses.replace(cfg, point_embeddings_input_dim=60)
+    data["point_coords"] = torch.rand(2, 11, generator=g)
+    run(cfg60, "point_mask", data, attn_mask_aux_input=("point_mask", "bbox_mask", "mask"))
+    # coordinates that cannot be padded to a divisor (N >= P) fail loudly, as the reference's loop would
+    data["point_coords"] = torch.rand(2, 64, generator=g)
+    with pytest.raises(RuntimeError):
+        run(cfg, "point_mask", data)
+    # unsupported constructor options still raise
+    with pytest.raises(NotImplementedError):
+        SDMatte(None, use_aux_input=True, aux_input=None, load_weight=False, config=cfg)
+    with pytest.raises(NotImplementedError):
+        SDMatte(None, use_aux_input=True, aux_input="trimap", add_noise=True, load_weight=False, config=cfg)

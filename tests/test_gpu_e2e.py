@@ -234,3 +234,38 @@ def test_e2e_full_model_1024_properties(pkg, monkeypatch):
     dense = eng.apply_matte(img, tri, S, False).cpu()
     assert torch.equal(dense, a)                                   # exact sparsity: same bits as the dense key walk
     eng.close()
+
+
+def test_e2e_other_prompt_types(pkg):
+    """Box / mask / point prompts of the reference core (meta_arch.py:22-28,131-206) through core.SDMatte on the GPU vs the oracle."""
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    from comfyui_sdmatte_amd.core import SDMatte
+    from comfyui_sdmatte_amd.weights import synthetic_state_dict
+    from comfyui_sdmatte_amd.synth import synthetic_inputs
+    from oracle import sdmatte_oracle as O
+    cfg = SDMatteConfig.tiny()
+    w = synthetic_state_dict(cfg, 3)
+    img, tri = synthetic_inputs(2, 128, 128, seed=5)
+    base = O.preprocess(img, tri, 128, False)
+    g = torch.Generator().manual_seed(9)
+    cases = [
+        ("bbox_mask", {"bbox_mask": base["trimap"], "bbox_coords": torch.tensor([[0.1, 0.2, 0.7, 0.9], [0.0, 0.3, 0.5, 1.0]])},
+         dict(attn_mask_aux_input=("point_mask", "bbox_mask", "mask"))),
+        ("mask", {"mask": base["trimap"], "mask_coords": torch.tensor([[0.0, 0.0, 1.0, 1.0]] * 2)},
+         dict(attn_mask_aux_input=("point_mask", "bbox_mask"))),                                  # no key mask
+        ("point_mask", {"point_mask": base["trimap"], "point_coords": torch.rand(2, 5, generator=g)},
+         dict(attn_mask_aux_input=("point_mask", "bbox_mask", "mask"))),
+        ("point_mask", {"point_mask": base["trimap"], "point_coords": torch.rand(2, 5, generator=g)},
+         dict(attn_mask_aux_input=("point_mask", "bbox_mask", "mask"), use_coor_input=False)),
+    ]
+    for aux_input, extra, kw in cases:
+        data = {"image": base["image"], "is_trans": torch.tensor([0, 1]), **extra}
+        m = SDMatte(None, use_aux_input=True, aux_input=aux_input, load_weight=False, config=cfg, **kw)
+        m.load_state_dict(w, strict=False)
+        m.eval().to("cuda:0")
+        out = m({k: (v.cuda() if torch.is_tensor(v) and v.dim() == 4 else v) for k, v in data.items()}).cpu()
+        ref = O.sdmatte_forward(w, cfg.as_dict(), data, aux_input=aux_input, **kw)
+        d = (out - ref).abs()
+        print(f"\n[{aux_input} {kw}] max|d|={d.max():.3e} mean|d|={d.mean():.3e}")
+        assert d.max().item() <= 1e-2 and d.mean().item() <= 1.5e-3
+        m.engine.close()

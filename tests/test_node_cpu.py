@@ -57,7 +57,10 @@ def test_model_load_api_errors(pkg, tmp_path):
     f.write_bytes(b"x")
     assert N.download_model("SDMatte.safetensors", models_dir=str(tmp_path)) == str(f)
     with pytest.raises(NotImplementedError):
-        SDMatte(None, aux_input="bbox_mask", use_aux_input=True)
+        SDMatte(None, aux_input="bbox_mask", use_aux_input=True, add_noise=True)      # noise / multi-step inference: not built
+    with pytest.raises(NotImplementedError):
+        SDMatte(None, aux_input=None, use_aux_input=True)                             # random prompt choice is a training feature
+    SDMatte(None, aux_input="bbox_mask", use_aux_input=True, load_weight=False)       # the other prompt types construct fine
     m = SDMatte(None, aux_input="trimap", use_aux_input=True, attn_mask_aux_input=["trimap"], load_weight=False)
     with pytest.raises(RuntimeError):
         m.to("cpu")                      # no CPU path
