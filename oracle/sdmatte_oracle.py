@@ -18,6 +18,10 @@ PARITY STATUS: *partially pinned*.
     behaviour on top of stock torch primitives; the composition is anchored on
     the reference's own call sites (cited per function below) and on the exact reproduction of the
     SD-2.1 parameter counts by the key schema (tests/test_schema.py).  The reference has no tests.
+  * "parity unpinned" as well for the prompt-type routing of `SDMatte.forward` (bbox_mask / mask / auto_mask /
+    point_mask, point-coordinate padding, use_coor_input, attn_mask_aux_input): `meta_arch.py` cannot be imported
+    (hard-coded `.cuda()`, diffusers), so `sdmatte_forward(..., aux_input=...)` restates meta_arch.py:131-206 and
+    replace.py:446-457 line by line (cited in place) without a golden vector.
 
 The reference's `force_cpu=True` branch is the semantics restated here: fp32, no autocast, default
 (un-sliced) AttnProcessor (sdmatte_nodes.py:355-360, utils.py:46).
