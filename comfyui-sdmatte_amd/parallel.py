@@ -60,3 +60,46 @@ def bucket_requests(sizes, world: int):
         for s in p:
             p[s].sort()
     return plan
+
+
+def matte_stream(engine, images, trimaps, sizes, is_transparent: bool = False, micro_batch: int = 4, dst: int = 0, device=None):
+    """Mixed-resolution request stream (BASELINE config #5): request i = (images[i] [H,W,3], trimaps[i] [H,W], sizes[i]).
+    Every rank holds the request list; `bucket_requests` gives each rank whole same-size groups balanced by estimated FLOPs;
+    a rank runs its groups in micro-batches of equal (H, W) and the alphas travel to `dst` point to point (shapes are known
+    from the request list, so no size exchange and no padding).  Returns the list of alphas [H,W] in request order on `dst`,
+    None on the other ranks.  No collective besides these sends exists on the path."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    device = device if device is not None else torch.device("cuda", engine.device)
+    plan = bucket_requests(sizes, world)
+    mine = {}
+    for S, idxs in sorted(plan[rank].items()):
+        by_shape = {}
+        for i in idxs:
+            by_shape.setdefault(tuple(images[i].shape[:2]), []).append(i)
+        for _, ids in sorted(by_shape.items()):
+            for k in range(0, len(ids), micro_batch):
+                chunk = ids[k:k + micro_batch]
+                img = torch.stack([images[i] for i in chunk]).to(device)
+                tri = torch.stack([trimaps[i] for i in chunk]).to(device)
+                a = engine.apply_matte(img, tri, S, is_transparent)
+                for j, i in enumerate(chunk):
+                    mine[i] = a[j]
+    if world == 1:
+        return [mine[i] for i in range(len(sizes))]
+    order = lambda r: sorted(i for v in plan[r].values() for i in v)      # the same deterministic order on both ends
+    if rank != dst:
+        for i in order(rank):
+            dist.send(mine[i].contiguous(), dst)
+        return None
+    out = [None] * len(sizes)
+    for i, a in mine.items():
+        out[i] = a
+    for r in range(world):
+        if r == dst:
+            continue
+        for i in order(r):
+            buf = torch.empty(tuple(images[i].shape[:2]), dtype=torch.float32, device=device)
+            dist.recv(buf, r)
+            out[i] = buf
+    return out

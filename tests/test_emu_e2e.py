@@ -79,6 +79,13 @@ def test_emu_fused_groupnorm_path(pkg, monkeypatch):
     eng.close()
 
 
+def _stream_requests():
+    from comfyui_sdmatte_amd.synth import synthetic_inputs
+    i0, t0 = synthetic_inputs(2, 64, 64, seed=21)
+    i1, t1 = synthetic_inputs(1, 50, 70, seed=22)
+    return [(i0[0], t0[0], 64), (i1[0], t1[0], 128), (i0[1], t0[1], 64)]
+
+
 def _dp_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -101,8 +108,14 @@ def _dp_worker(rank, world, port, q):
     lo, hi = parallel.shard_range(2, world, rank)
     a = eng.apply_matte(img[lo:hi], tri[lo:hi], 64)
     outs = parallel.gather_alphas(a, 0)
+    # mixed-resolution request stream (BASELINE config #5 at toy scale): 3 requests, two inference sizes, two image shapes
+    reqs = _stream_requests()
+    res = parallel.matte_stream(eng, [r[0] for r in reqs], [r[1] for r in reqs], [r[2] for r in reqs], micro_batch=2, dst=0,
+                                device=torch.device("cpu"))
     if rank == 0:
-        q.put(torch.cat(outs, 0))
+        q.put((torch.cat(outs, 0), res))
+    else:
+        assert res is None
     dist.barrier()
     dist.destroy_process_group()
     eng.close()
@@ -120,15 +133,23 @@ def test_data_parallel_two_ranks_gloo(pkg):
     procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = q.get(timeout=600)
+    got, stream = q.get(timeout=900)
     for p in procs:
         p.join(timeout=600)
         assert p.exitcode == 0
     cfg = SDMatteConfig.tiny()
+    w = synthetic_state_dict(cfg, 0)
     img, tri = synthetic_inputs(2, 64, 64)
-    ref, _ = O.apply_matte(synthetic_state_dict(cfg, 0), cfg.as_dict(), img, tri, 64, mask_refine=False)
+    ref, _ = O.apply_matte(w, cfg.as_dict(), img, tri, 64, mask_refine=False)
     d = (got - ref).abs()
     assert got.shape == ref.shape and d.max().item() < 1e-2 and d.mean().item() < 1.5e-3
+    # the request stream: every alpha back on rank 0, in request order, at its own resolution
+    reqs = _stream_requests()
+    assert len(stream) == len(reqs)
+    for (im, tr, S), a in zip(reqs, stream):
+        r, _ = O.apply_matte(w, cfg.as_dict(), im[None], tr[None], S, mask_refine=False)
+        dd = (a - r[0]).abs()
+        assert a.shape == im.shape[:2] and dd.max().item() < 1e-2 and dd.mean().item() < 1.5e-3
     # partitioning helpers
     assert [parallel.shard_range(32, 8, r) for r in (0, 7)] == [(0, 4), (28, 32)]
     assert parallel.shard_range(5, 4, 3) == (5, 5)
