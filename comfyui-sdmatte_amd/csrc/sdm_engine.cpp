@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <string>
 #include <unordered_map>
@@ -51,17 +52,30 @@ static int dev_memcpy_d2d(void* d, const void* s, size_t n, void* st) { return (
 static int dev_memset(void* d, int v, size_t n, void* st) { return (int)hipMemsetAsync(d, v, n, (hipStream_t)st); }
 static int dev_sync(void* st) { return (int)hipStreamSynchronize((hipStream_t)st); }
 static const char* dev_errstr(int e) { return hipGetErrorString((hipError_t)e); }
+// Kernels with more than 48 KB of dynamic LDS need the attribute once PER DEVICE (one process may drive one engine per GPU,
+// INTEGRATION.md 3): a bit per device id, set with relaxed atomics (setting it twice is harmless).
 #define SDM_SET_SMEM(kernel, bytes)                                                                              \
   do {                                                                                                           \
-    static bool done_ = false;                                                                                   \
-    if (!done_ && (bytes) > 48 * 1024) {                                                                         \
-      (void)hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
-      done_ = true;                                                                                              \
+    if ((bytes) > 48 * 1024) {                                                                                   \
+      static std::atomic<unsigned long long> done_{0ull};                                                        \
+      int dev_ = 0;                                                                                              \
+      (void)hipGetDevice(&dev_);                                                                                 \
+      const unsigned long long bit_ = 1ull << (dev_ & 63);                                                       \
+      if (!(done_.load(std::memory_order_relaxed) & bit_)) {                                                     \
+        (void)hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+        done_.fetch_or(bit_, std::memory_order_relaxed);                                                         \
+      }                                                                                                          \
     }                                                                                                            \
   } while (0)
 #endif
 
 static inline int rup(int a, int b) { return ((a + b - 1) / b) * b; }
+// every entry point that touches the GPU selects the engine's device first: one process may own one engine per GPU
+#ifdef SDM_EMU
+static inline void dev_use(int) {}
+#else
+static inline void dev_use(int device) { (void)hipSetDevice(device); }
+#endif
 static inline size_t rupz(size_t a, size_t b) { return ((a + b - 1) / b) * b; }
 
 // ------------------------------------------------------------------------------------------------
@@ -1431,6 +1445,7 @@ int sdm_create(sdm_ctx** out, int device_id, const sdm_config* cfg) {
 }
 
 void sdm_destroy(sdm_ctx* e) {
+  if (e) dev_use(e->device);
   if (!e) return;
   dev_sync(e->stream);
   if (e->warena) dev_free(e->warena);
@@ -1458,6 +1473,7 @@ static float to_f32(const void* p, int dtype, size_t i) {
 }
 
 int sdm_load_tensor(sdm_ctx* e, const char* name, int dtype, int ndim, const int64_t* shape, const void* host_ptr) {
+  if (e) dev_use(e->device);
   if (!e || !name || !host_ptr) return SDM_ERR_INVALID;
   std::string key(name);
   // legacy VAE attention names
@@ -1554,6 +1570,7 @@ static int fold_cross_kv(sdm_ctx* e) {
 }
 
 int sdm_finalize_weights(sdm_ctx* e) {
+  if (e) dev_use(e->device);
   if (!e) return SDM_ERR_INVALID;
   { int rc = fold_cross_kv(e); if (rc) return rc; }
   e->missing.clear();
@@ -1578,12 +1595,14 @@ const char* sdm_missing_key(sdm_ctx* e, int64_t i) {
 
 int64_t sdm_weight_blob_bytes(sdm_ctx* e) { return e ? (int64_t)e->warena_bytes : 0; }
 int sdm_export_weight_blob(sdm_ctx* e, void* dst) {
+  if (e) dev_use(e->device);
   if (!e || !dst) return SDM_ERR_INVALID;
   SDM_CHECK_DEV(e, dev_memcpy_d2d(dst, e->warena, e->warena_bytes, e->stream));
   SDM_CHECK_DEV(e, dev_sync(e->stream));
   return SDM_OK;
 }
 int sdm_import_weight_blob(sdm_ctx* e, const void* src) {
+  if (e) dev_use(e->device);
   if (!e || !src) return SDM_ERR_INVALID;
   SDM_CHECK_DEV(e, dev_memcpy_d2d(e->warena, src, e->warena_bytes, e->stream));
   SDM_CHECK_DEV(e, dev_sync(e->stream));
@@ -1607,12 +1626,14 @@ int sdm_import_host_blob(sdm_ctx* e, const void* src) {
 
 int sdm_forward(sdm_ctx* e, const float* image, const float* trimap, int B, int S, const int32_t* is_trans, const float* coords, float* alpha,
                 int ptr_kind, void* stream) {
+  if (e) dev_use(e->device);
   if (!e || !image || !trimap || !alpha) return SDM_ERR_INVALID;
   return forward_impl(e, 0, image, trimap, B, S, S, S, is_trans, coords, 4, 0, true, alpha, ptr_kind, stream);
 }
 
 int sdm_forward_ex(sdm_ctx* e, const float* image, const float* aux, int B, int S, const int32_t* is_trans, const float* cond, int cond_dim,
                    int cond_kind, int use_attention_mask, float* alpha, int ptr_kind, void* stream) {
+  if (e) dev_use(e->device);
   if (!e || !image || !aux || !alpha) return SDM_ERR_INVALID;
   if (cond_kind != SDM_COND_BOX && cond_kind != SDM_COND_POINTS) SDM_FAIL(e, SDM_ERR_INVALID, "unknown conditioning kind %d", cond_kind);
   return forward_impl(e, 0, image, aux, B, S, S, S, is_trans, cond, cond_dim, cond_kind, use_attention_mask != 0, alpha, ptr_kind, stream);
@@ -1620,12 +1641,14 @@ int sdm_forward_ex(sdm_ctx* e, const float* image, const float* aux, int B, int 
 
 int sdm_apply_matte(sdm_ctx* e, const float* image, const float* trimap, int B, int H, int W, int S, int is_transparent, float* alpha,
                     int ptr_kind, void* stream) {
+  if (e) dev_use(e->device);
   if (!e || !image || !trimap || !alpha) return SDM_ERR_INVALID;
   std::vector<int32_t> it((size_t)std::max(B, 1), is_transparent ? 1 : 0);
   return forward_impl(e, 1, image, trimap, B, H, W, S, it.data(), nullptr, 4, 0, true, alpha, ptr_kind, stream);
 }
 
 int sdm_synchronize(sdm_ctx* e) {
+  if (e) dev_use(e->device);
   if (!e) return SDM_ERR_INVALID;
   SDM_CHECK_DEV(e, dev_sync(e->stream));
 #ifndef SDM_EMU
@@ -1674,6 +1697,7 @@ int sdm_conv_num_cfgs(int ntaps, int stride) { return conv_num_cfgs(ntaps, strid
 int sdm_op_conv(sdm_ctx* e, const void* in0, const void* in1, int C0, int C1, int in_f32, int N, int Hin, int Win, int up, int stride,
                 int pad_mode, int ntaps, const float* w, const float* bias, int O, void* out, int out_f32, const void* res, int res_f32,
                 int geglu, float out_scale, int tile_cfg) {
+  if (e) dev_use(e->device);
   if (!e || !in0 || !w || !out) return SDM_ERR_INVALID;
   if (C0 % 16 || C1 % 16) SDM_FAIL(e, SDM_ERR_INVALID, "sdm_op_conv: channel counts must be multiples of 16");
   ConvL L;
@@ -1708,6 +1732,7 @@ int sdm_op_conv(sdm_ctx* e, const void* in0, const void* in1, int C0, int C1, in
 /* Bench/ablation helper (not used by the engine): times `iters` launches of one conv with HIP events; returns ms per launch
  * (negative on error).  ablate bits: see ConvParams::ablate. */
 float sdm_bench_conv(sdm_ctx* e, int N, int H, int W, int Cin, int Cout, int ntaps, int stride, int in_f32, int tile_cfg, int ablate, int iters) {
+  if (e) dev_use(e->device);
   if (!e) return -1.f;
 #ifdef SDM_EMU
   return -1.f;
@@ -1750,6 +1775,7 @@ float sdm_bench_conv(sdm_ctx* e, int N, int H, int W, int Cin, int Cout, int nta
 
 /* Bench/ablation helper for the d=64 attention kernel (not used by the engine). */
 float sdm_bench_attn(sdm_ctx* e, int B, int heads, int Lq, int Lk, int qt, int ablate, int iters) {
+  if (e) dev_use(e->device);
   if (!e) return -1.f;
 #ifdef SDM_EMU
   return -1.f;
@@ -1787,11 +1813,13 @@ float sdm_bench_attn(sdm_ctx* e, int B, int heads, int Lq, int Lk, int qt, int a
 
 int sdm_op_groupnorm(sdm_ctx* e, const void* in0, const void* in1, int C0, int C1, int in_f32, int N, int HW, int groups, const float* gamma,
                      const float* beta, float eps, int silu, void* out) {
+  if (e) dev_use(e->device);
   if (!e || !in0 || !out) return SDM_ERR_INVALID;
   return run_two_pass(e, [&]() { return op_groupnorm_raw(e, in0, in1, C0, C1, in_f32, N, HW, groups, gamma, beta, eps, silu, (half_t*)out); });
 }
 
 int sdm_op_layernorm(sdm_ctx* e, const void* x, int in_f32, long rows, int C, const float* gamma, const float* beta, float eps, void* out) {
+  if (e) dev_use(e->device);
   if (!e || !x || !out) return SDM_ERR_INVALID;
   if (C % 64 || C > 64 * SDM_LN_MAXV) SDM_FAIL(e, SDM_ERR_INVALID, "layernorm: unsupported C %d", C);
   SDM_LAUNCH(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, e->stream, x, in_f32, gamma, beta, (half_t*)out, rows, C, eps);
@@ -1801,6 +1829,7 @@ int sdm_op_layernorm(sdm_ctx* e, const void* x, int in_f32, long rows, int C, co
 
 int sdm_op_attention(sdm_ctx* e, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* bias, int B, int heads,
                      int Lq, int Lk, int D, void* out, int ldo) {
+  if (e) dev_use(e->device);
   if (!e || !q || !k || !v || !out) return SDM_ERR_INVALID;
   return run_two_pass(e, [&]() {
     T b2 = talloc(e, B, 1, 1, Lk, 1);
@@ -1820,6 +1849,7 @@ int sdm_op_attention(sdm_ctx* e, const void* q, int ldq, const void* k, int ldk,
 }
 
 int sdm_op_resize_aa(sdm_ctx* e, const float* in, int P, int Hin, int Win, float* out, int Hout, int Wout) {
+  if (e) dev_use(e->device);
   if (!e || !in || !out) return SDM_ERR_INVALID;
   SDM_LAUNCH(resize_planes_kernel, dim3((unsigned)(((long)P * Hout * Wout + 255) / 256)), dim3(256), 0, e->stream, in, out, P, Hin, Win, Hout, Wout, 0);
   SDM_CHECK_DEV(e, dev_sync(e->stream));
@@ -1827,6 +1857,7 @@ int sdm_op_resize_aa(sdm_ctx* e, const float* in, int P, int Hin, int Win, float
 }
 
 int sdm_op_mask_bias(sdm_ctx* e, const float* plane, int B, int S, int level, float* out) {
+  if (e) dev_use(e->device);
   if (!e || !plane || !out) return SDM_ERR_INVALID;
   const int lk = (S / 8) >> level;
   SDM_LAUNCH(mask_bias_kernel, dim3(sdm_cdiv(B * lk * lk, 256)), dim3(256), 0, e->stream, plane, out, B, S, level, e->cfg.attn_mask_value, 1.0f);
