@@ -82,9 +82,9 @@ __global__ void prep_trimap_kernel(const float* __restrict__ tri, half_t* __rest
 
 // already pre-processed core-API inputs: image fp32 NCHW [B,3,S,S], trimap fp32 [B,1,S,S] (in [-1,1])
 __global__ void prep_nchw_kernel(const float* __restrict__ img, const float* __restrict__ tri, half_t* __restrict__ out_img,
-                                 half_t* __restrict__ out_tri, float* __restrict__ plane, int B, int S) {
+                                 half_t* __restrict__ out_tri, float* __restrict__ plane, int B, int SH, int SW) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long hw = (long)S * S;
+  const long hw = (long)SH * SW;
   if (i >= B * hw) return;
   const long b = i / hw, pq = i % hw;
   f16x8 a, t, z;
@@ -100,14 +100,16 @@ __global__ void prep_nchw_kernel(const float* __restrict__ img, const float* __r
   *(f16x8*)(out_tri + (size_t)i * 16 + 8) = z;
 }
 
-// bias[level][b][i*lk + j] = (1 - (t[b][8*s*i][8*s*j] + 1)/2) * mask_value * log2e, s = 2^level, lk = l >> level
-__global__ void mask_bias_kernel(const float* __restrict__ plane, float* __restrict__ bias, int B, int S, int level, float mask_value,
+// bias[level][b][i*wk + j] = (1 - (t[b][8*s*i][8*s*j] + 1)/2) * mask_value * log2e, s = 2^level, (hk, wk) = (SH/8, SW/8) >> level.
+// The reference only admits square latents (replace.py:57-60 asserts perfect squares); the stride-2^k pick is the same rule
+// on a rectangle.
+__global__ void mask_bias_kernel(const float* __restrict__ plane, float* __restrict__ bias, int B, int SH, int SW, int level, float mask_value,
                                  float mult) {
-  const int l = S / 8, lk = l >> level, s = 1 << level;
+  const int hk = (SH / 8) >> level, wk = (SW / 8) >> level, s = 1 << level;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long)B * lk * lk) return;
-  const int j = i % lk, ii = (i / lk) % lk, b = i / ((long)lk * lk);
-  const float t = plane[((size_t)b * S + (size_t)8 * s * ii) * S + 8 * s * j];
+  if (i >= (long)B * hk * wk) return;
+  const int j = i % wk, ii = (i / wk) % hk, b = i / ((long)hk * wk);
+  const float t = plane[((size_t)b * SH + (size_t)8 * s * ii) * SW + 8 * s * j];
   const float m = (t + 1.0f) / 2.0f;
   bias[i] = ((1.0f - m) * mask_value) * mult;
 }

@@ -1131,7 +1131,7 @@ static int prepare_variants(sdm_ctx* e, int B, const int32_t* is_trans, const fl
 }
 
 // ------------------------------------------------------------------------------------------------
-// the model: x16 [2B,S,S,16] fp16 (rgb images then trimaps), plane [B,S,S] fp32 (trimap in [-1,1]) -> alpha [B,S,S]
+// the model: x16 [2B,SH,SW,16] fp16 (rgb images then trimaps), plane [B,SH,SW] fp32 (trimap in [-1,1]) -> alpha [B,SH,SW]
 // ------------------------------------------------------------------------------------------------
 static int vae_encode(sdm_ctx* e, const T& x16, T* moments) {
   const float eps = e->cfg.vae_eps;
@@ -1215,23 +1215,23 @@ static int unet_forward(sdm_ctx* e, const T& uin, float* const* bias_lvl, int* c
   return 0;
 }
 
-static int run_model(sdm_ctx* e, const T& x16, const T& plane, int B, int S, bool use_mask, T* alpha) {
+static int run_model(sdm_ctx* e, const T& x16, const T& plane, int B, int SH, int SW, bool use_mask, T* alpha) {
   const sdm_config& c = e->cfg;
-  const int l = S / 8;
+  const int lh = SH / 8, lw = SW / 8;
   // attention key bias at the 4 U-Net levels (meta_arch.py:200-204, replace.py:401-403,56-63)
   T biasbuf[4], tilebuf[4];
   float* bias_lvl[4];
   int* tiles_lvl[4];            // per level: the key tiles that can contribute to the softmax (AttnParams::tiles), built once per forward
   for (int k = 0; k < 4; ++k) {
-    const int lk = l >> k, nt = sdm_cdiv(lk * lk, 64);
-    biasbuf[k] = talloc(e, B, 1, 1, lk * lk, 1);
+    const int lk2 = (lh >> k) * (lw >> k), nt = sdm_cdiv(lk2, 64);
+    biasbuf[k] = talloc(e, B, 1, 1, lk2, 1);
     tilebuf[k] = talloc(e, B, 1, 1, nt + 1, 1);
     bias_lvl[k] = (float*)biasbuf[k].p;
     tiles_lvl[k] = (int*)tilebuf[k].p;
     if (!e->dry && use_mask) {
-      SDM_LAUNCH(mask_bias_kernel, dim3(sdm_cdiv(B * lk * lk, 256)), dim3(256), 0, e->stream, (const float*)plane.p, bias_lvl[k], B, S, k,
+      SDM_LAUNCH(mask_bias_kernel, dim3(sdm_cdiv(B * lk2, 256)), dim3(256), 0, e->stream, (const float*)plane.p, bias_lvl[k], B, SH, SW, k,
                  c.attn_mask_value, SDM_LOG2E);
-      SDM_LAUNCH(attn_active_tiles_kernel, dim3(B), dim3(256), 0, e->stream, (const float*)bias_lvl[k], lk * lk, nt, tiles_lvl[k], nt + 1,
+      SDM_LAUNCH(attn_active_tiles_kernel, dim3(B), dim3(256), 0, e->stream, (const float*)bias_lvl[k], lk2, nt, tiles_lvl[k], nt + 1,
                  SDM_ATTN_SKIP_MARGIN);
     }
     // prompt types outside attn_mask_aux_input run the self-attention without a key mask (meta_arch.py:199-206)
@@ -1242,11 +1242,11 @@ static int run_model(sdm_ctx* e, const T& x16, const T& plane, int B, int S, boo
   TRY(vae_encode(e, x16, &moments));
   // quant_conv -> mean half * scaling_factor, written straight into the 8(+8 pad)-channel U-Net input:
   // channels 0..3 = rgb latent, 4..7 = trimap latent (torch.cat order of meta_arch.py:244)
-  T uin = talloc(e, B, l, l, 16, 0);
+  T uin = talloc(e, B, lh, lw, 16, 0);
   if (!e->dry) SDM_CHECK_DEV(e, dev_memset(uin.p, 0, uin.bytes, e->stream));
   for (int half = 0; half < 2; ++half) {
     T mv = moments; mv.N = B;
-    if (!e->dry) mv.p = (unsigned char*)moments.p + (size_t)half * B * l * l * 16 * 2;
+    if (!e->dry) mv.p = (unsigned char*)moments.p + (size_t)half * B * lh * lw * 16 * 2;
     ConvArgs a; a.in0 = &mv; a.out = &uin; a.out_ch_off = half * 4; a.cout_valid = 4; a.out_scale = c.vae_scaling_factor;
     TRY(op_conv(e, e->convs[e->quant], a));
   }
@@ -1262,10 +1262,10 @@ static int run_model(sdm_ctx* e, const T& x16, const T& plane, int B, int S, boo
   TRY(conv_simple(e, e->post_quant, lat, &z, 16, 0)); tfree(e, lat);
   T dec;
   TRY(vae_decode(e, z, &dec)); tfree(e, z);
-  *alpha = talloc(e, B, S, S, 1, 1);
+  *alpha = talloc(e, B, SH, SW, 1, 1);
   if (!e->dry)
-    SDM_LAUNCH(alpha_out_kernel, dim3((unsigned)(((long)B * S * S + 255) / 256)), dim3(256), 0, e->stream, (const float*)dec.p, (float*)alpha->p,
-               (long)B * S * S);
+    SDM_LAUNCH(alpha_out_kernel, dim3((unsigned)(((long)B * SH * SW + 255) / 256)), dim3(256), 0, e->stream, (const float*)dec.p, (float*)alpha->p,
+               (long)B * SH * SW);
   tfree(e, dec);
   return 0;
 }
@@ -1282,15 +1282,18 @@ static int ensure_buf(sdm_ctx* e, void** p, size_t* cap, size_t need) {
 }
 
 // mode 0: core API (NCHW preprocessed, S x S); mode 1: node API (BHWC image + BHW trimap at H x W)
+// mode 0 takes the inference size as (SH, SW) = (H, W) and S is ignored; mode 1 resizes H x W to S x S like the node.
 static int forward_impl(sdm_ctx* e, int mode, const float* image, const float* trimap, int B, int H, int W, int S, const int32_t* is_trans,
                         const float* cond, int cond_dim, int cond_kind, bool use_mask, float* out, int ptr_kind, void* stream_arg) {
   if (!e->finalized) SDM_FAIL(e, SDM_ERR_STATE, "weights not finalised: call sdm_load_tensor(...) and sdm_finalize_weights first");
-  if (B <= 0 || S <= 0 || S % 64) SDM_FAIL(e, SDM_ERR_INVALID, "inference size must be a positive multiple of 64 (got %d)", S);
+  const int SH = (mode == 0) ? H : S, SW = (mode == 0) ? W : S;
+  if (B <= 0 || SH <= 0 || SW <= 0 || SH % 64 || SW % 64)
+    SDM_FAIL(e, SDM_ERR_INVALID, "inference size must be a positive multiple of 64 (got %dx%d)", SH, SW);
   if (mode == 1 && (H <= 0 || W <= 0)) SDM_FAIL(e, SDM_ERR_INVALID, "bad image size %dx%d", H, W);
   (void)stream_arg;   // all work is queued on the engine stream; callers sync through sdm_synchronize
-  const size_t in_img = (mode == 0) ? (size_t)B * 3 * S * S * 4 : (size_t)B * H * W * 3 * 4;
-  const size_t in_tri = (mode == 0) ? (size_t)B * S * S * 4 : (size_t)B * H * W * 4;
-  const size_t out_bytes = (mode == 0) ? (size_t)B * S * S * 4 : (size_t)B * H * W * 4;
+  const size_t in_img = (size_t)B * H * W * 3 * 4;          // mode 0: [B,3,SH,SW]; mode 1: [B,H,W,3]
+  const size_t in_tri = (size_t)B * H * W * 4;
+  const size_t out_bytes = (size_t)B * H * W * 4;
   const float* d_img = image; const float* d_tri = trimap; float* d_out = out;
   if (ptr_kind == SDM_PTR_HOST) {
     TRY(ensure_buf(e, &e->io_in, &e->io_in_bytes, in_img + in_tri));
@@ -1313,25 +1316,25 @@ static int forward_impl(sdm_ctx* e, int mode, const float* image, const float* t
 #ifndef SDM_EMU
     if (pass == 1) (void)hipEventRecord(e->ev0, (hipStream_t)e->stream);
 #endif
-    T x16 = talloc(e, 2 * B, S, S, 16, 0);
-    T plane = talloc(e, B, S, S, 1, 1);
+    T x16 = talloc(e, 2 * B, SH, SW, 16, 0);
+    T plane = talloc(e, B, SH, SW, 1, 1);
     if (!e->dry) {
-      const unsigned nb = (unsigned)(((long)B * S * S + 255) / 256);
+      const unsigned nb = (unsigned)(((long)B * SH * SW + 255) / 256);
       half_t* img16 = (half_t*)x16.p;
-      half_t* tri16 = img16 + (size_t)B * S * S * 16;
+      half_t* tri16 = img16 + (size_t)B * SH * SW * 16;
       if (mode == 0) {
-        SDM_LAUNCH(prep_nchw_kernel, dim3(nb), dim3(256), 0, e->stream, d_img, d_tri, img16, tri16, (float*)plane.p, B, S);
+        SDM_LAUNCH(prep_nchw_kernel, dim3(nb), dim3(256), 0, e->stream, d_img, d_tri, img16, tri16, (float*)plane.p, B, SH, SW);
       } else {
         SDM_LAUNCH(prep_image_kernel, dim3(nb), dim3(256), 0, e->stream, d_img, img16, B, H, W, S);
         SDM_LAUNCH(prep_trimap_kernel, dim3(nb), dim3(256), 0, e->stream, d_tri, tri16, (float*)plane.p, B, H, W, S);
       }
     }
     T alpha;
-    int rc = run_model(e, x16, plane, B, S, use_mask, &alpha);
+    int rc = run_model(e, x16, plane, B, SH, SW, use_mask, &alpha);
     if (rc) { e->dry = false; return rc; }
     if (!e->dry) {
       if (mode == 0) {
-        SDM_CHECK_DEV(e, dev_memcpy_d2d(d_out, alpha.p, (size_t)B * S * S * 4, e->stream));
+        SDM_CHECK_DEV(e, dev_memcpy_d2d(d_out, alpha.p, (size_t)B * SH * SW * 4, e->stream));
       } else {
         SDM_LAUNCH(resize_planes_kernel, dim3((unsigned)(((long)B * H * W + 255) / 256)), dim3(256), 0, e->stream, (const float*)alpha.p, d_out, B,
                    S, S, H, W, 1);
@@ -1639,6 +1642,14 @@ int sdm_forward_ex(sdm_ctx* e, const float* image, const float* aux, int B, int 
   return forward_impl(e, 0, image, aux, B, S, S, S, is_trans, cond, cond_dim, cond_kind, use_attention_mask != 0, alpha, ptr_kind, stream);
 }
 
+int sdm_forward_rect(sdm_ctx* e, const float* image, const float* aux, int B, int SH, int SW, const int32_t* is_trans, const float* cond,
+                     int cond_dim, int cond_kind, int use_attention_mask, float* alpha, int ptr_kind, void* stream) {
+  if (e) dev_use(e->device);
+  if (!e || !image || !aux || !alpha) return SDM_ERR_INVALID;
+  if (cond_kind != SDM_COND_BOX && cond_kind != SDM_COND_POINTS) SDM_FAIL(e, SDM_ERR_INVALID, "unknown conditioning kind %d", cond_kind);
+  return forward_impl(e, 0, image, aux, B, SH, SW, 0, is_trans, cond, cond_dim, cond_kind, use_attention_mask != 0, alpha, ptr_kind, stream);
+}
+
 int sdm_apply_matte(sdm_ctx* e, const float* image, const float* trimap, int B, int H, int W, int S, int is_transparent, float* alpha,
                     int ptr_kind, void* stream) {
   if (e) dev_use(e->device);
@@ -1860,7 +1871,7 @@ int sdm_op_mask_bias(sdm_ctx* e, const float* plane, int B, int S, int level, fl
   if (e) dev_use(e->device);
   if (!e || !plane || !out) return SDM_ERR_INVALID;
   const int lk = (S / 8) >> level;
-  SDM_LAUNCH(mask_bias_kernel, dim3(sdm_cdiv(B * lk * lk, 256)), dim3(256), 0, e->stream, plane, out, B, S, level, e->cfg.attn_mask_value, 1.0f);
+  SDM_LAUNCH(mask_bias_kernel, dim3(sdm_cdiv(B * lk * lk, 256)), dim3(256), 0, e->stream, plane, out, B, S, S, level, e->cfg.attn_mask_value, 1.0f);
   SDM_CHECK_DEV(e, dev_sync(e->stream));
   return 0;
 }

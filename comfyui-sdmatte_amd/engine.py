@@ -57,7 +57,7 @@ def to_c_config(cfg: SDMatteConfig, stream_f32: bool = True) -> SdmConfig:
 EXPORTS = [
     "sdm_default_config", "sdm_create", "sdm_destroy", "sdm_last_error", "sdm_load_tensor", "sdm_finalize_weights",
     "sdm_weight_stats", "sdm_missing_key", "sdm_weight_blob_bytes", "sdm_export_weight_blob", "sdm_import_weight_blob",
-    "sdm_host_blob_bytes", "sdm_export_host_blob", "sdm_import_host_blob", "sdm_forward", "sdm_forward_ex", "sdm_apply_matte",
+    "sdm_host_blob_bytes", "sdm_export_host_blob", "sdm_import_host_blob", "sdm_forward", "sdm_forward_ex", "sdm_forward_rect", "sdm_apply_matte",
     "sdm_synchronize", "sdm_last_forward_ms", "sdm_profile_enable", "sdm_profile_count", "sdm_profile_get", "sdm_profile_dump",
     "sdm_op_conv", "sdm_conv_num_cfgs", "sdm_bench_conv", "sdm_bench_attn", "sdm_op_groupnorm", "sdm_op_layernorm", "sdm_op_attention", "sdm_op_resize_aa",
     "sdm_op_mask_bias",
@@ -87,6 +87,7 @@ class Bindings:
             "sdm_import_host_blob": (i32, [vp, vp]),
             "sdm_forward": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, i32, vp]),
             "sdm_forward_ex": (i32, [vp, vp, vp, i32, i32, vp, vp, i32, i32, i32, vp, i32, vp]),
+            "sdm_forward_rect": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, i32, i32, i32, vp, i32, vp]),
             "sdm_apply_matte": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, vp]),
             "sdm_synchronize": (i32, [vp]),
             "sdm_last_forward_ms": (f32, [vp]),
@@ -208,11 +209,11 @@ class Engine:
         """SDMatte.forward(data): image [B,3,S,S] in [-1,1], aux prompt image (trimap / bbox_mask / mask / point_mask) [B,1,S,S]
         in [-1,1] -> alpha [B,1,S,S].  `coords` [B,4] feed bbox_embedding (None -> [0,0,1,1]); `point_coords` [B,N] select the
         point prompt (point_embedding) instead; use_attention_mask=False drops the aux key mask of the self-attention."""
-        B, _, S, _ = image_b3ss.shape
+        B, _, SH, SW = image_b3ss.shape                    # square in the reference; rectangles are an extension (sdm_forward_rect)
         image_b3ss = image_b3ss.float().contiguous()
         trimap_b1ss = trimap_b1ss.float().contiguous()
         if out is None:
-            out = torch.empty(B, 1, S, S, dtype=torch.float32, device=image_b3ss.device)
+            out = torch.empty(B, 1, SH, SW, dtype=torch.float32, device=image_b3ss.device)
         it = np.ascontiguousarray(np.zeros(B, np.int32) if is_trans is None else np.asarray(is_trans, np.int32).reshape(B))
         if point_coords is not None:
             co = np.ascontiguousarray(np.asarray(point_coords, np.float32).reshape(B, -1))
@@ -220,9 +221,9 @@ class Engine:
         else:
             co = None if coords is None else np.ascontiguousarray(np.asarray(coords, np.float32).reshape(B, 4))
             kind, dim = 0, 4
-        self._check(self.lib.sdm_forward_ex(self.h, _ptr(image_b3ss), _ptr(trimap_b1ss), B, S, it.ctypes.data_as(C.c_void_p),
-                                            co.ctypes.data_as(C.c_void_p) if co is not None else None, dim, kind,
-                                            1 if use_attention_mask else 0, _ptr(out), self._kind(image_b3ss), None), "sdm_forward_ex")
+        self._check(self.lib.sdm_forward_rect(self.h, _ptr(image_b3ss), _ptr(trimap_b1ss), B, SH, SW, it.ctypes.data_as(C.c_void_p),
+                                              co.ctypes.data_as(C.c_void_p) if co is not None else None, dim, kind,
+                                              1 if use_attention_mask else 0, _ptr(out), self._kind(image_b3ss), None), "sdm_forward_rect")
         if sync:
             self.synchronize()
         return out

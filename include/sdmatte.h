@@ -110,6 +110,12 @@ enum sdm_cond_kind { SDM_COND_BOX = 0, SDM_COND_POINTS = 1 };
 int sdm_forward_ex(sdm_ctx* ctx, const float* image_b3ss, const float* aux_b1ss, int B, int S, const int32_t* is_trans,
                    const float* cond, int cond_dim, int cond_kind, int use_attention_mask, float* alpha_b1ss, int ptr_kind, void* stream);
 
+/* Rectangular inference (beyond the reference, whose attention-mask code asserts square latents,
+ * replace.py:57-60): same as sdm_forward_ex with image [B,3,SH,SW], aux [B,1,SH,SW], alpha [B,1,SH,SW]; SH and SW multiples
+ * of 64.  The level-k key bias keeps the reference's stride-2^k pick, bias_k[i,j] = bias_0[2^k i, 2^k j]. */
+int sdm_forward_rect(sdm_ctx* ctx, const float* image_b3hw, const float* aux_b1hw, int B, int SH, int SW, const int32_t* is_trans,
+                     const float* cond, int cond_dim, int cond_kind, int use_attention_mask, float* alpha_b1hw, int ptr_kind, void* stream);
+
 /* Node-level call.  Replaces the device part of SDMatteApply.apply_matte (sdmatte_nodes.py:339-363):
  *   image fp32 [B,H,W,3] in [0,1], trimap fp32 [B,H,W] in [0,1]  ->  antialiased resize to SxS, normalise,
  *   forward, resize back to (H,W), clamp(0,1)  ->  alpha fp32 [B,H,W].

@@ -22,6 +22,8 @@ PARITY STATUS: *partially pinned*.
     point_mask, point-coordinate padding, use_coor_input, attn_mask_aux_input): `meta_arch.py` cannot be imported
     (hard-coded `.cuda()`, diffusers), so `sdmatte_forward(..., aux_input=...)` restates meta_arch.py:131-206 and
     replace.py:446-457 line by line (cited in place) without a golden vector.
+  * EXTENSION beyond the reference (no parity claim possible): rectangular token grids in `prepare_attention_mask`
+    (`src_hw` / `dst_hw`); the reference asserts perfect squares (replace.py:59-60).  Square inputs take the reference branch.
 
 The reference's `force_cpu=True` branch is the semantics restated here: fp32, no autocast, default
 (un-sliced) AttnProcessor (sdmatte_nodes.py:355-360, utils.py:46).
@@ -96,17 +98,24 @@ def vae_attention(w, p: str, x: Tensor, groups: int, eps: float) -> Tensor:
     return o + r
 
 
-def prepare_attention_mask(bias_b1l: Tensor, target_length: int, heads: int) -> Tensor:
+def prepare_attention_mask(bias_b1l: Tensor, target_length: int, heads: int, src_hw=None, dst_hw=None) -> Tensor:
     """Restatement of custom_prepare_attention_mask (replace.py:20-72): nearest-resize the
-    additive bias, viewed as a square image, to the level's token grid; repeat per head."""
+    additive bias, viewed as a square image, to the level's token grid; repeat per head.
+    `src_hw` / `dst_hw` (EXTENSION, not in the reference, which asserts perfect squares at replace.py:59-60): the same
+    nearest resize on a rectangular token grid."""
     B = bias_b1l.shape[0]
     cur = bias_b1l.shape[-1]
     if cur != target_length:
-        cs = int(math.sqrt(cur))
-        ts = int(math.sqrt(target_length))
-        assert cs * cs == cur and ts * ts == target_length        # replace.py:59-60
-        m = bias_b1l.view(B, -1, cs, cs)
-        m = F.interpolate(m, size=(ts, ts), mode="nearest")        # replace.py:62
+        if src_hw is not None and src_hw[0] != src_hw[1]:
+            assert src_hw[0] * src_hw[1] == cur and dst_hw[0] * dst_hw[1] == target_length
+            m = bias_b1l.view(B, -1, src_hw[0], src_hw[1])
+            m = F.interpolate(m, size=tuple(dst_hw), mode="nearest")
+        else:
+            cs = int(math.sqrt(cur))
+            ts = int(math.sqrt(target_length))
+            assert cs * cs == cur and ts * ts == target_length        # replace.py:59-60
+            m = bias_b1l.view(B, -1, cs, cs)
+            m = F.interpolate(m, size=(ts, ts), mode="nearest")        # replace.py:62
         bias_b1l = m.view(B, 1, target_length)
     return bias_b1l.repeat_interleave(heads, dim=0)                # replace.py:65-67
 
@@ -143,7 +152,7 @@ def attention_core(q: Tensor, k: Tensor, v: Tensor, heads: int, bias: Optional[T
 
 
 def transformer_2d(w, p: str, x: Tensor, ehs: Tensor, bias_b1l: Optional[Tensor], heads: int,
-                   groups: int, gn_eps: float, ln_eps: float) -> Tensor:
+                   groups: int, gn_eps: float, ln_eps: float, hw0=None) -> Tensor:
     """[3P Transformer2DModel(use_linear_projection=True) + BasicTransformerBlock] (Appendix A.7);
     attention internals per replace.py:20-122."""
     B, C, H, W = x.shape
@@ -157,7 +166,7 @@ def transformer_2d(w, p: str, x: Tensor, ehs: Tensor, bias_b1l: Optional[Tensor]
     q = F.linear(n, w[b + ".attn1.to_q.weight"])
     k = F.linear(n, w[b + ".attn1.to_k.weight"])
     v = F.linear(n, w[b + ".attn1.to_v.weight"])
-    mb = None if bias_b1l is None else prepare_attention_mask(bias_b1l, H * W, heads)
+    mb = None if bias_b1l is None else prepare_attention_mask(bias_b1l, H * W, heads, hw0, (H, W))
     a = attention_core(q, k, v, heads, mb)
     a = F.linear(a, w[b + ".attn1.to_out.0.weight"], w[b + ".attn1.to_out.0.bias"])
     h = h + a
@@ -260,6 +269,7 @@ def unet_forward(w, cfg: dict, sample: Tensor, trans: Tensor, ehs: Tensor, coord
         bias = (1 - attention_mask.to(sample.dtype)) * cfg["attn_mask_value"]
         bias = bias.unsqueeze(1)
     emb = unet_embedding(w, cfg, trans, coords_emb, cond_key)
+    hw0 = tuple(sample.shape[-2:])                                               # level-0 token grid (square in the reference)
     h = F.conv2d(sample, w["unet.conv_in.weight"], w["unet.conv_in.bias"], padding=1)   # :462
     if taps is not None:
         taps["unet.conv_in"] = h
@@ -268,7 +278,7 @@ def unet_forward(w, cfg: dict, sample: Tensor, trans: Tensor, ehs: Tensor, coord
         for j in range(cfg["unet_layers_per_block"]):
             h = resnet_block(w, f"unet.down_blocks.{i}.resnets.{j}", h, emb, g, reps)
             if i < nlev - 1:
-                h = transformer_2d(w, f"unet.down_blocks.{i}.attentions.{j}", h, ehs, bias, heads[i], g, geps, leps)
+                h = transformer_2d(w, f"unet.down_blocks.{i}.attentions.{j}", h, ehs, bias, heads[i], g, geps, leps, hw0)
             skips.append(h)
         if i < nlev - 1:
             h = F.conv2d(h, w[f"unet.down_blocks.{i}.downsamplers.0.conv.weight"],
@@ -277,7 +287,7 @@ def unet_forward(w, cfg: dict, sample: Tensor, trans: Tensor, ehs: Tensor, coord
         if taps is not None:
             taps[f"unet.down{i}"] = h
     h = resnet_block(w, "unet.mid_block.resnets.0", h, emb, g, reps)             # replace.py:493-504
-    h = transformer_2d(w, "unet.mid_block.attentions.0", h, ehs, bias, heads[-1], g, geps, leps)
+    h = transformer_2d(w, "unet.mid_block.attentions.0", h, ehs, bias, heads[-1], g, geps, leps, hw0)
     h = resnet_block(w, "unet.mid_block.resnets.1", h, emb, g, reps)
     if taps is not None:
         taps["unet.mid"] = h
@@ -288,7 +298,7 @@ def unet_forward(w, cfg: dict, sample: Tensor, trans: Tensor, ehs: Tensor, coord
             h = torch.cat([h, s], dim=1)
             h = resnet_block(w, f"unet.up_blocks.{i}.resnets.{j}", h, emb, g, reps)
             if i > 0:
-                h = transformer_2d(w, f"unet.up_blocks.{i}.attentions.{j}", h, ehs, bias, rheads[i], g, geps, leps)
+                h = transformer_2d(w, f"unet.up_blocks.{i}.attentions.{j}", h, ehs, bias, rheads[i], g, geps, leps, hw0)
         if i < nlev - 1:
             h = F.interpolate(h, scale_factor=2.0, mode="nearest")
             h = F.conv2d(h, w[f"unet.up_blocks.{i}.upsamplers.0.conv.weight"],

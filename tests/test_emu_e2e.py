@@ -218,3 +218,26 @@ def test_emu_other_prompt_types_match_oracle(pkg):
         SDMatte(None, use_aux_input=True, aux_input=None, load_weight=False, config=cfg)
     with pytest.raises(NotImplementedError):
         SDMatte(None, use_aux_input=True, aux_input="trimap", add_noise=True, load_weight=False, config=cfg)
+
+
+def test_emu_rectangular_inference_matches_oracle(pkg):
+    """Rectangular inference (an extension: the reference asserts square latents): core API with
+    [B,3,64,128] inputs vs the oracle's rectangular restatement, incl. the 4-level key-bias pyramid on a 8x16 token grid."""
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    from comfyui_sdmatte_amd.weights import synthetic_state_dict
+    from comfyui_sdmatte_amd.synth import synthetic_inputs
+    from oracle import sdmatte_oracle as O
+    cfg = SDMatteConfig.tiny()
+    w = synthetic_state_dict(cfg, 4)
+    eng = _emu_engine(cfg)
+    eng.load_state_dict(w)
+    img, tri = synthetic_inputs(1, 64, 128, seed=8)
+    data = {"image": (img.permute(0, 3, 1, 2).contiguous() - 0.5) / 0.5, "trimap": tri.unsqueeze(1) * 2 - 1,
+            "is_trans": torch.tensor([0]), "trimap_coords": torch.tensor([[0.0, 0.0, 1.0, 1.0]])}
+    ref = O.sdmatte_forward(w, cfg.as_dict(), data)
+    out = eng.forward(data["image"], data["trimap"], is_trans=data["is_trans"].numpy())
+    d = (out - ref).abs()
+    assert out.shape == (1, 1, 64, 128) and d.max().item() < 1e-2 and d.mean().item() < 1.5e-3, (d.max().item(), d.mean().item())
+    with pytest.raises(RuntimeError):
+        eng.forward(data["image"][..., :96], data["trimap"][..., :96])          # 96 is not a multiple of 64
+    eng.close()

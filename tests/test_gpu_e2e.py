@@ -269,3 +269,26 @@ def test_e2e_other_prompt_types(pkg):
         print(f"\n[{aux_input} {kw}] max|d|={d.max():.3e} mean|d|={d.mean():.3e}")
         assert d.max().item() <= 1e-2 and d.mean().item() <= 1.5e-3
         m.engine.close()
+
+
+def test_e2e_rectangular_inference(pkg):
+    """Rectangular inference sizes (an extension over the reference's square-only attention mask) vs the oracle on the GPU."""
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    from comfyui_sdmatte_amd.engine import Engine
+    from comfyui_sdmatte_amd.weights import synthetic_state_dict
+    from comfyui_sdmatte_amd.synth import synthetic_inputs
+    from oracle import sdmatte_oracle as O
+    cfg = SDMatteConfig.tiny()
+    w = synthetic_state_dict(cfg, 4)
+    eng = Engine(cfg, 0)
+    eng.load_state_dict(w)
+    for (H, W) in ((128, 192), (192, 64)):
+        img, tri = synthetic_inputs(2, H, W, seed=8)
+        data = {"image": (img.permute(0, 3, 1, 2).contiguous() - 0.5) / 0.5, "trimap": tri.unsqueeze(1) * 2 - 1,
+                "is_trans": torch.tensor([0, 1]), "trimap_coords": torch.tensor([[0.0, 0.0, 1.0, 1.0]] * 2)}
+        ref = O.sdmatte_forward(w, cfg.as_dict(), data)
+        out = eng.forward(data["image"].cuda(), data["trimap"].cuda(), is_trans=data["is_trans"].numpy()).cpu()
+        d = (out - ref).abs()
+        print(f"\n[rect {H}x{W}] max|d|={d.max():.3e} mean|d|={d.mean():.3e}")
+        assert out.shape == (2, 1, H, W) and d.max().item() <= 1e-2 and d.mean().item() <= 1.5e-3
+    eng.close()
