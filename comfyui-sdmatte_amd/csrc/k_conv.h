@@ -28,9 +28,6 @@
 #ifndef SDM_CONV_VREUSE
 #define SDM_CONV_VREUSE 1   /* vertical A-fragment reuse across taps (A/B switch for experiments) */
 #endif
-#ifndef SDM_CONV_PIPE
-#define SDM_CONV_PIPE 1
-#endif
 
 struct ConvParams {
   const void* in0; const void* in1;     // NHWC sources (channel concat: in0 then in1); in1 may be null
@@ -297,7 +294,6 @@ conv_mfma_kernel(ConvParams p) {
       if ((p.ablate & 4) && c0 > 0) continue;
     }
     // ---- MFMA over taps and K sub-steps ----
-#if SDM_CONV_PIPE || 1   /* the non-pipelined loop below does not implement the swizzled layout */
     // Software-pipelined fragment reads with a pinned schedule: B fragments of step s+1 are read at the top of step s
     // (double buffer, 2*NTL regs x4), each A fragment is re-read IN PLACE for step s+1 right after the MFMAs that consumed it.
     // Every ds_read therefore has ~3/4 of a step (6 MFMAs = 192 cycles) of cover instead of none.
@@ -378,24 +374,6 @@ conv_mfma_kernel(ConvParams p) {
       }
     }
     }
-#else
-#pragma unroll
-    for (int tap = 0; tap < NTAPS; ++tap) {
-      const int toff = (NTAPS == 9) ? ((tap / 3) * HPW + (tap % 3)) * PITCH : 0;
-#pragma unroll
-      for (int ks = 0; ks < KC / 16; ++ks) {
-        f16x8 a[MT], b[NTL];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) a[i] = *(const f16x8*)(As + abase[i] + toff + ks * 32);
-#pragma unroll
-        for (int j = 0; j < NTL; ++j) b[j] = *(const f16x8*)(Bs + tap * BN * PITCH + bbase[j] + ks * 32);
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NTL; ++j) acc[i][j] = SDM_MFMA_32x32x16_F16(a[i], b[j], acc[i][j]);
-      }
-    }
-#endif
     if (DB) {
       if (c0 + KC < Cin) {          // the other half was last read one iteration ago, before the previous barrier
         unsigned char* An = smem + (((c0 / KC) & 1) ^ 1) * C::TILE_BYTES;
