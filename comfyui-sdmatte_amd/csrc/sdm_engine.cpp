@@ -148,7 +148,11 @@ static int conv_pick_cfg(int ntaps, int stride, const ConvParams& p) {
       blocks = ((p.M + t[i].TH * t[i].TW - 1) / (t[i].TH * t[i].TW)) * sdm_cdiv(p.Cout_pad, t[i].BN);
     }
     if (best < 0) { best = i; best_blocks = blocks; }
-    if (blocks >= 256) {
+    // first (largest) tile that still spreads over the chip.  Measured: a 3x3 stride-1 layer with 160 blocks of the 256x128 tile
+    // beats 640 blocks of the 128x64 tile by 6-12 % (and 160 x 128x64 beats 320 x 64x64 by 22 %), so half a block per CU is
+    // enough there; GEMMs and stride-2 layers keep the one-block-per-CU rule.
+    const long enough = (ntaps == 9 && stride == 1) ? 128 : 256;
+    if (blocks >= enough) {
       // cfg 3 (512-pixel tile, 1 block per CU) needs at least ~2 blocks per CU of its own to pay off
       if (use_db && ntaps == 9 && stride == 1 && i == 0 && (long)p.N * sdm_cdiv(p.Hout, 16) * sdm_cdiv(p.Wout, 32) * sdm_cdiv(p.Cout_pad, 128) >= 512) return 3;
       // thin outputs (conv_out layers, Cout <= 32): the same 256-pixel tile with 32 output channels instead of 128 (HBM-bound
@@ -159,7 +163,7 @@ static int conv_pick_cfg(int ntaps, int stride, const ConvParams& p) {
       if (ntaps == 9 && stride == 2 && i == 0 && conv_cfg_ok(t[3], p) &&
           (long)p.N * sdm_cdiv(p.Hout, 8) * sdm_cdiv(p.Wout, 32) * sdm_cdiv(p.Cout_pad, 128) >= 256) return 3;
       return i;
-    }   // first (largest) tile that still gives every CU a block
+    }
     if (blocks > best_blocks) { best = i; best_blocks = blocks; }
   }
   return best;
