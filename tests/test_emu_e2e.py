@@ -41,6 +41,10 @@ def test_emu_full_forward_matches_oracle(pkg):
     ra, _ = O.apply_matte(w, cfg.as_dict(), img2, tri2, 64, mask_refine=False)
     d2 = (a - ra).abs()
     assert d2.max().item() < 1e-2 and d2.mean().item() < 1.5e-3
+    # the request-stream runner without a process group (world 1) is the same computation
+    from comfyui_sdmatte_amd import parallel
+    st = parallel.matte_stream(eng, [img2[0]], [tri2[0]], [64], device=torch.device("cpu"))
+    assert len(st) == 1 and torch.equal(st[0], a[0])
     # weight blob export/import round trip gives a bit-identical engine
     eng2 = _emu_engine(cfg)
     blob = torch.empty(eng.weight_blob_bytes(), dtype=torch.uint8)
