@@ -28,7 +28,7 @@ class SDMatte:
                  use_encoder_attention_mask=False, add_noise=False, attn_mask_aux_input=("point_mask", "bbox_mask", "mask"),
                  aux_input_list=("point_mask", "bbox_mask", "mask"), use_encoder_hidden_states=True, residual_connection=False,
                  use_attention_mask_list=(True, True, True), use_encoder_hidden_states_list=(True, True, True), load_weight=True,
-                 config: SDMatteConfig = None, stream_f32: bool = True):
+                 config: SDMatteConfig = None, stream_f32: bool = True, precision=None):
         # `pretrained_model_name_or_path` only supplied SD-2.1 config JSONs to the reference (meta_arch.py:95-118);
         # the constants are embedded (config.py), so it is accepted and ignored.
         self.pretrained_model_name_or_path = pretrained_model_name_or_path
@@ -53,6 +53,7 @@ class SDMatte:
         self.aux_input = aux_input
         self.config = config or SDMatteConfig.full()
         self.stream_f32 = stream_f32
+        self.precision = precision          # None -> engine.DEFAULT_PRECISION ("fp16x3": within 1e-3 of the reference's fp32 path)
         self.engine = None
         self._pending = None
         self.training = False
@@ -78,7 +79,7 @@ class SDMatte:
         if self.engine is None or self.engine.device != idx:
             if self.engine is not None:
                 self.engine.close()
-            self.engine = Engine(self.config, idx, self.stream_f32)
+            self.engine = Engine(self.config, idx, self.stream_f32, precision=self.precision)
             if self._pending is not None:
                 self._upload()
         return self

@@ -22,6 +22,10 @@ struct AttnParams {
   const half_t* vt; long vt_bs; long vt_hs; int ldvt;      // vt[b][head][d][key]  (key padded to ldvt, zero filled)
   const float* bias; long bias_bs;                         // bias[b][key] * log2e, or null
   half_t* o; long o_bs; int ldo;                           // o [b][row][head*D + d]
+  int o_f32;                                               // 1: o is fp32 (same indexing), 0: fp16
+  // precise (split-fp16) variant, d = 64: q / k / vt are the HIGH parts; the low parts live in a second plane at these element
+  // offsets (q = q_hi + q_lo etc., written by the producing GEMM's `out_f32 == 2` epilogue and by transpose_v on both planes)
+  long q_lo, k_lo, vt_lo;
   int Lq, Lk;
   float scale_log2e;
   // Active key tiles (d = 64 only; null = all tiles).  tiles[b*tiles_bs] = n, tiles[b*tiles_bs + 1 + i] = index of the i-th 64-key tile of
@@ -48,6 +52,8 @@ struct AttnParams {
 #define ATTN64_PV 136   /* V^T rows: 34 dwords -> the 32 lanes of a ds_read_b64 half-wave hit 64 distinct banks */
 #define ATTN64_BUF (64 * ATTN64_PK + 64 * ATTN64_PV + 256)
 #define ATTN64_SMEM (2 * ATTN64_BUF)
+#define ATTN64P_BUF (2 * 64 * ATTN64_PK + 2 * 64 * ATTN64_PV + 256)   /* precise: K_hi | K_lo | V^T_hi | V^T_lo | bias */
+#define ATTN64P_SMEM (2 * ATTN64P_BUF)
 
 // XCD-aware work mapping.  The dispatcher places block id on XCD id % 8 (MI355X_MICROARCH.md, speed only - never needed for
 // correctness).  All query blocks of one (image, head) should share an XCD so that its K / V^T (4 MB at L = 16384) stay in that
@@ -65,17 +71,25 @@ SDM_DEV_INLINE bool attn_block_coords(const AttnParams& p, int bid, int& b, int&
   return qblk < p.nq_blocks;
 }
 
-template <int QT>
+// PREC = 1 (precise mode): q, k and V^T arrive as fp16 pairs hi + lo and the probabilities are split the same way, every
+// product is evaluated as hi.hi + lo.hi + hi.lo into the same fp32 accumulators (3 MFMAs instead of 1; the lo.lo term is 2^-22).
+template <int QT, int PREC = 0>
 __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
+  static_assert(!PREC || QT == 1, "the split-precision variant keeps one 32-query tile per wave");
   SDM_DYN_SMEM(smem);
   constexpr int PK = ATTN64_PK, PV = ATTN64_PV;
+  constexpr int BUF = PREC ? ATTN64P_BUF : ATTN64_BUF;
+  constexpr int KLO = 64 * PK;                                   // PREC: byte offset of the K_lo tile behind K_hi
+  constexpr int VOFF = (PREC ? 2 : 1) * 64 * PK;                 // V^T_hi tile
+  constexpr int VLO = 64 * PV;                                   // PREC: V^T_lo behind V^T_hi
+  constexpr int BOFF = VOFF + (PREC ? 2 : 1) * 64 * PV;          // bias row
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, l31 = lane & 31;
   int b, head, qblk;
   if (!attn_block_coords(p, blockIdx.x, b, head, qblk)) return;     // padding block of the XCD-aware grid
   const int q0 = qblk * (128 * QT) + wave * (32 * QT);
 
-  f16x8 qf[QT][4];
+  f16x8 qf[QT][4], qfl[PREC ? QT : 1][4];
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     int qrow = q0 + qt * 32 + l31;
@@ -83,6 +97,10 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
     const half_t* qp = p.q + (size_t)b * p.q_bs + (size_t)qrow * p.ldq + head * 64 + hi * 8;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[qt][ks] = *(const f16x8*)(qp + ks * 16);
+    if (PREC) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) qfl[PREC ? qt : 0][ks] = *(const f16x8*)(qp + p.q_lo + ks * 16);
+    }
     // The logit scale d^-1/2 * log2(e) lives in Q.  The engine folds it into the to_q weights at load time (exact: one fp16
     // rounding of the GEMM result either way) and passes scale_log2e == 1; the stand-alone operator entry scales Q here.
     if (p.scale_log2e != 1.0f) {
@@ -113,7 +131,7 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
   const float* bbase = p.bias ? p.bias + (size_t)b * p.bias_bs : nullptr;
   const int ntiles = (p.Lk + 63) / 64;
 
-  f16x8 kreg[2], vreg[2];
+  f16x8 kreg[2], vreg[2], kregl[PREC ? 2 : 1], vregl[PREC ? 2 : 1];
   float breg = 0.0f;
   bool binr = true;
   // without a bias the load still happens (from the K tensor: >= Lk readable floats) and its value is discarded by a select
@@ -130,6 +148,10 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
       if (kr > p.Lk - 1) kr = p.Lk - 1;
       kreg[i] = *(const f16x8*)(kbase + (size_t)kr * p.ldk + part * 8);
       vreg[i] = *(const f16x8*)(vbase + (size_t)row * p.ldvt + k0 + part * 8);
+      if (PREC) {
+        kregl[PREC ? i : 0] = *(const f16x8*)(kbase + p.k_lo + (size_t)kr * p.ldk + part * 8);
+        vregl[PREC ? i : 0] = *(const f16x8*)(vbase + p.vt_lo + (size_t)row * p.ldvt + k0 + part * 8);
+      }
     }
     // bias: UNCONDITIONAL raw load, consumed only in stage() after the MFMAs.  (`bbase ? bbase[kb] : 0` followed by a select
     // made hipcc branch around the load and wait vmcnt(0) right here - which also drains the four K / V^T prefetch loads
@@ -140,7 +162,7 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
     breg = bsrc[kb];
   };
   auto stage = [&](int buf) {
-    unsigned char* base = smem + buf * ATTN64_BUF;
+    unsigned char* base = smem + buf * BUF;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int v = tid + i * 256;
@@ -150,10 +172,17 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
       f16x4 lo, hi4;
 #pragma unroll
       for (int e = 0; e < 4; ++e) { lo[e] = vreg[i][e]; hi4[e] = vreg[i][4 + e]; }
-      *(f16x4*)(base + 64 * PK + row * PV + part * 16) = lo;
-      *(f16x4*)(base + 64 * PK + row * PV + part * 16 + 8) = hi4;
+      *(f16x4*)(base + VOFF + row * PV + part * 16) = lo;
+      *(f16x4*)(base + VOFF + row * PV + part * 16 + 8) = hi4;
+      if (PREC) {
+        *(f16x8*)(base + KLO + row * PK + part * 16) = kregl[PREC ? i : 0];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lo[e] = vregl[PREC ? i : 0][e]; hi4[e] = vregl[PREC ? i : 0][4 + e]; }
+        *(f16x4*)(base + VOFF + VLO + row * PV + part * 16) = lo;
+        *(f16x4*)(base + VOFF + VLO + row * PV + part * 16 + 8) = hi4;
+      }
     }
-    if (tid < 64) ((float*)(base + 64 * PK + 64 * PV))[tid] = binr ? (bbase ? breg : 0.0f) : SDM_NEG_BIG;
+    if (tid < 64) ((float*)(base + BOFF))[tid] = binr ? (bbase ? breg : 0.0f) : SDM_NEG_BIG;
   };
   // tile walk: all ntiles tiles, or the active-tile list of this image (wave-uniform scalar loads)
   const int* tl = p.tiles ? p.tiles + (size_t)b * p.tiles_bs : nullptr;
@@ -164,9 +193,9 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
   __syncthreads();
 
   for (int t = 0; t < nwalk; ++t) {
-    const unsigned char* Ks = smem + (t & 1) * ATTN64_BUF;
-    const unsigned char* Vs = Ks + 64 * PK;
-    const float* Bs = (const float*)(Ks + 64 * PK + 64 * PV);
+    const unsigned char* Ks = smem + (t & 1) * BUF;
+    const unsigned char* Vs = Ks + VOFF;
+    const float* Bs = (const float*)(Ks + BOFF);
     if (t + 1 < nwalk && !(p.ablate & 8)) prefetch(tile_at(t + 1));
 
     // S^T[key][q] for 2 key tiles of 32 (x QT query tiles).  The accumulators START from the per-key additive bias (read
@@ -191,6 +220,11 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
         const f16x8 a = *(const f16x8*)(Ks + (kt * 32 + l31) * PK + ks * 32 + hi * 16);
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) s[qt][kt] = SDM_MFMA_32x32x16_F16(a, qf[qt][ks], s[qt][kt]);
+        if (PREC) {
+          const f16x8 al = *(const f16x8*)(Ks + KLO + (kt * 32 + l31) * PK + ks * 32 + hi * 16);
+          s[0][kt] = SDM_MFMA_32x32x16_F16(al, qf[0][ks], s[0][kt]);
+          s[0][kt] = SDM_MFMA_32x32x16_F16(a, qfl[0][ks], s[0][kt]);
+        }
       }
     }
     if (!(p.ablate & 1)) {
@@ -227,13 +261,18 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        f16x8 pf[QT];
+        f16x8 pf[QT], pfl;
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
           for (int j = 0; j < 8; ++j) pf[qt][j] = (half_t)s[qt][kt][8 * u + j];
+        if (PREC) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pfl[j] = (half_t)(s[0][kt][8 * u + j] - (float)pf[0][j]);
+        }
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) ls[qt] = SDM_MFMA_32x32x16_F16(ones, pf[qt], ls[qt]);      // every row = sum_k P[k][q]
+        if (PREC) ls[0] = SDM_MFMA_32x32x16_F16(ones, pfl, ls[0]);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           const unsigned char* vp = Vs + (dt * 32 + l31) * PV + (kt * 32 + 16 * u + 4 * hi) * 2;
@@ -244,6 +283,15 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
           for (int e = 0; e < 4; ++e) { vf[e] = v0[e]; vf[4 + e] = v1[e]; }
 #pragma unroll
           for (int qt = 0; qt < QT; ++qt) o[qt][dt] = SDM_MFMA_32x32x16_F16(vf, pf[qt], o[qt][dt]);
+          if (PREC) {
+            const f16x4 w0 = *(const f16x4*)(vp + VLO);
+            const f16x4 w1 = *(const f16x4*)(vp + VLO + 16);
+            f16x8 vfl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { vfl[e] = w0[e]; vfl[4 + e] = w1[e]; }
+            o[0][dt] = SDM_MFMA_32x32x16_F16(vfl, pf[0], o[0][dt]);
+            o[0][dt] = SDM_MFMA_32x32x16_F16(vf, pfl, o[0][dt]);
+          }
         }
       }
     }
@@ -253,6 +301,33 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
 
   // epilogue: per-wave staging [32 q][64 d] fp16 -> coalesced 16-B row stores (all waves passed the last barrier)
   unsigned char* stg = smem + wave * (32 * PK);
+  if (p.o_f32) {                    // fp32 output (precise-mode graphs): [32 q][64 d] fp32 staging at pitch 272 B
+    constexpr int PS = 272;
+    unsigned char* stf = smem + wave * (32 * PS);
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      const float inv = 1.0f / ls[qt][0];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 h;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) h[e] = o[qt][dt][4 * g + e] * inv;
+          *(f32x4*)(stf + l31 * PS + (dt * 32 + 8 * g + 4 * hi) * 4) = h;
+        }
+      SDM_WAVE_SYNC();
+#pragma unroll
+      for (int pass = 0; pass < 8; ++pass) {
+        const int row = pass * 4 + (lane >> 4), part = lane & 15;
+        const int qg = q0 + qt * 32 + row;
+        if (qg < p.Lq)
+          *(f32x4*)((float*)p.o + (size_t)b * p.o_bs + (size_t)qg * p.ldo + head * 64 + part * 4) = *(const f32x4*)(stf + row * PS + part * 16);
+      }
+      SDM_WAVE_SYNC();
+    }
+    return;
+  }
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     const float l = ls[qt][0];      // all 32 rows of the ones.P^T tile hold the same sum over every key (both lane halves included)
@@ -283,159 +358,12 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
 // (w&1): partial S^T over its 256 d, exchanged with the partner wave through LDS; both then run the
 // same softmax and each accumulates O^T for its own 256 d.  32-key tiles.
 // ------------------------------------------------------------------------------------------------
-#define ATTN512_PKK 1040
-#define ATTN512_PKV 72    /* 18 dwords: conflict-free ds_read_b64 across the 32 d-rows of a half-wave */
-#define ATTN512_KS_BYTES (32 * ATTN512_PKK)
-#define ATTN512_VS_BYTES (512 * ATTN512_PKV)
 #define ATTN512_X_BYTES (8 * 16 * 64 * 4)
-#define ATTN512_SMEM (ATTN512_KS_BYTES + ATTN512_VS_BYTES + ATTN512_X_BYTES)
-
-__global__ void __launch_bounds__(512) attn_d512_sync_kernel(AttnParams p) {
-  SDM_DYN_SMEM(smem);
-  constexpr int PKK = ATTN512_PKK, PKV = ATTN512_PKV;
-  unsigned char* Ks = smem;
-  unsigned char* Vs = smem + ATTN512_KS_BYTES;
-  float* Xs = (float*)(smem + ATTN512_KS_BYTES + ATTN512_VS_BYTES);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int hi = lane >> 5, l31 = lane & 31;
-  const int qgp = wave >> 1, dh = wave & 1;
-  int b, head_unused, qblk;
-  if (!attn_block_coords(p, blockIdx.x, b, head_unused, qblk)) return;     // XCD-aware 1-D grid (one image per XCD at a time)
-  const int q0 = qblk * 128 + qgp * 32;
-
-  f16x8 qf[16];
-  {
-    int qrow = q0 + l31;
-    if (qrow > p.Lq - 1) qrow = p.Lq - 1;
-    const half_t* qp = p.q + (size_t)b * p.q_bs + (size_t)qrow * p.ldq + dh * 256 + hi * 8;
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) qf[ks] = *(const f16x8*)(qp + ks * 16);
-  }
-  f32x16 o[8];
-#pragma unroll
-  for (int dt = 0; dt < 8; ++dt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[dt][r] = 0.0f;
-  float m_i = SDM_NEG_BIG, l_i = 0.0f;
-
-  const half_t* kbase = p.k + (size_t)b * p.k_bs;
-  const half_t* vbase = p.vt + (size_t)b * p.vt_bs;
-  const int ntiles = (p.Lk + 31) / 32;
-
-  for (int t = 0; t < ntiles; ++t) {
-    const int k0 = t * 32;
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int v = tid + i * 512;
-      {  // K tile: 32 keys x 64 vectors
-        const int row = v >> 6, part = v & 63;
-        int kr = k0 + row;
-        if (kr > p.Lk - 1) kr = p.Lk - 1;                    // unconditional load; keys >= Lk are masked after QK^T
-        *(f16x8*)(Ks + row * PKK + part * 16) = *(const f16x8*)(kbase + (size_t)kr * p.ldk + part * 8);
-      }
-      {  // V^T tile: 512 d x 4 vectors (32 keys)
-        const int row = v >> 2, part = v & 3;
-        const f16x8 vv = *(const f16x8*)(vbase + (size_t)row * p.ldvt + k0 + part * 8);
-        f16x4 lo, hi4;                                       // rows are only 8-byte aligned (pitch 72)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { lo[e] = vv[e]; hi4[e] = vv[4 + e]; }
-        *(f16x4*)(Vs + row * PKV + part * 16) = lo;
-        *(f16x4*)(Vs + row * PKV + part * 16 + 8) = hi4;
-      }
-    }
-    __syncthreads();
-    f32x16 s;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = 0.0f;
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const f16x8 a = *(const f16x8*)(Ks + l31 * PKK + (dh * 256 + ks * 16 + hi * 8) * 2);
-      s = SDM_MFMA_32x32x16_F16(a, qf[ks], s);
-    }
-    float* xme = Xs + wave * (16 * 64);
-    const float* xpt = Xs + (wave ^ 1) * (16 * 64);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) xme[r * 64 + lane] = s[r];
-    __syncthreads();
-    float mx = SDM_NEG_BIG;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      float x = (s[r] + xpt[r * 64 + lane]) * p.scale_log2e;
-      if (key >= p.Lk) x = SDM_NEG_BIG;
-      s[r] = x;
-      mx = fmaxf(mx, x);
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float mnew = fmaxf(m_i, mx);
-    const float alpha = sdm_exp2(m_i - mnew);
-    m_i = mnew;
-    float rs = 0.0f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float pv = sdm_exp2(s[r] - mnew);
-      s[r] = pv;
-      rs += pv;
-    }
-    l_i = l_i * alpha + rs;
-#pragma unroll
-    for (int dt = 0; dt < 8; ++dt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      f16x8 pf;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) pf[j] = (half_t)s[8 * u + j];
-#pragma unroll
-      for (int dt = 0; dt < 8; ++dt) {
-        const unsigned char* vp = Vs + (dh * 256 + dt * 32 + l31) * PKV + (16 * u + 4 * hi) * 2;
-        const f16x4 v0 = *(const f16x4*)vp;
-        const f16x4 v1 = *(const f16x4*)(vp + 16);
-        f16x8 vf;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { vf[e] = v0[e]; vf[4 + e] = v1[e]; }
-        o[dt] = SDM_MFMA_32x32x16_F16(vf, pf, o[dt]);
-      }
-    }
-  }
-
-  l_i += __shfl_xor(l_i, 32);
-  const float inv = 1.0f / l_i;
-  // epilogue: two passes of 4 d-tiles (128 d) through per-wave LDS staging [32 q][128 d] fp16, pitch 272
-  constexpr int PS = 272;
-  unsigned char* stg = smem + wave * (32 * PS);
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    __syncthreads();
-#pragma unroll
-    for (int d4 = 0; d4 < 4; ++d4) {
-      const int dt = half * 4 + d4;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f16x4 h;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) h[e] = (half_t)(o[dt][4 * g + e] * inv);
-        *(f16x4*)(stg + l31 * PS + (d4 * 32 + 8 * g + 4 * hi) * 2) = h;
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int pass = 0; pass < 8; ++pass) {
-      const int row = pass * 4 + (lane >> 4), part = lane & 15;
-      const int qg = q0 + row;
-      if (qg < p.Lq)
-        *(f16x8*)(p.o + (size_t)b * p.o_bs + (size_t)qg * p.ldo + dh * 256 + half * 128 + part * 8) =
-            *(const f16x8*)(stg + row * PS + part * 16);
-    }
-  }
-}
 
 // ------------------------------------------------------------------------------------------------
-// d = 512, pipelined: same work split as attn_d512_sync_kernel (8 waves = 4 query groups x 2 d-halves), but the K and
+// d = 512, pipelined (8 waves = 4 query groups x 2 d-halves as described above): the K and
 // V^T tiles arrive by LDS-DMA into DOUBLE-BUFFERED, unpadded, XOR-swizzled LDS images, so tile t+1 streams in while
-// tile t is multiplied (the synchronous kernel spends ~4/5 of its time waiting on load -> LDS write -> barrier chains;
+// tile t is multiplied (a synchronous load -> LDS write -> barrier version spent ~4/5 of its time waiting;
 // there are no registers left to prefetch through).  LDS: 2 x 32 KB K + 2 x 32 KB V^T + 32 KB exchange = all 160 KB.
 //   K image  [32 rows][64 chunks of 16 B]: row rho holds key k0 + pi(rho), chunk position c' holds source chunk
 //            c' ^ (rho & 15)  -> conflict-free ds_read_b128 down a column of 16 rows.
@@ -571,6 +499,35 @@ __global__ void __launch_bounds__(512) attn_d512_kernel(AttnParams p) {
 
   l_i += __shfl_xor(l_i, 32);
   const float inv = 1.0f / l_i;
+  if (p.o_f32) {                   // fp32 output (precise-mode graphs): [32 q][128 d] fp32 staging per wave, pitch 528 B
+    constexpr int PF = 528;
+    unsigned char* stf = smem + wave * (32 * PF);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      __syncthreads();
+#pragma unroll
+      for (int d4 = 0; d4 < 4; ++d4) {
+        const int dt = half * 4 + d4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 h;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) h[e] = o[dt][4 * g + e] * inv;
+          *(f32x4*)(stf + l31 * PF + (d4 * 32 + 8 * g + 4 * hi) * 4) = h;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int pass = 0; pass < 16; ++pass) {
+        const int row = pass * 2 + (lane >> 5), part = lane & 31;
+        const int qg = q0 + row;
+        if (qg < p.Lq)
+          *(f32x4*)((float*)p.o + (size_t)b * p.o_bs + (size_t)qg * p.ldo + dh * 256 + half * 128 + part * 4) =
+              *(const f32x4*)(stf + row * PF + part * 16);
+      }
+    }
+    return;
+  }
   constexpr int PS = 272;
   unsigned char* stg = smem + wave * (32 * PS);
 #pragma unroll

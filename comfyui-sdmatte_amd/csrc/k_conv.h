@@ -39,10 +39,13 @@ struct ConvParams {
   int pad_t, pad_l;
   long M;                               // NTAPS==1: number of rows (N*H*W)
   const half_t* w;                      // packed weights, K16 layout
+  const half_t* w_lo;                   // SPLIT kernels: fp16 low parts of the (scaled) weights, same layout: w = (w_hi + w_lo) * acc_scale
+  float acc_scale;                      // multiplies the accumulator in the epilogue (undoes the power-of-two weight pre-scale; 1 otherwise)
+  size_t out_lo_off;                    // out_f32 == 2: element offset of the low-part plane behind the high-part plane
   const float* bias;                    // [nvariants][Cout_pad]
   const int* bias_sel;                  // [N] variant per image or null
   int Cout_pad;                         // GEMM N (multiple of 32)
-  void* out; int out_f32;
+  void* out; int out_f32;               // 0: fp16, 1: fp32, 2: two fp16 planes hi | lo with hi + lo = the fp32 value (attention operands of the precise mode)
   int Cout_store;                       // row stride (channels) of the output tensor
   int Cout_valid;                       // number of (post-epilogue) channels actually stored (mult of 4)
   int out_ch_off;                       // channel offset inside the output row (mult of 4)
@@ -60,7 +63,7 @@ struct ConvParams {
                                         // layer (reduced by gn_partials_scale_shift_kernel); NTAPS==9 or one image per launch
 };
 
-template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN, int DB = 0>
+template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN, int DB = 0, int SPLIT = 0>
 struct ConvCfg {
   static constexpr int NTHREADS = 64 * WM * WN;
   static constexpr int BM = TH * TW;
@@ -75,25 +78,33 @@ struct ConvCfg {
   static constexpr int A_BYTES = HP * PITCH;
   static constexpr int B_BYTES = NTAPS * BN * PITCH;
   static constexpr int STG_BYTES = WM * WN * 32 * WTN * 4;
-  static constexpr int TILE_BYTES = A_BYTES + B_BYTES;          // one K-chunk of A halo + B taps
+  static constexpr int TILE_BYTES = (SPLIT ? 2 : 1) * A_BYTES + B_BYTES;   // one K-chunk of A halo (SPLIT: high and low parts) + B taps
   static constexpr int SMEM = ((DB ? 2 : 1) * TILE_BYTES) > STG_BYTES ? ((DB ? 2 : 1) * TILE_BYTES) : STG_BYTES;
   static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of 32x32");
   static_assert(KC % 16 == 0, "KC multiple of the MFMA K (16)");
   static_assert(!DB || KC == 16, "swizzled double-buffered tiles assume 2 halves per row");
+  static_assert(!(DB && SPLIT), "the split-operand kernels use the single-buffered tile");
 };
 
-template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN, int IN_F32, int DB, int GN>
+// SPLIT = 1 ("precise" mode): every operand enters the MFMAs as a pair of fp16 values hi + lo (22 significant
+// bits).  The fp32 activation (after the fused GroupNorm/SiLU, if any) is split while it is staged: hi = fp16(x),
+// lo = fp16(x - hi) into two LDS halo tiles; the weights were split (and pre-scaled by a power of two so that the low parts stay
+// fp16-normal) when they were packed: w * 2^k = w_hi + w_lo.  Per K-chunk the accumulators receive
+//   A_hi.B_hi + A_lo.B_hi   (B tile = w_hi),   then   A_hi.B_lo   (B tile re-staged with w_lo);
+// the lo.lo term (2^-22 relative) is dropped.  fp32 accumulation as before; the epilogue multiplies by acc_scale = 2^-k.
+template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN, int IN_F32, int DB, int GN, int SPLIT = 0>
 // second argument = minimum waves per SIMD: the big 4-wave tiles keep 2 blocks/CU resident (2 waves/SIMD, <= 256 registers)
 __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BN == 128) ? 2 : 1)
 conv_mfma_kernel(ConvParams p) {
-  using C = ConvCfg<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN, DB>;
+  static_assert(!SPLIT || IN_F32, "split operands are produced from fp32 activations");
+  using C = ConvCfg<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN, DB, SPLIT>;
   constexpr int NT = C::NTHREADS, MT = C::MT, NTL = C::NTL, PITCH = C::PITCH, KV = C::KV;
   constexpr int HPW = C::HPW, HP = C::HP, WTM = C::WTM, WTN = C::WTN;
   constexpr int A_VEC = HP * KV, B_VEC = NTAPS * BN * KV;
   constexpr int A_PER = (A_VEC + NT - 1) / NT, B_PER = (B_VEC + NT - 1) / NT;
   SDM_DYN_SMEM(smem);
   unsigned char* As = smem;                 // current K-chunk tile (switches between the two halves when DB)
-  unsigned char* Bs = smem + C::A_BYTES;
+  unsigned char* Bs = smem + (SPLIT ? 2 : 1) * C::A_BYTES;      // SPLIT: A_hi | A_lo | B
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -190,6 +201,7 @@ conv_mfma_kernel(ConvParams p) {
     rs1 = sdm_make_rsrc(p.in1 ? (const unsigned char*)p.in1 + base_px * p.C1 * es : (const unsigned char*)p.in0, p.in1 ? (unsigned int)(npx * p.C1 * es) : 0u);
     rsw = sdm_make_rsrc(p.w, (unsigned int)((size_t)Cin * NTAPS * p.Cout_pad * 2));
   }
+  const sdm_rsrc rsw_lo = SPLIT ? sdm_make_rsrc(p.w_lo, (unsigned int)((size_t)Cin * NTAPS * p.Cout_pad * 2)) : rsw;
   // B vector v -> (h = v&1, co = (v>>1)%BN, rest = (v>>1)/BN -> tap = rest%NTAPS, sc = rest/NTAPS) of the K16-packed weights
   const int b_h = tid & 1, b_co = (tid >> 1) % BN, b_rest0 = (tid >> 1) / BN;
   constexpr int B_RSTEP_NUM = NT / 2;                // (v>>1) advances by NT/2 per i
@@ -199,7 +211,7 @@ conv_mfma_kernel(ConvParams p) {
   // raw staging registers (the global loads of chunk k+1 are in flight while chunk k is multiplied)
   u32x4 a_raw[A_PER][IN_F32 ? 2 : 1];
   u32x4 b_raw[B_PER];
-  auto issue_loads = [&](int c0) {
+  auto issue_loads_a = [&](int c0) {
     // every load is unconditional and independent: they are all in flight at once (a per-element `if (ok) load` makes hipcc
     // branch around each load and drain vmcnt(0) per element - measured 4.9 us per K-chunk)
     const bool second = c0 >= p.C0;
@@ -212,6 +224,8 @@ conv_mfma_kernel(ConvParams p) {
       a_raw[i][0] = sdm_buffer_load16(rs, off, 0);
       if (IN_F32) a_raw[i][IN_F32 ? 1 : 0] = sdm_buffer_load16(rs, off, 16);
     }
+  };
+  auto issue_loads_b = [&](int c0, const sdm_rsrc rsb) {
     const unsigned int chunk_row0 = (unsigned int)(c0 / 16) * NTAPS;
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
@@ -219,10 +233,11 @@ conv_mfma_kernel(ConvParams p) {
       const int rest = (2 * BN >= NT) ? (lin / BN) : (b_rest0 + i * (NT / (2 * BN)));
       const int tap = rest % NTAPS, sc = rest / NTAPS;
       const unsigned int voff = ((tid + i * NT) < B_VEC) ? b_voff : SDM_BUF_INVALID;
-      b_raw[i] = sdm_buffer_load16(rsw, voff, (chunk_row0 + (unsigned int)(sc * NTAPS + tap)) * b_row_bytes);
+      b_raw[i] = sdm_buffer_load16(rsb, voff, (chunk_row0 + (unsigned int)(sc * NTAPS + tap)) * b_row_bytes);
     }
   };
-  auto write_lds = [&](unsigned char* Ad, unsigned char* Bd, int c0w) {
+  auto issue_loads = [&](int c0) { issue_loads_a(c0); issue_loads_b(c0, rsw); };
+  auto write_lds_a = [&](unsigned char* Ad, int c0w) {
     f32x4 gs0, gs1, gh0, gh1;
     if (GN) {                      // the 8 channels of this thread are the same for every i
       const float* tb = gn_tab + c0w + a_part;
@@ -233,7 +248,29 @@ conv_mfma_kernel(ConvParams p) {
     for (int i = 0; i < A_PER; ++i) {
       if (tid + i * NT < A_VEC) {
         f16x8 val;
-        if (GN) {
+        if (SPLIT) {
+          // fp32 value (after the fused GroupNorm / SiLU) -> hi = fp16(y), lo = fp16(y - hi): both halo tiles written here
+          float x[8];
+          const f32x4 lo4 = __builtin_bit_cast(f32x4, a_raw[i][0]), hi4 = __builtin_bit_cast(f32x4, a_raw[i][IN_F32 ? 1 : 0]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { x[e] = lo4[e]; x[4 + e] = hi4[e]; }
+          const bool inside = a_pix[i] >= 0;
+          f16x8 vlo;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float y = x[e];
+            if (GN) {
+              y = y * (e < 4 ? gs0[e & 3] : gs1[e & 3]) + (e < 4 ? gh0[e & 3] : gh1[e & 3]);
+              if (p.gn_silu) y = y * sdm_rcp(1.0f + sdm_exp2(-y * SDM_LOG2E));
+              if (!inside) y = 0.0f;                     // zero padding stays zero AFTER the normalisation
+            }
+            const half_t h = (half_t)y;
+            val[e] = h;
+            vlo[e] = (half_t)(y - (float)h);
+          }
+          const int hp_s = a_hp0 + i * (NT / KV);
+          *(f16x8*)(Ad + C::A_BYTES + hp_s * PITCH + a_part * 2) = vlo;
+        } else if (GN) {
           float x[8];
           if (IN_F32) {
             const f32x4 lo = __builtin_bit_cast(f32x4, a_raw[i][0]), hi4 = __builtin_bit_cast(f32x4, a_raw[i][IN_F32 ? 1 : 0]);
@@ -262,6 +299,8 @@ conv_mfma_kernel(ConvParams p) {
         *(f16x8*)(Ad + hp_w * PITCH + (DB ? ((((a_part >> 3) ^ (hp_w >> 3)) & 1) << 4) : (a_part * 2))) = val;
       }
     }
+  };
+  auto write_lds_b = [&](unsigned char* Bd) {
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
       if ((tid + i * NT) < B_VEC) {
@@ -273,26 +312,9 @@ conv_mfma_kernel(ConvParams p) {
       }
     }
   };
+  auto write_lds = [&](unsigned char* Ad, unsigned char* Bd, int c0w) { write_lds_a(Ad, c0w); write_lds_b(Bd); };
 
-  issue_loads(0);
-  if (DB) {                      // double-buffered tiles: chunk 0 is staged up front, ONE barrier per K-chunk afterwards
-    if (GN) __syncthreads();     // gn_tab filled
-    write_lds(As, Bs, 0);
-    __syncthreads();
-  }
-  for (int c0 = 0; c0 < Cin; c0 += KC) {
-    if (DB) {
-      const int cur = (c0 / KC) & 1;
-      As = smem + cur * C::TILE_BYTES;
-      Bs = As + C::A_BYTES;
-      if (c0 + KC < Cin) issue_loads(c0 + KC);       // in flight during the MFMAs below
-    } else {
-      __syncthreads();            // every wave has finished reading the previous chunk from LDS
-      if (!(p.ablate & 2) || c0 == 0) write_lds(As, Bs, c0);
-      __syncthreads();
-      if (c0 + KC < Cin && !(p.ablate & 1)) issue_loads(c0 + KC);
-      if ((p.ablate & 4) && c0 > 0) continue;
-    }
+  auto mfma_chunk = [&](const unsigned char* Ap) {
     // ---- MFMA over taps and K sub-steps ----
     // Software-pipelined fragment reads with a pinned schedule: B fragments of step s+1 are read at the top of step s
     // (double buffer, 2*NTL regs x4), each A fragment is re-read IN PLACE for step s+1 right after the MFMAs that consumed it.
@@ -303,10 +325,10 @@ conv_mfma_kernel(ConvParams p) {
       const int tap = step / (KC / 16), ks = step % (KC / 16);
       if (DB) {
         const int row = abase[i] + ((NTAPS == 9) ? (tap / 3) * HPW + (tap % 3) : 0);
-        return (const f16x8*)(As + row * PITCH + ((((lane >> 5) ^ (row >> 3)) & 1) << 4));
+        return (const f16x8*)(Ap + row * PITCH + ((((lane >> 5) ^ (row >> 3)) & 1) << 4));
       }
       const int toff = (NTAPS == 9) ? ((tap / 3) * HPW + (tap % 3)) * PITCH : 0;
-      return (const f16x8*)(As + abase[i] + toff + ks * 32);
+      return (const f16x8*)(Ap + abase[i] + toff + ks * 32);
     };
     auto b_addr = [&](int step, int j) {
       const int tap = step / (KC / 16), ks = step % (KC / 16);
@@ -323,7 +345,7 @@ conv_mfma_kernel(ConvParams p) {
 #pragma unroll
       for (int ks = 0; ks < KC / 16; ++ks) {
         f16x8 fav[2], fbv[3][NTL];
-        auto av = [&](int s) { return *(const f16x8*)(As + abase[0] + ((s % NR) * HPW + (s / NR)) * PITCH + ks * 32); };
+        auto av = [&](int s) { return *(const f16x8*)(Ap + abase[0] + ((s % NR) * HPW + (s / NR)) * PITCH + ks * 32); };
         auto bv = [&](int dy, int dx, int j) { return *(const f16x8*)(Bs + (dy * 3 + dx) * BN * PITCH + bbase[j] + ks * 32); };
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
@@ -374,6 +396,45 @@ conv_mfma_kernel(ConvParams p) {
       }
     }
     }
+  };
+
+  issue_loads(0);
+  if (DB) {                      // double-buffered tiles: chunk 0 is staged up front, ONE barrier per K-chunk afterwards
+    if (GN) __syncthreads();     // gn_tab filled
+    write_lds(As, Bs, 0);
+    __syncthreads();
+  }
+  for (int c0 = 0; c0 < Cin; c0 += KC) {
+    if (SPLIT) {
+      __syncthreads();            // every wave has finished reading the previous chunk from LDS
+      write_lds_a(As, c0);        // A_hi and A_lo halo tiles
+      write_lds_b(Bs);            // w_hi taps of this chunk
+      __syncthreads();
+      issue_loads_b(c0, rsw_lo);  // w_lo taps of this chunk: in flight during the two MFMA passes below
+      mfma_chunk(As);                       // A_hi . w_hi
+      mfma_chunk(As + C::A_BYTES);          // A_lo . w_hi
+      __syncthreads();            // every wave is done with the w_hi taps
+      write_lds_b(Bs);
+      __syncthreads();
+      // next chunk's activations and w_hi taps: in flight during the third pass (issued only now, when the B staging
+      // registers are free again: the A + B staging sets together with 128 accumulators are what fits in 256 registers)
+      if (c0 + KC < Cin) { issue_loads_a(c0 + KC); issue_loads_b(c0 + KC, rsw); }
+      mfma_chunk(As);                       // A_hi . w_lo
+      continue;
+    }
+    if (DB) {
+      const int cur = (c0 / KC) & 1;
+      As = smem + cur * C::TILE_BYTES;
+      Bs = As + C::A_BYTES;
+      if (c0 + KC < Cin) issue_loads(c0 + KC);       // in flight during the MFMAs below
+    } else {
+      __syncthreads();            // every wave has finished reading the previous chunk from LDS
+      if (!(p.ablate & 2) || c0 == 0) write_lds(As, Bs, c0);
+      __syncthreads();
+      if (c0 + KC < Cin && !(p.ablate & 1)) issue_loads(c0 + KC);
+      if ((p.ablate & 4) && c0 > 0) continue;
+    }
+    mfma_chunk(As);
     if (DB) {
       if (c0 + KC < Cin) {          // the other half was last read one iteration ago, before the previous barrier
         unsigned char* An = smem + (((c0 / KC) & 1) ^ 1) * C::TILE_BYTES;
@@ -452,7 +513,7 @@ conv_mfma_kernel(ConvParams p) {
         const f32x4 t = *(const f32x4*)(stg + row * WTN + lc);
         float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (t[e] + bu[e]) * p.out_scale;
+        for (int e = 0; e < 4; ++e) v[e] = ((SPLIT ? t[e] * p.acc_scale : t[e]) + bu[e]) * p.out_scale;
         if (p.res) {
           if (p.res_f32) {
             const f32x4 r4 = __builtin_bit_cast(f32x4, rr[pass]);
@@ -466,11 +527,17 @@ conv_mfma_kernel(ConvParams p) {
         }
         if (valid && oc < p.Cout_valid && !(p.ablate & 8)) {
           const size_t oidx = (opix_base + (size_t)lp) * p.Cout_store + p.out_ch_off + oc;
-          if (p.out_f32) {
+          if (p.out_f32 == 1) {
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = v[e];
             *(f32x4*)((float*)p.out + oidx) = o;
+          } else if (p.out_f32 == 2) {                  // hi | lo fp16 planes (operands of the split-precision attention)
+            f16x4 oh, ol;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { oh[e] = (half_t)v[e]; ol[e] = (half_t)(v[e] - (float)oh[e]); }
+            *(f16x4*)((half_t*)p.out + oidx) = oh;
+            *(f16x4*)((half_t*)p.out + p.out_lo_off + oidx) = ol;
           } else {
             f16x4 o;
 #pragma unroll
@@ -511,11 +578,23 @@ conv_mfma_kernel(ConvParams p) {
         const bool valid = pix_of(i, row, lp);
         const f32x4 t = *(const f32x4*)(stg + row * WTN + ucol);
         const f32x4 g4 = *(const f32x4*)(stg + row * WTN + ucol + 32);
-        f16x4 o;
+        f32x4 o4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (half_t)(((t[e] + bu[e]) * sdm_gelu_erf(g4[e] + bg[e])) * p.out_scale);
-        if (valid && oc < p.Cout_valid && !(p.ablate & 8))
-          *(f16x4*)((half_t*)p.out + (opix_base + (size_t)lp) * p.Cout_store + p.out_ch_off + oc) = o;
+        for (int e = 0; e < 4; ++e) {
+          const float u = (SPLIT ? t[e] * p.acc_scale : t[e]) + bu[e], g = (SPLIT ? g4[e] * p.acc_scale : g4[e]) + bg[e];
+          o4[e] = (u * sdm_gelu_erf(g)) * p.out_scale;
+        }
+        if (valid && oc < p.Cout_valid && !(p.ablate & 8)) {
+          const size_t oidx = (opix_base + (size_t)lp) * p.Cout_store + p.out_ch_off + oc;
+          if (p.out_f32) {
+            *(f32x4*)((float*)p.out + oidx) = o4;
+          } else {
+            f16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (half_t)o4[e];
+            *(f16x4*)((half_t*)p.out + oidx) = o;
+          }
+        }
       }
       SDM_WAVE_SYNC();
     }
@@ -556,8 +635,10 @@ SDM_DEV_INLINE int pack_src_row(int co, int O, int co_off, int geglu) {
   return (o >= 0 && o < O) ? o : -1;
 }
 
+// wp_lo != null (precise mode): the scaled weight v is stored as the fp16 pair hi = fp16(v), lo = fp16(v - hi) in two tensors of
+// the same layout (`scale` then carries the power-of-two pre-scale that keeps the low parts in the fp16 normal range).
 __global__ void pack_conv_weight_kernel(const float* __restrict__ w, half_t* __restrict__ wp, int O, int I, int ntaps, int Cin_pad,
-                                        int Cout_pad, int ci_off, int co_off, int geglu, float scale) {
+                                        int Cout_pad, int ci_off, int co_off, int geglu, float scale, half_t* __restrict__ wp_lo) {
   const size_t total = (size_t)Cin_pad * ntaps * Cout_pad;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int k = idx % 16;
@@ -570,7 +651,10 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, half_t* __r
     if (o < 0) continue;
     float v = 0.0f;
     if (ci >= 0 && ci < I) v = w[((size_t)o * I + ci) * ntaps + tap];
-    wp[idx] = (half_t)(v * scale);
+    const float vs = v * scale;
+    const half_t hi = (half_t)vs;
+    wp[idx] = hi;
+    if (wp_lo) wp_lo[idx] = (half_t)(vs - (float)hi);
   }
 }
 

@@ -39,8 +39,24 @@ SDM_DEV_INLINE float resize_aa_sample(F fetch, int in_h, int in_w, int out_h, in
   return acc;
 }
 
-// image fp32 [B,H,W,3] in [0,1] -> NHWC16 fp16 [B,S,S,16]: ch0..2 = (resize(x)-0.5)/0.5, ch3..15 = 0
-__global__ void prep_image_kernel(const float* __restrict__ img, half_t* __restrict__ out, int B, int H, int W, int S) {
+// one NHWC16 pixel: channels 0..2 = (c0, c1, c2), 3..15 = 0; fp16 (fast graph) or fp32 (precise graph: the first conv splits it)
+SDM_DEV_INLINE void prep_store16(void* out, size_t pix, float c0, float c1, float c2, int out_f32) {
+  if (out_f32) {
+    f32x4 a = {c0, c1, c2, 0.0f}, z = {0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4* o = (f32x4*)((float*)out + pix * 16);
+    o[0] = a; o[1] = z; o[2] = z; o[3] = z;
+  } else {
+    f16x8 a, z;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a[e] = (half_t)0.0f; z[e] = (half_t)0.0f; }
+    a[0] = (half_t)c0; a[1] = (half_t)c1; a[2] = (half_t)c2;
+    *(f16x8*)((half_t*)out + pix * 16) = a;
+    *(f16x8*)((half_t*)out + pix * 16 + 8) = z;
+  }
+}
+
+// image fp32 [B,H,W,3] in [0,1] -> NHWC16 [B,S,S,16]: ch0..2 = (resize(x)-0.5)/0.5, ch3..15 = 0
+__global__ void prep_image_kernel(const float* __restrict__ img, void* __restrict__ out, int out_f32, int B, int H, int W, int S) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)B * S * S) return;
   const int ox = i % S, oy = (i / S) % S, b = i / ((long)S * S);
@@ -52,16 +68,11 @@ __global__ void prep_image_kernel(const float* __restrict__ img, half_t* __restr
     else x = resize_aa_sample([&](int y, int xx) { return pl[((size_t)y * W + xx) * 3]; }, H, W, S, S, oy, ox);
     v[c] = (x - 0.5f) / 0.5f;
   }
-  f16x8 a, z;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { a[e] = (half_t)0.0f; z[e] = (half_t)0.0f; }
-  a[0] = (half_t)v[0]; a[1] = (half_t)v[1]; a[2] = (half_t)v[2];
-  *(f16x8*)(out + (size_t)i * 16) = a;
-  *(f16x8*)(out + (size_t)i * 16 + 8) = z;
+  prep_store16(out, (size_t)i, v[0], v[1], v[2], out_f32);
 }
 
 // trimap fp32 [B,H,W] in [0,1] -> t = resize(x)*2-1: NHWC16 fp16 (ch0..2 = t) and fp32 plane [B,S,S]
-__global__ void prep_trimap_kernel(const float* __restrict__ tri, half_t* __restrict__ out, float* __restrict__ plane, int B, int H,
+__global__ void prep_trimap_kernel(const float* __restrict__ tri, void* __restrict__ out, int out_f32, float* __restrict__ plane, int B, int H,
                                    int W, int S) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)B * S * S) return;
@@ -72,32 +83,20 @@ __global__ void prep_trimap_kernel(const float* __restrict__ tri, half_t* __rest
   else x = resize_aa_sample([&](int y, int xx) { return pl[(size_t)y * W + xx]; }, H, W, S, S, oy, ox);
   const float t = x * 2.0f - 1.0f;
   plane[i] = t;
-  f16x8 a, z;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { a[e] = (half_t)0.0f; z[e] = (half_t)0.0f; }
-  a[0] = (half_t)t; a[1] = (half_t)t; a[2] = (half_t)t;
-  *(f16x8*)(out + (size_t)i * 16) = a;
-  *(f16x8*)(out + (size_t)i * 16 + 8) = z;
+  prep_store16(out, (size_t)i, t, t, t, out_f32);
 }
 
 // already pre-processed core-API inputs: image fp32 NCHW [B,3,S,S], trimap fp32 [B,1,S,S] (in [-1,1])
-__global__ void prep_nchw_kernel(const float* __restrict__ img, const float* __restrict__ tri, half_t* __restrict__ out_img,
-                                 half_t* __restrict__ out_tri, float* __restrict__ plane, int B, int SH, int SW) {
+__global__ void prep_nchw_kernel(const float* __restrict__ img, const float* __restrict__ tri, void* __restrict__ out_img,
+                                 void* __restrict__ out_tri, int out_f32, float* __restrict__ plane, int B, int SH, int SW) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long hw = (long)SH * SW;
   if (i >= B * hw) return;
   const long b = i / hw, pq = i % hw;
-  f16x8 a, t, z;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { a[e] = (half_t)0.0f; t[e] = (half_t)0.0f; z[e] = (half_t)0.0f; }
-  for (int c = 0; c < 3; ++c) a[c] = (half_t)img[(b * 3 + c) * hw + pq];
   const float tv = tri[b * hw + pq];
-  t[0] = (half_t)tv; t[1] = (half_t)tv; t[2] = (half_t)tv;
   plane[i] = tv;
-  *(f16x8*)(out_img + (size_t)i * 16) = a;
-  *(f16x8*)(out_img + (size_t)i * 16 + 8) = z;
-  *(f16x8*)(out_tri + (size_t)i * 16) = t;
-  *(f16x8*)(out_tri + (size_t)i * 16 + 8) = z;
+  prep_store16(out_img, (size_t)i, img[(b * 3 + 0) * hw + pq], img[(b * 3 + 1) * hw + pq], img[(b * 3 + 2) * hw + pq], out_f32);
+  prep_store16(out_tri, (size_t)i, tv, tv, tv, out_f32);
 }
 
 // bias[level][b][i*wk + j] = (1 - (t[b][8*s*i][8*s*j] + 1)/2) * mask_value * log2e, s = 2^level, (hk, wk) = (SH/8, SW/8) >> level.
@@ -142,10 +141,6 @@ __global__ void resize_planes_kernel(const float* __restrict__ in, float* __rest
 __global__ void scale_copy_kernel(const float* __restrict__ in, float* __restrict__ out, long n, float mult) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = in[i] * mult;
-}
-
-__global__ void fill_zero_kernel(uint32_t* __restrict__ p, long n) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = 0u;
 }
 
 // bench helpers only: pseudo-random fill (realistic operand toggling; constant data lets the chip clock ~25 % higher

@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(GN_PSS_THREADS) gn_partials_scale_shift_kernel
 
 // y = act(x*scale + shift) -> fp16 NHWC with C channels (concat materialised)
 __global__ void __launch_bounds__(512) gn_apply_kernel(GnSrc s, const float* __restrict__ scale, const float* __restrict__ shift,
-                                                       half_t* __restrict__ out, int silu, int pix_per_block) {
+                                                       void* __restrict__ out, int out_f32, int silu, int pix_per_block) {
   const int C = s.C0 + s.C1;
   const int CV = C / 8;
   const int slots = blockDim.x / CV;
@@ -174,21 +174,32 @@ __global__ void __launch_bounds__(512) gn_apply_kernel(GnSrc s, const float* __r
   for (int p = p0 + slot; p < p1; p += slots) {
     float v[8];
     sdm_load8_as_f32(src, ((size_t)n * s.HW + p) * Cs + cc, s.in_f32, v);
-    f16x8 o;
+    float y[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float y = v[e] * a[e] + b[e];
-      if (silu) y = sdm_silu(y);
-      o[e] = (half_t)y;
+      y[e] = v[e] * a[e] + b[e];
+      if (silu) y[e] = sdm_silu(y[e]);
     }
-    *(f16x8*)(out + ((size_t)n * s.HW + p) * C + c) = o;
+    const size_t oi = ((size_t)n * s.HW + p) * C + c;
+    if (out_f32) {                                 // precise mode: the consumer splits the fp32 value into an fp16 pair itself
+      f32x4 o0, o1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { o0[e] = y[e]; o1[e] = y[4 + e]; }
+      *(f32x4*)((float*)out + oi) = o0;
+      *(f32x4*)((float*)out + oi + 4) = o1;
+    } else {
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (half_t)y[e];
+      *(f16x8*)((half_t*)out + oi) = o;
+    }
   }
 }
 
-// LayerNorm over the last dim C (multiple of 64, <= 64*LN_MAXV), one wave per row, fp32/fp16 in -> fp16 out.
+// LayerNorm over the last dim C (multiple of 64, <= 64*LN_MAXV), one wave per row, fp32/fp16 in -> fp16 (or fp32) out.
 #define SDM_LN_MAXV 20
 __global__ void __launch_bounds__(256) layernorm_kernel(const void* __restrict__ x, int in_f32, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, half_t* __restrict__ out, long rows, int C,
+                                                        const float* __restrict__ beta, void* __restrict__ out, int out_f32, long rows, int C,
                                                         float eps) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long row = (long)blockIdx.x * (blockDim.x >> 6) + wave;
@@ -220,7 +231,9 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const void* __restrict__
   for (int i = 0; i < SDM_LN_MAXV; ++i) {
     if (i < nv) {
       const int c = i * 64 + lane;
-      out[(size_t)row * C + c] = (half_t)((v[i] - mean) * rstd * gamma[c] + beta[c]);
+      const float y = (v[i] - mean) * rstd * gamma[c] + beta[c];
+      if (out_f32) ((float*)out)[(size_t)row * C + c] = y;
+      else ((half_t*)out)[(size_t)row * C + c] = (half_t)y;
     }
   }
 }

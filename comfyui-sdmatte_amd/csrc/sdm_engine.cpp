@@ -90,8 +90,24 @@ static void launch_conv_t(const ConvParams& p_in, void* stream) {
   const long total_m = (long)p.tiles_m * ((NTAPS == 9) ? p.N : 1);
   p.xcd_chunk = (int)((total_m + 7) / 8);
   const dim3 grid((unsigned)(8L * p.xcd_chunk * p.tiles_n), 1, 1);      // 1-D, XCD-aware mapping in the kernel
-  if (GNOK && p.gn_scale) {      // fused GroupNorm apply: the scale|shift table of the image follows the tiles in LDS
-    const size_t smem = (size_t)C::SMEM + (size_t)(p.C0 + p.C1) * 8;
+  const size_t gn_extra = (size_t)(p.C0 + p.C1) * 8;                    // fused GroupNorm apply: the scale|shift table of the image follows the tiles in LDS
+  if constexpr (!DB) {
+    if (p.w_lo) {                  // precise mode: split-fp16 operands (fp32 activations only)
+      using CS = ConvCfg<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN, 0, 1>;
+      if (GNOK && p.gn_scale) {
+        auto k = conv_mfma_kernel<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN, 1, 0, GNOK, 1>;
+        SDM_SET_SMEM(k, CS::SMEM + 1024 * 8);
+        SDM_LAUNCH(k, grid, dim3(CS::NTHREADS), (size_t)CS::SMEM + gn_extra, stream, p);
+      } else {
+        auto k = conv_mfma_kernel<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN, 1, 0, 0, 1>;
+        SDM_SET_SMEM(k, CS::SMEM);
+        SDM_LAUNCH(k, grid, dim3(CS::NTHREADS), CS::SMEM, stream, p);
+      }
+      return;
+    }
+  }
+  if (GNOK && p.gn_scale) {
+    const size_t smem = (size_t)C::SMEM + gn_extra;
     if (p.in_f32) {
       auto k = conv_mfma_kernel<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN, 1, DB, GNOK>;
       SDM_SET_SMEM(k, C::SMEM + 1024 * 8);
@@ -117,9 +133,9 @@ static void launch_conv_t(const ConvParams& p_in, void* stream) {
 struct ConvCfgInfo { int TH, TW, BN, KC, WM; };
 static const ConvCfgInfo kCfg3s1[] = {{8, 32, 128, 16, 2}, {4, 32, 64, 32, 4}, {8, 8, 64, 16, 2}, {16, 32, 128, 16, 4}, {8, 32, 32, 16, 4}};
 static const ConvCfgInfo kCfg3s2[] = {{4, 32, 64, 16, 4}, {8, 8, 64, 16, 2}, {4, 32, 128, 16, 2}, {8, 32, 128, 16, 4}};
-static const ConvCfgInfo kCfg1[] = {{8, 32, 128, 64, 2}, {4, 32, 64, 64, 4}, {8, 8, 64, 64, 2}, {8, 8, 64, 16, 2}};
+static const ConvCfgInfo kCfg1[] = {{8, 32, 128, 64, 2}, {4, 32, 64, 64, 4}, {8, 8, 64, 64, 2}, {8, 8, 64, 16, 2}, {8, 32, 128, 32, 2}};
 
-static int conv_num_cfgs(int ntaps, int stride) { return ntaps == 9 ? (stride == 1 ? 5 : 4) : 4; }
+static int conv_num_cfgs(int ntaps, int stride) { return ntaps == 9 ? (stride == 1 ? 5 : 4) : 5; }
 static const ConvCfgInfo* conv_cfg_table(int ntaps, int stride) { return ntaps == 9 ? (stride == 1 ? kCfg3s1 : kCfg3s2) : kCfg1; }
 
 static bool conv_cfg_ok(const ConvCfgInfo& c, const ConvParams& p) {
@@ -140,6 +156,7 @@ static int conv_pick_cfg(int ntaps, int stride, const ConvParams& p) {
     if (!conv_cfg_ok(t[i], p)) continue;
     if (ntaps == 9 && stride == 1 && i >= 3) continue;          // cfg 3 / 4: variants of cfg 0, substituted below
     if (ntaps == 9 && stride == 2 && i >= 2) continue;          // cfg 2: forced only; cfg 3: substituted below
+    if (ntaps == 1 && i >= 4) continue;                         // cfg 4: the fp32-input form of cfg 0, substituted below
     long blocks;
     if (ntaps == 9) {
       if (t[i].TW > 8 && p.Wout < 24) continue;   // 32-wide strips would be mostly padding
@@ -162,6 +179,9 @@ static int conv_pick_cfg(int ntaps, int stride, const ConvParams& p) {
       // down-samplers) once there is a block for every CU
       if (ntaps == 9 && stride == 2 && i == 0 && conv_cfg_ok(t[3], p) &&
           (long)p.N * sdm_cdiv(p.Hout, 8) * sdm_cdiv(p.Wout, 32) * sdm_cdiv(p.Cout_pad, 128) >= 256) return 3;
+      // fp32 activations into the 256x128 GEMM tile: K-chunks of 32 (the 64-channel chunk needs 64 staging registers on top of
+      // the 128 accumulators and spills)
+      if (ntaps == 1 && i == 0 && p.in_f32 && conv_cfg_ok(t[4], p)) return 4;
       return i;
     }
     if (blocks > best_blocks) { best = i; best_blocks = blocks; }
@@ -191,6 +211,7 @@ static int launch_conv(int ntaps, int stride, int cfg, const ConvParams& p, void
       case 1: launch_conv_t<1, 1, 4, 32, 64, 64, 4, 1>(p, stream); return 0;
       case 2: launch_conv_t<1, 1, 8, 8, 64, 64, 2, 1>(p, stream); return 0;
       case 3: launch_conv_t<1, 1, 8, 8, 64, 16, 2, 1>(p, stream); return 0;
+      case 4: launch_conv_t<1, 1, 8, 32, 128, 32, 2, 2>(p, stream); return 0;
     }
   }
   return -1;
@@ -205,7 +226,12 @@ struct ConvL {
   size_t w_off = 0, b_off = 0;
   half_t* w = nullptr;
   float* b = nullptr;
+  // precise mode (sdm_config::precise_mask has the layer's stage bit): weights are packed as fp16 pairs w * 2^w_exp = hi + lo
+  int stage = 0, split = 0, w_exp = 0;
+  size_t wlo_off = 0;
+  half_t* w_lo = nullptr;
 };
+static const int kSplitWeightExp = 8;      // pre-scale 2^8: typical |w| ~ 1e-2 .. 1 -> low parts ~ 1e-3 .. 1e-1 * 2^-4: fp16-normal
 struct NormL {
   int C = 0;
   size_t g_off = 0, b_off = 0;
@@ -236,6 +262,8 @@ struct T {  // NHWC activation tensor living in the arena
   long rows() const { return (long)N * H * W; }
 };
 
+// activation element formats (T::f32): 0 fp16, 1 fp32, 2 two fp16 planes hi | lo (split-precision attention operands)
+static inline size_t fmt_bytes(int f) { return f ? 4 : 2; }
 static const int kMaxVariants = 8;
 // conditioning of one image: opacity class + either 4 box coordinates (kind 0: bbox_embedding) or N point coordinates
 // (kind 1: point_embedding), meta_arch.py:147-197 / replace.py:446-457
@@ -286,6 +314,7 @@ struct sdm_ctx {
   size_t h_time1w, h_time1b, h_time2w, h_time2b, h_bbox1w, h_bbox1b, h_bbox2w, h_bbox2b, h_auxw, h_auxb;
   size_t h_point1w, h_point1b, h_point2w, h_point2b;
   std::vector<Variant> variants;
+  int act_f32 = 0;             // precise_mask != 0: every activation that is fp16 in the fast graph is kept in fp32
   int* d_bias_sel = nullptr;   // [max batch]
   int bias_sel_cap = 0;
   // activation arena
@@ -307,6 +336,7 @@ struct sdm_ctx {
   std::string prof_dump;   // per-launch CSV of the last profiled forward
 #ifndef SDM_EMU
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;   // ordering against the caller's stream (SDM_PTR_DEVICE calls)
 #endif
 };
 
@@ -334,6 +364,7 @@ static std::string g_create_err;
 struct Builder {
   sdm_ctx* e;
   size_t woff = 0;
+  int stage = 0;           // sdm_precise_stage of the layers being built
   explicit Builder(sdm_ctx* c) : e(c) {}
   int conv(const std::string& name, int ntaps, int I_pad16_src, int O, int geglu = 0) {
     ConvL L;
@@ -343,6 +374,9 @@ struct Builder {
     L.geglu = geglu;
     L.w_off = woff; woff += rupz((size_t)L.Cin_pad * ntaps * L.Cout_pad * 2, 256);
     L.b_off = woff; woff += rupz((size_t)L.Cout_pad * 4, 256);
+    L.stage = stage;
+    L.split = (e->cfg.precise_mask & stage) ? 1 : 0;
+    if (L.split) { L.w_exp = kSplitWeightExp; L.wlo_off = woff; woff += rupz((size_t)L.Cin_pad * ntaps * L.Cout_pad * 2, 256); }
     e->convs.push_back(L);
     return (int)e->convs.size() - 1;
   }
@@ -399,6 +433,9 @@ struct Builder {
     return r;
   }
   VaeAttnB vae_attn(const std::string& p, int C) {
+    const int outer = stage;
+    stage = SDM_PRECISE_VAE_ATTN_LIN;
+    struct Restore { int& s; int v; ~Restore() { s = v; } } restore{stage, outer};
     VaeAttnB a; a.C = C;
     a.gn = norm_named(p + ".group_norm", C);
     a.qkv = conv(p + ".qkv", 1, C, 3 * C);
@@ -413,6 +450,9 @@ struct Builder {
     return a;
   }
   TfB transformer(const std::string& p, int C, int heads, int ctx) {
+    const int outer = stage;
+    stage = SDM_PRECISE_UNET_TF;
+    struct Restore { int& s; int v; ~Restore() { s = v; } } restore{stage, outer};
     TfB t; t.C = C; t.heads = heads;
     t.gn = norm_named(p + ".norm", C);
     t.proj_in = conv_named(p + ".proj_in", 1, C, C);
@@ -453,6 +493,7 @@ static void build_model(sdm_ctx* e) {
   const int* vc = c.vae_channels;
   const int lc = 4;
   // ---- VAE encoder ----
+  B.stage = SDM_PRECISE_VAE_ENC;
   e->enc_conv_in = B.conv_named("vae.encoder.conv_in", 9, 3, vc[0]);
   int cprev = vc[0];
   e->enc_res.resize(4);
@@ -469,6 +510,7 @@ static void build_model(sdm_ctx* e) {
   e->enc_norm_out = B.norm_named("vae.encoder.conv_norm_out", cm);
   e->enc_conv_out = B.conv_named("vae.encoder.conv_out", 9, cm, 2 * lc);
   e->quant = B.conv_named("vae.quant_conv", 1, 2 * lc, 2 * lc);
+  B.stage = SDM_PRECISE_VAE_DEC;
   e->post_quant = B.conv_named("vae.post_quant_conv", 1, lc, lc);
   // ---- VAE decoder ----
   e->dec_conv_in = B.conv_named("vae.decoder.conv_in", 9, lc, cm);
@@ -487,6 +529,7 @@ static void build_model(sdm_ctx* e) {
   e->dec_norm_out = B.norm_named("vae.decoder.conv_norm_out", vc[0]);
   e->dec_conv_out = B.conv_named("vae.decoder.conv_out", 9, vc[0], 3);
   // ---- U-Net ----
+  B.stage = SDM_PRECISE_UNET_RES;
   const int* uc = c.unet_channels;
   const int te = uc[0] * 4, ctx = c.cross_attention_dim;
   e->u_conv_in = B.conv_named("unet.conv_in", 9, c.unet_in_channels, uc[0]);
@@ -547,7 +590,7 @@ static void build_model(sdm_ctx* e) {
 // ------------------------------------------------------------------------------------------------
 static T talloc(sdm_ctx* e, int N, int H, int W, int C, int f32) {
   T t; t.N = N; t.H = H; t.W = W; t.C = C; t.f32 = f32;
-  t.bytes = rupz((size_t)N * H * W * C * (f32 ? 4 : 2), 256);
+  t.bytes = rupz((size_t)N * H * W * C * fmt_bytes(f32), 256);
   // first fit in the free list
   for (auto it = e->freelist.begin(); it != e->freelist.end(); ++it) {
     if (it->second >= t.bytes) {
@@ -637,6 +680,12 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
   p.w = L.w; p.bias = a.bias_override ? a.bias_override : L.b; p.bias_sel = a.bias_sel;
   p.Cout_pad = L.Cout_pad;
   p.out = a.out->p; p.out_f32 = a.out->f32; p.Cout_store = a.out->C;
+  p.out_lo_off = (size_t)a.out->rows() * a.out->C;
+  p.acc_scale = 1.0f;
+  if (L.split) {
+    if (!p.in_f32) SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: split-precision layers take fp32 activations", L.name.c_str());
+    p.w_lo = L.w_lo; p.acc_scale = ldexpf(1.0f, -L.w_exp);
+  }
   const int nout = L.geglu ? L.Cout_pad / 2 : L.Cout_pad;
   p.Cout_valid = a.cout_valid >= 0 ? a.cout_valid : std::min(nout, a.out->C - a.out_ch_off);
   p.out_ch_off = a.out_ch_off;
@@ -660,7 +709,7 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
   if (a.gn_scale && !(L.ntaps == 9 && a.stride == 1 && (cfg == 0 || cfg == 4) && p.C0 + p.C1 <= 1024))
     SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: fused GroupNorm requested for an unsupported tile configuration", L.name.c_str());
   if (a.out->want_stats) {
-    if (L.geglu || a.out_ch_off) SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: fused statistics unsupported with this epilogue", L.name.c_str());
+    if (L.geglu || a.out_ch_off || p.out_f32 == 2) SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: fused statistics unsupported with this epilogue", L.name.c_str());
     const ConvCfgInfo& ci = conv_cfg_table(L.ntaps, a.stride)[cfg];
     const long tiles = (L.ntaps == 9) ? (long)sdm_cdiv(p.Hout, ci.TH) * sdm_cdiv(p.Wout, ci.TW)
                                       : ((long)p.Hout * p.Wout + ci.TH * ci.TW - 1) / (ci.TH * ci.TW);
@@ -745,7 +794,7 @@ static int gn_scale_shift(sdm_ctx* e, const void* in0, const void* in1, int C0, 
 }
 
 static int op_groupnorm_raw(sdm_ctx* e, const void* in0, const void* in1, int C0, int C1, int in_f32, int N, int HW, int groups,
-                            const float* gamma, const float* beta, float eps, int silu, half_t* out, const float* st0 = nullptr,
+                            const float* gamma, const float* beta, float eps, int silu, void* out, int out_f32, const float* st0 = nullptr,
                             int rows0 = 0, const float* st1 = nullptr, int rows1 = 0, bool have_stats = false) {
   const int C = C0 + C1;
   T scratch; float* scale; float* shift;
@@ -758,8 +807,8 @@ static int op_groupnorm_raw(sdm_ctx* e, const void* in0, const void* in1, int C0
     int ppb = std::max(slots * 8, sdm_cdiv(HW, 2048 / std::max(1, N)));
     ppb = rup(ppb, slots);
     const int nb = sdm_cdiv(HW, ppb);
-    prof_begin(e, "gn_apply", 0, (double)N * HW * C * (in_f32 ? 4 : 2) + (double)N * HW * C * 2);
-    SDM_LAUNCH(gn_apply_kernel, dim3(nb, N), dim3(threads), 0, e->stream, s, (const float*)scale, (const float*)shift, out, silu, ppb);
+    prof_begin(e, "gn_apply", 0, (double)N * HW * C * (in_f32 ? 4 : 2) + (double)N * HW * C * (out_f32 ? 4 : 2));
+    SDM_LAUNCH(gn_apply_kernel, dim3(nb, N), dim3(threads), 0, e->stream, s, (const float*)scale, (const float*)shift, out, out_f32, silu, ppb);
     prof_end(e);
   }
   tfree(e, scratch);
@@ -769,31 +818,36 @@ static int op_groupnorm_raw(sdm_ctx* e, const void* in0, const void* in1, int C0
 static int op_gn(sdm_ctx* e, const NormL& n, const T& x, const T* x2, int silu, float eps, T* out) {
   const int C = x.C + (x2 ? x2->C : 0);
   if (C != n.C) SDM_FAIL(e, SDM_ERR_INVALID, "groupnorm: C %d != %d", C, n.C);
-  *out = talloc(e, x.N, x.H, x.W, C, 0);
+  *out = talloc(e, x.N, x.H, x.W, C, e->act_f32);
   const bool hs = x.sbytes && (!x2 || x2->sbytes);     // statistics already produced by the conv epilogue(s)
   return op_groupnorm_raw(e, x.p, x2 ? x2->p : nullptr, x.C, x2 ? x2->C : 0, x.f32, x.N, x.H * x.W, e->cfg.groups, n.g, n.b, eps, silu,
-                          (half_t*)out->p, x.stats, x.srows, x2 ? x2->stats : nullptr, x2 ? x2->srows : 0, hs);
+                          out->p, out->f32, x.stats, x.srows, x2 ? x2->stats : nullptr, x2 ? x2->srows : 0, hs);
 }
 
 static int op_ln(sdm_ctx* e, const NormL& n, const T& x, float eps, T* out) {
   if (x.C != n.C || x.C % 64 || x.C > 64 * SDM_LN_MAXV) SDM_FAIL(e, SDM_ERR_INVALID, "layernorm: unsupported C %d", x.C);
-  *out = talloc(e, x.N, x.H, x.W, x.C, 0);
+  *out = talloc(e, x.N, x.H, x.W, x.C, e->act_f32);
   if (e->dry) return 0;
   const long rows = x.rows();
-  prof_begin(e, "layernorm", 0, (double)rows * x.C * ((x.f32 ? 4 : 2) + 2));
+  prof_begin(e, "layernorm", 0, (double)rows * x.C * ((x.f32 ? 4 : 2) + (out->f32 ? 4 : 2)));
   SDM_LAUNCH(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, e->stream, (const void*)x.p, x.f32, (const float*)n.g,
-             (const float*)n.b, (half_t*)out->p, rows, x.C, eps);
+             (const float*)n.b, out->p, out->f32, rows, x.C, eps);
   prof_end(e);
   return 0;
 }
 
 // q/k/v are views into fp16 row-major buffers; v is transposed into an arena scratch first
+// Precise variant (d = 64): q / k / v point at the HIGH planes of split fp16 pairs, the low planes follow at element offsets
+// q_lo / k_lo / v_lo (written by the producing GEMM with out_f32 == 2); `out` is fp16 or fp32 (out_f32).
+struct AttnPrec { int prec = 0; long q_lo = 0, k_lo = 0, v_lo = 0; int out_f32 = 0; };
 static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* k, int ldk, const half_t* v, int ldv, const float* bias_l2,
-                            int B, int heads, int Lq, int Lk, int D, half_t* out, int ldo, bool q_prescaled = false, const int* tiles = nullptr) {
+                            int B, int heads, int Lq, int Lk, int D, void* out, int ldo, bool q_prescaled = false, const int* tiles = nullptr,
+                            AttnPrec ap = AttnPrec()) {
   if (!(D == 64 || (D == 512 && heads == 1))) SDM_FAIL(e, SDM_ERR_INVALID, "attention: unsupported head dim %d x %d heads", D, heads);
   if ((ldq | ldk | ldv | ldo) % 8) SDM_FAIL(e, SDM_ERR_INVALID, "attention: row strides must be multiples of 8");
+  if (ap.prec && D != 64) SDM_FAIL(e, SDM_ERR_INVALID, "attention: the split-precision variant exists for head dim 64 only");
   const int ldvt = rup(Lk, 64);
-  T vt = talloc(e, B, heads, D, ldvt, 0);
+  T vt = talloc(e, (ap.prec ? 2 : 1) * B, heads, D, ldvt, 0);      // precise: V^T_hi planes of all images, then V^T_lo
   // key tiles whose bias underflows the softmax are skipped (exact, AttnParams::tiles); the engine passes one list per U-Net
   // level, the stand-alone operator entry builds it here.  SDM_ATTN_DENSE=1 walks every tile (A/B hook).
   const bool dense_attn = getenv("SDM_ATTN_DENSE") != nullptr;
@@ -811,6 +865,9 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
     prof_begin(e, "transpose_v", 0, (double)B * Lk * heads * D * 4);
     SDM_LAUNCH(transpose_v_kernel, dim3(ldvt / 64, heads * (D / 64), B), dim3(256), 0, e->stream, v, (long)Lk * ldv, ldv, (half_t*)vt.p, vt_bs,
                vt_hs, ldvt, Lk, D);
+    if (ap.prec)
+      SDM_LAUNCH(transpose_v_kernel, dim3(ldvt / 64, heads * (D / 64), B), dim3(256), 0, e->stream, v + ap.v_lo, (long)Lk * ldv, ldv,
+                 (half_t*)vt.p + (size_t)B * vt_bs, vt_bs, vt_hs, ldvt, Lk, D);
     prof_end(e);
     AttnParams p;
     memset(&p, 0, sizeof(p));
@@ -819,7 +876,8 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
     p.vt = (const half_t*)vt.p; p.vt_bs = vt_bs; p.vt_hs = vt_hs; p.ldvt = ldvt;
     p.bias = bias_l2; p.bias_bs = Lk;
     p.tiles = tiles; p.tiles_bs = ntiles64 + 1;
-    p.o = out; p.o_bs = (long)Lq * ldo; p.ldo = ldo;
+    p.o = (half_t*)out; p.o_bs = (long)Lq * ldo; p.ldo = ldo; p.o_f32 = ap.out_f32;
+    p.q_lo = ap.q_lo; p.k_lo = ap.k_lo; p.vt_lo = (long)B * vt_bs;
     p.Lq = Lq; p.Lk = Lk;
     p.scale_log2e = q_prescaled ? 1.0f : (1.0f / sqrtf((float)D)) * SDM_LOG2E;      // engine: folded into the to_q weights (d = 64 only)
     double flops = 4.0 * B * heads * (double)Lq * Lk * D;
@@ -842,26 +900,25 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
       prof_begin(e, "attn_d64", flops, bytes, adesc);
       // 64 queries per wave when that still leaves >= 2 blocks per CU, else 32
       const char* force_qt = getenv("SDM_ATTN_QT");       // test hook: force the 64-query-per-wave variant (measured slower)
-      const bool qt2 = force_qt && force_qt[0] == '2';
+      const bool qt2 = force_qt && force_qt[0] == '2' && !ap.prec;
       const int qrows = qt2 ? 256 : 128;
       p.batch = B; p.heads = heads; p.nq_blocks = sdm_cdiv(Lq, qrows); p.q_chunks = 8;     // B*heads*8 units: always a multiple of 8
       const int qb = sdm_cdiv(p.nq_blocks, p.q_chunks);
       const unsigned nblk = (unsigned)(B * heads * p.q_chunks * qb);                         // 1-D grid, XCD-aware mapping in the kernel
-      if (qt2) { SDM_LAUNCH(attn_d64_kernel<2>, dim3(nblk, 1, 1), dim3(256), ATTN64_SMEM, e->stream, p); }
+      if (ap.prec) {
+        auto kp = attn_d64_kernel<1, 1>;
+        SDM_SET_SMEM(kp, ATTN64P_SMEM);
+        SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(256), ATTN64P_SMEM, e->stream, p);
+      }
+      else if (qt2) { SDM_LAUNCH(attn_d64_kernel<2>, dim3(nblk, 1, 1), dim3(256), ATTN64_SMEM, e->stream, p); }
       else { SDM_LAUNCH(attn_d64_kernel<1>, dim3(nblk, 1, 1), dim3(256), ATTN64_SMEM, e->stream, p); }
       prof_end(e);
     } else {
-      static const bool sync512 = getenv("SDM_ATTN512_SYNC") != nullptr;    // A/B hook: the synchronous-staging kernel
       prof_begin(e, "attn_d512", flops, bytes);
       p.batch = B; p.heads = 1; p.nq_blocks = sdm_cdiv(Lq, 128); p.q_chunks = 8;
       const unsigned nblk = (unsigned)(B * p.q_chunks * sdm_cdiv(p.nq_blocks, p.q_chunks));
-      if (sync512) {
-        SDM_SET_SMEM(attn_d512_sync_kernel, ATTN512_SMEM);
-        SDM_LAUNCH(attn_d512_sync_kernel, dim3(nblk), dim3(512), ATTN512_SMEM, e->stream, p);
-      } else {
-        SDM_SET_SMEM(attn_d512_kernel, ATTN512P_SMEM);
-        SDM_LAUNCH(attn_d512_kernel, dim3(nblk), dim3(512), ATTN512P_SMEM, e->stream, p);
-      }
+      SDM_SET_SMEM(attn_d512_kernel, ATTN512P_SMEM);
+      SDM_LAUNCH(attn_d512_kernel, dim3(nblk), dim3(512), ATTN512P_SMEM, e->stream, p);
       prof_end(e);
     }
   }
@@ -928,7 +985,7 @@ static int gn_conv(sdm_ctx* e, const NormL& n, const ConvL& L, const T& x, const
 // ResnetBlock2D (Appendix A.3).  x (+ x2: channel concat) -> new stream tensor; frees nothing.
 static int resblock(sdm_ctx* e, const ResB& r, const T& x, const T* x2, float eps, T* out) {
   const int sf = e->cfg.stream_f32;
-  T h1 = talloc(e, x.N, x.H, x.W, r.cout, 0);
+  T h1 = talloc(e, x.N, x.H, x.W, r.cout, e->act_f32);
   TRY(tstats(e, h1));
   {
     ConvArgs a; a.out = &h1;
@@ -966,13 +1023,14 @@ static int linear(sdm_ctx* e, int layer, const T& in, T* out, int Cout, int out_
 static int vae_attention(sdm_ctx* e, const VaeAttnB& a, const T& x, T* out) {
   T hn, qkv, ao;
   TRY(op_gn(e, e->norms[a.gn], x, nullptr, 0, e->cfg.vae_eps, &hn));
-  TRY(linear(e, a.qkv, hn, &qkv, 3 * a.C, 0));
+  TRY(linear(e, a.qkv, hn, &qkv, 3 * a.C, 0));          // the single-head d=512 core always takes fp16 operands
   tfree(e, hn);
-  ao = talloc(e, x.N, x.H, x.W, a.C, 0);
+  ao = talloc(e, x.N, x.H, x.W, a.C, e->act_f32);
   const int L = x.H * x.W;
   const half_t* q = (const half_t*)qkv.p;
+  AttnPrec ap; ap.out_f32 = ao.f32;
   TRY(op_attention_raw(e, q, 3 * a.C, q ? q + a.C : nullptr, 3 * a.C, q ? q + 2 * a.C : nullptr, 3 * a.C, nullptr, x.N, 1, L, L, a.C,
-                       (half_t*)ao.p, a.C));
+                       ao.p, a.C, false, nullptr, ap));
   tfree(e, qkv);
   TRY(linear(e, a.out, ao, out, a.C, e->cfg.stream_f32, &x, true));
   tfree(e, ao);
@@ -989,32 +1047,37 @@ static int transformer(sdm_ctx* e, const TfB& t, const T& x, const T& uin, const
   tfree(e, hn);
   // self-attention with the trimap key bias
   TRY(op_ln(e, e->norms[t.ln1], h, e->cfg.unet_ln_eps, &n));
-  TRY(linear(e, t.qkv1, n, &qkv, 3 * C, 0));
+  const int pa = (e->cfg.precise_mask & SDM_PRECISE_UNET_ATTN) ? 1 : 0;      // split-precision attention cores: q|k|v as hi|lo planes
+  TRY(linear(e, t.qkv1, n, &qkv, 3 * C, pa ? 2 : 0));
   tfree(e, n);
-  ao = talloc(e, x.N, x.H, x.W, C, 0);
+  ao = talloc(e, x.N, x.H, x.W, C, e->act_f32);
   {
     const half_t* q = (const half_t*)qkv.p;
-    TRY(op_attention_raw(e, q, 3 * C, q ? q + C : nullptr, 3 * C, q ? q + 2 * C : nullptr, 3 * C, bias, x.N, t.heads, L, L, 64, (half_t*)ao.p, C, true, tiles));
+    AttnPrec ap; ap.prec = pa; ap.out_f32 = ao.f32;
+    ap.q_lo = ap.k_lo = ap.v_lo = (long)qkv.rows() * qkv.C;
+    TRY(op_attention_raw(e, q, 3 * C, q ? q + C : nullptr, 3 * C, q ? q + 2 * C : nullptr, 3 * C, bias, x.N, t.heads, L, L, 64, ao.p, C, true, tiles, ap));
   }
   tfree(e, qkv);
   TRY(linear(e, t.o1, ao, &h2, C, sf, &h));
   tfree(e, ao); tfree(e, h);
   // cross-attention to the trimap-latent tokens
   TRY(op_ln(e, e->norms[t.ln2], h2, e->cfg.unet_ln_eps, &n));
-  TRY(linear(e, t.q2, n, &q2, C, 0));
+  TRY(linear(e, t.q2, n, &q2, C, pa ? 2 : 0));
   tfree(e, n);
-  TRY(conv_simple(e, t.kv2, uin, &kv, 2 * C, 0));      // folded aux_conv_in + to_k|to_v: tokens = latent pixels, row-major
-  ao = talloc(e, x.N, x.H, x.W, C, 0);
+  TRY(conv_simple(e, t.kv2, uin, &kv, 2 * C, pa ? 2 : 0));      // folded aux_conv_in + to_k|to_v: tokens = latent pixels, row-major
+  ao = talloc(e, x.N, x.H, x.W, C, e->act_f32);
   {
     const half_t* kk = (const half_t*)kv.p;
-    TRY(op_attention_raw(e, (const half_t*)q2.p, C, kk, 2 * C, kk ? kk + C : nullptr, 2 * C, nullptr, x.N, t.heads, L, L0, 64, (half_t*)ao.p, C, true));
+    AttnPrec ap; ap.prec = pa; ap.out_f32 = ao.f32;
+    ap.q_lo = (long)q2.rows() * q2.C; ap.k_lo = ap.v_lo = (long)kv.rows() * kv.C;
+    TRY(op_attention_raw(e, (const half_t*)q2.p, C, kk, 2 * C, kk ? kk + C : nullptr, 2 * C, nullptr, x.N, t.heads, L, L0, 64, ao.p, C, true, nullptr, ap));
   }
   tfree(e, q2); tfree(e, kv);
   TRY(linear(e, t.o2, ao, &h, C, sf, &h2));
   tfree(e, ao); tfree(e, h2);
   // GEGLU feed-forward
   TRY(op_ln(e, e->norms[t.ln3], h, e->cfg.unet_ln_eps, &n));
-  TRY(linear(e, t.ff1, n, &f, 4 * C, 0));
+  TRY(linear(e, t.ff1, n, &f, 4 * C, e->act_f32));
   tfree(e, n);
   TRY(linear(e, t.ff2, f, &h2, C, sf, &h));
   tfree(e, f); tfree(e, h);
@@ -1156,7 +1219,7 @@ static int vae_encode(sdm_ctx* e, const T& x16, T* moments) {
   TRY(resblock(e, e->enc_mid0, h, nullptr, eps, &t)); tfree(e, h); h = t;
   TRY(vae_attention(e, e->enc_attn, h, &t)); tfree(e, h); h = t;
   TRY(resblock(e, e->enc_mid1, h, nullptr, eps, &t)); tfree(e, h); h = t;
-  *moments = talloc(e, h.N, h.H, h.W, 16, 0);
+  *moments = talloc(e, h.N, h.H, h.W, 16, e->act_f32);
   { ConvArgs a; a.out = moments; TRY(gn_conv(e, e->norms[e->enc_norm_out], e->convs[e->enc_conv_out], h, nullptr, 1, eps, a)); }
   tfree(e, h);
   return 0;
@@ -1221,7 +1284,7 @@ static int unet_forward(sdm_ctx* e, const T& uin, float* const* bias_lvl, int* c
     if (i < 3) { TRY(conv_simple(e, e->u_up_us[i], h, &t, c.unet_channels[3 - i], sf, 1, 0, 1, nullptr, 1.0f, true)); tfree(e, h); h = t; }
   }
   // label_latent / scaling_factor (meta_arch.py:254) folded into the conv_out epilogue
-  *out = talloc(e, h.N, h.H, h.W, 16, 0);
+  *out = talloc(e, h.N, h.H, h.W, 16, e->act_f32);
   { ConvArgs a; a.out = out; a.out_scale = 1.0f / c.vae_scaling_factor; TRY(gn_conv(e, e->norms[e->u_norm_out], e->convs[e->u_conv_out], h, nullptr, 1, eps, a)); }
   tfree(e, h);
   return 0;
@@ -1254,11 +1317,11 @@ static int run_model(sdm_ctx* e, const T& x16, const T& plane, int B, int SH, in
   TRY(vae_encode(e, x16, &moments));
   // quant_conv -> mean half * scaling_factor, written straight into the 8(+8 pad)-channel U-Net input:
   // channels 0..3 = rgb latent, 4..7 = trimap latent (torch.cat order of meta_arch.py:244)
-  T uin = talloc(e, B, lh, lw, 16, 0);
+  T uin = talloc(e, B, lh, lw, 16, e->act_f32);
   if (!e->dry) SDM_CHECK_DEV(e, dev_memset(uin.p, 0, uin.bytes, e->stream));
   for (int half = 0; half < 2; ++half) {
     T mv = moments; mv.N = B;
-    if (!e->dry) mv.p = (unsigned char*)moments.p + (size_t)half * B * lh * lw * 16 * 2;
+    if (!e->dry) mv.p = (unsigned char*)moments.p + (size_t)half * B * lh * lw * 16 * fmt_bytes(moments.f32);
     ConvArgs a; a.in0 = &mv; a.out = &uin; a.out_ch_off = half * 4; a.cout_valid = 4; a.out_scale = c.vae_scaling_factor;
     TRY(op_conv(e, e->convs[e->quant], a));
   }
@@ -1271,7 +1334,7 @@ static int run_model(sdm_ctx* e, const T& x16, const T& plane, int B, int SH, in
   for (int k = 3; k >= 0; --k) { tfree(e, tilebuf[k]); tfree(e, biasbuf[k]); }
   // post_quant_conv + decoder (meta_arch.py:255-256)
   T z;
-  TRY(conv_simple(e, e->post_quant, lat, &z, 16, 0)); tfree(e, lat);
+  TRY(conv_simple(e, e->post_quant, lat, &z, 16, e->act_f32)); tfree(e, lat);
   T dec;
   TRY(vae_decode(e, z, &dec)); tfree(e, z);
   *alpha = talloc(e, B, SH, SW, 1, 1);
@@ -1302,7 +1365,18 @@ static int forward_impl(sdm_ctx* e, int mode, const float* image, const float* t
   if (B <= 0 || SH <= 0 || SW <= 0 || SH % 64 || SW % 64)
     SDM_FAIL(e, SDM_ERR_INVALID, "inference size must be a positive multiple of 64 (got %dx%d)", SH, SW);
   if (mode == 1 && (H <= 0 || W <= 0)) SDM_FAIL(e, SDM_ERR_INVALID, "bad image size %dx%d", H, W);
-  (void)stream_arg;   // all work is queued on the engine stream; callers sync through sdm_synchronize
+  // Stream contract (include/sdmatte.h): kernels run on the engine's own stream.  For DEVICE pointers the caller names the
+  // stream on which it produced the inputs and will consume the outputs (NULL = the device's default stream): the engine
+  // stream waits for everything queued there at call time, and that stream waits for the outputs before the call returns
+  // control (no host synchronisation).  HOST pointers are copied on the engine stream, followed by a host sync below.
+#ifndef SDM_EMU
+  if (ptr_kind == SDM_PTR_DEVICE) {
+    SDM_CHECK_DEV(e, (int)hipEventRecord(e->ev_in, (hipStream_t)stream_arg));
+    SDM_CHECK_DEV(e, (int)hipStreamWaitEvent((hipStream_t)e->stream, e->ev_in, 0));
+  }
+#else
+  (void)stream_arg;
+#endif
   const size_t in_img = (size_t)B * H * W * 3 * 4;          // mode 0: [B,3,SH,SW]; mode 1: [B,H,W,3]
   const size_t in_tri = (size_t)B * H * W * 4;
   const size_t out_bytes = (size_t)B * H * W * 4;
@@ -1328,17 +1402,17 @@ static int forward_impl(sdm_ctx* e, int mode, const float* image, const float* t
 #ifndef SDM_EMU
     if (pass == 1) (void)hipEventRecord(e->ev0, (hipStream_t)e->stream);
 #endif
-    T x16 = talloc(e, 2 * B, SH, SW, 16, 0);
+    T x16 = talloc(e, 2 * B, SH, SW, 16, e->act_f32);
     T plane = talloc(e, B, SH, SW, 1, 1);
     if (!e->dry) {
       const unsigned nb = (unsigned)(((long)B * SH * SW + 255) / 256);
-      half_t* img16 = (half_t*)x16.p;
-      half_t* tri16 = img16 + (size_t)B * SH * SW * 16;
+      void* img16 = x16.p;
+      void* tri16 = (unsigned char*)x16.p + (size_t)B * SH * SW * 16 * fmt_bytes(x16.f32);
       if (mode == 0) {
-        SDM_LAUNCH(prep_nchw_kernel, dim3(nb), dim3(256), 0, e->stream, d_img, d_tri, img16, tri16, (float*)plane.p, B, SH, SW);
+        SDM_LAUNCH(prep_nchw_kernel, dim3(nb), dim3(256), 0, e->stream, d_img, d_tri, img16, tri16, x16.f32, (float*)plane.p, B, SH, SW);
       } else {
-        SDM_LAUNCH(prep_image_kernel, dim3(nb), dim3(256), 0, e->stream, d_img, img16, B, H, W, S);
-        SDM_LAUNCH(prep_trimap_kernel, dim3(nb), dim3(256), 0, e->stream, d_tri, tri16, (float*)plane.p, B, H, W, S);
+        SDM_LAUNCH(prep_image_kernel, dim3(nb), dim3(256), 0, e->stream, d_img, img16, x16.f32, B, H, W, S);
+        SDM_LAUNCH(prep_trimap_kernel, dim3(nb), dim3(256), 0, e->stream, d_tri, tri16, x16.f32, (float*)plane.p, B, H, W, S);
       }
     }
     T alpha;
@@ -1362,6 +1436,12 @@ static int forward_impl(sdm_ctx* e, int mode, const float* image, const float* t
     SDM_CHECK_DEV(e, dev_memcpy_d2h(out, e->io_out, out_bytes, e->stream));
     SDM_CHECK_DEV(e, dev_sync(e->stream));
   }
+#ifndef SDM_EMU
+  else {
+    SDM_CHECK_DEV(e, (int)hipEventRecord(e->ev_out, (hipStream_t)e->stream));
+    SDM_CHECK_DEV(e, (int)hipStreamWaitEvent((hipStream_t)stream_arg, e->ev_out, 0));
+  }
+#endif
   return 0;
 }
 
@@ -1419,6 +1499,10 @@ int sdm_create(sdm_ctx** out, int device_id, const sdm_config* cfg) {
   sdm_ctx* e = new sdm_ctx();
   if (cfg) e->cfg = *cfg; else sdm_default_config(&e->cfg);
   if (e->cfg.point_embeddings_input_dim <= 0) e->cfg.point_embeddings_input_dim = 1680;
+  e->cfg.precise_mask &= SDM_PRECISE_ALL;
+  if (const char* pm = getenv("SDM_PRECISE_MASK")) e->cfg.precise_mask = atoi(pm) & SDM_PRECISE_ALL;      // experiment hook (per-stage attribution)
+  e->act_f32 = e->cfg.precise_mask ? 1 : 0;
+  if (e->act_f32) e->cfg.stream_f32 = 1;
   e->device = device_id;
   const sdm_config& c = e->cfg;
   for (int i = 0; i < 4; ++i) {
@@ -1440,13 +1524,17 @@ int sdm_create(sdm_ctx** out, int device_id, const sdm_config* cfg) {
   if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { g_create_err = "hipStreamCreate failed"; delete e; return SDM_ERR_HIP; }
   e->stream = st; e->own_stream = true;
   (void)hipEventCreate(&e->ev0); (void)hipEventCreate(&e->ev1);
+  (void)hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming); (void)hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming);
 #endif
   // weight arena (+ temb tables)
   void* p = nullptr;
   if (dev_malloc(&p, e->warena_bytes) != 0) { g_create_err = "cannot allocate weight arena"; delete e; return SDM_ERR_NOMEM; }
   e->warena = (unsigned char*)p;
   dev_memset(e->warena, 0, e->warena_bytes, e->stream);
-  for (auto& L : e->convs) { L.w = (half_t*)(e->warena + L.w_off); L.b = (float*)(e->warena + L.b_off); }
+  for (auto& L : e->convs) {
+    L.w = (half_t*)(e->warena + L.w_off); L.b = (float*)(e->warena + L.b_off);
+    if (L.split) L.w_lo = (half_t*)(e->warena + L.wlo_off);
+  }
   for (auto& n : e->norms) { n.g = (float*)(e->warena + n.g_off); n.b = (float*)(e->warena + n.b_off); }
   for (auto& t : e->tembs) {
     void* q = nullptr;
@@ -1473,6 +1561,8 @@ void sdm_destroy(sdm_ctx* e) {
 #ifndef SDM_EMU
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
+  if (e->ev_in) (void)hipEventDestroy(e->ev_in);
+  if (e->ev_out) (void)hipEventDestroy(e->ev_out);
   if (e->own_stream) (void)hipStreamDestroy((hipStream_t)e->stream);
 #endif
   delete e;
@@ -1522,7 +1612,8 @@ int sdm_load_tensor(sdm_ctx* e, const char* name, int dtype, int ndim, const int
       const int O = (int)s.shape[0], I = (int)s.shape[1];
       const size_t total = (size_t)L.Cin_pad * L.ntaps * L.Cout_pad;
       SDM_LAUNCH(pack_conv_weight_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 65535)), dim3(256), 0, e->stream,
-                 (const float*)e->stage, L.w, O, I, L.ntaps, L.Cin_pad, L.Cout_pad, s.ci_off, s.co_off, L.geglu, s.w_scale);
+                 (const float*)e->stage, L.w, O, I, L.ntaps, L.Cin_pad, L.Cout_pad, s.ci_off, s.co_off, L.geglu,
+                 s.w_scale * ldexpf(1.0f, L.w_exp), L.w_lo);
     } else if (s.kind == SLOT_CONV_B) {
       ConvL& L = e->convs[s.layer];
       SDM_LAUNCH(pack_bias_kernel, dim3(sdm_cdiv(L.Cout_pad, 256)), dim3(256), 0, e->stream, (const float*)e->stage, L.b, (int)s.shape[0],
@@ -1572,10 +1663,11 @@ static int fold_cross_kv(sdm_ctx* e) {
     // upload as an OIHW [2C][4][3][3] tensor; the 4 latent channels sit at channels 4..7 of the 16-channel U-Net input
     if (ensure_buf(e, &e->stage, &e->stage_bytes, std::max(wf.size() * 4, (size_t)1 << 20)) != 0) return SDM_ERR_NOMEM;
     SDM_CHECK_DEV(e, dev_memset(L.w, 0, (size_t)L.Cin_pad * 9 * L.Cout_pad * 2, e->stream));
+    if (L.w_lo) SDM_CHECK_DEV(e, dev_memset(L.w_lo, 0, (size_t)L.Cin_pad * 9 * L.Cout_pad * 2, e->stream));
     SDM_CHECK_DEV(e, dev_memcpy_h2d(e->stage, wf.data(), wf.size() * 4, e->stream));
     const size_t total = (size_t)L.Cin_pad * 9 * L.Cout_pad;
     SDM_LAUNCH(pack_conv_weight_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 65535)), dim3(256), 0, e->stream, (const float*)e->stage,
-               L.w, 2 * C, 4, 9, L.Cin_pad, L.Cout_pad, 4, 0, 0, 1.0f);
+               L.w, 2 * C, 4, 9, L.Cin_pad, L.Cout_pad, 4, 0, 0, ldexpf(1.0f, L.w_exp), L.w_lo);
     SDM_CHECK_DEV(e, dev_sync(e->stream));
     SDM_CHECK_DEV(e, dev_memcpy_h2d(e->stage, bf.data(), bf.size() * 4, e->stream));
     SDM_LAUNCH(pack_bias_kernel, dim3(sdm_cdiv(L.Cout_pad, 256)), dim3(256), 0, e->stream, (const float*)e->stage, L.b, 2 * C, L.Cout_pad, 0, 0);
@@ -1733,7 +1825,7 @@ int sdm_op_conv(sdm_ctx* e, const void* in0, const void* in1, int C0, int C1, in
   L.w = (half_t*)wp; L.b = (float*)bp;
   const size_t total = (size_t)L.Cin_pad * ntaps * L.Cout_pad;
   SDM_LAUNCH(pack_conv_weight_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 65535)), dim3(256), 0, e->stream, w, L.w, O, L.I, ntaps,
-             L.Cin_pad, L.Cout_pad, 0, 0, geglu, 1.0f);
+             L.Cin_pad, L.Cout_pad, 0, 0, geglu, ldexpf(1.0f, L.w_exp), L.w_lo);
   if (bias) SDM_LAUNCH(pack_bias_kernel, dim3(sdm_cdiv(L.Cout_pad, 256)), dim3(256), 0, e->stream, bias, L.b, O, L.Cout_pad, 0, geglu);
   int Ho = Hin << up, Wo = Win << up;
   if (stride == 2) { Ho /= 2; Wo /= 2; }
@@ -1838,14 +1930,14 @@ int sdm_op_groupnorm(sdm_ctx* e, const void* in0, const void* in1, int C0, int C
                      const float* beta, float eps, int silu, void* out) {
   if (e) dev_use(e->device);
   if (!e || !in0 || !out) return SDM_ERR_INVALID;
-  return run_two_pass(e, [&]() { return op_groupnorm_raw(e, in0, in1, C0, C1, in_f32, N, HW, groups, gamma, beta, eps, silu, (half_t*)out); });
+  return run_two_pass(e, [&]() { return op_groupnorm_raw(e, in0, in1, C0, C1, in_f32, N, HW, groups, gamma, beta, eps, silu, out, 0); });
 }
 
 int sdm_op_layernorm(sdm_ctx* e, const void* x, int in_f32, long rows, int C, const float* gamma, const float* beta, float eps, void* out) {
   if (e) dev_use(e->device);
   if (!e || !x || !out) return SDM_ERR_INVALID;
   if (C % 64 || C > 64 * SDM_LN_MAXV) SDM_FAIL(e, SDM_ERR_INVALID, "layernorm: unsupported C %d", C);
-  SDM_LAUNCH(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, e->stream, x, in_f32, gamma, beta, (half_t*)out, rows, C, eps);
+  SDM_LAUNCH(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, e->stream, x, in_f32, gamma, beta, out, 0, rows, C, eps);
   SDM_CHECK_DEV(e, dev_sync(e->stream));
   return 0;
 }

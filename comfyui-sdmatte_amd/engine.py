@@ -29,11 +29,34 @@ class SdmConfig(C.Structure):
         ("bbox_embeddings_input_dim", C.c_int32), ("groups", C.c_int32),
         ("vae_eps", C.c_float), ("unet_res_eps", C.c_float), ("unet_tf_gn_eps", C.c_float), ("unet_ln_eps", C.c_float),
         ("vae_scaling_factor", C.c_float), ("attn_mask_value", C.c_float),
-        ("stream_f32", C.c_int32), ("point_embeddings_input_dim", C.c_int32), ("reserved", C.c_int32 * 6),
+        ("stream_f32", C.c_int32), ("point_embeddings_input_dim", C.c_int32), ("precise_mask", C.c_int32), ("reserved", C.c_int32 * 5),
     ]
 
 
-def to_c_config(cfg: SDMatteConfig, stream_f32: bool = True) -> SdmConfig:
+# sdm_precise_stage bits (include/sdmatte.h)
+PRECISE_VAE_ENC, PRECISE_VAE_DEC, PRECISE_VAE_ATTN_LIN, PRECISE_UNET_RES, PRECISE_UNET_TF, PRECISE_UNET_ATTN = 1, 2, 4, 8, 16, 32
+PRECISE_ALL = 63
+PRECISIONS = {
+    # fp16 MFMA operands everywhere: fastest; alpha within ~4e-3 of the reference's fp32 CPU path (the rounding floor of any
+    # fp16-operand evaluation of this graph, the reference's own CUDA autocast path included)
+    "fp16": 0,
+    # split-fp16 operands (hi + lo, 3 MFMAs per product) and fp32 activations in every stage: alpha within 1e-3 (measured ~1e-4)
+    "fp16x3": PRECISE_ALL,
+}
+DEFAULT_PRECISION = os.environ.get("SDMATTE_PRECISION", "fp16x3")
+
+
+def precise_mask_of(precision) -> int:
+    if precision is None:
+        precision = DEFAULT_PRECISION
+    if isinstance(precision, int):
+        return precision & PRECISE_ALL
+    if precision not in PRECISIONS:
+        raise ValueError(f"unknown precision {precision!r}; expected one of {sorted(PRECISIONS)} or a stage bit mask")
+    return PRECISIONS[precision]
+
+
+def to_c_config(cfg: SDMatteConfig, stream_f32: bool = True, precision=None) -> SdmConfig:
     c = SdmConfig()
     for i in range(4):
         c.vae_channels[i] = cfg.vae_channels[i]
@@ -51,6 +74,7 @@ def to_c_config(cfg: SDMatteConfig, stream_f32: bool = True) -> SdmConfig:
     c.vae_scaling_factor, c.attn_mask_value = cfg.vae_scaling_factor, cfg.attn_mask_value
     c.stream_f32 = 1 if stream_f32 else 0
     c.point_embeddings_input_dim = cfg.point_embeddings_input_dim
+    c.precise_mask = precise_mask_of(precision)
     return c
 
 
@@ -134,11 +158,12 @@ def _ptr(t):
 class Engine:
     """One engine per GPU (one process per GPU under torch.distributed, or one per device inside ComfyUI)."""
 
-    def __init__(self, cfg: SDMatteConfig = None, device: int = 0, stream_f32: bool = True, _lib: Bindings = None):
+    def __init__(self, cfg: SDMatteConfig = None, device: int = 0, stream_f32: bool = True, _lib: Bindings = None, precision=None):
         self.lib = _lib or load_library()
         self.cfg = cfg or SDMatteConfig.full()
         self.device = device
-        self._ccfg = to_c_config(self.cfg, stream_f32)
+        self.precise_mask = precise_mask_of(precision)
+        self._ccfg = to_c_config(self.cfg, stream_f32, self.precise_mask)
         h = C.c_void_p()
         rc = self.lib.sdm_create(C.byref(h), device, C.byref(self._ccfg))
         if rc != 0:
@@ -204,6 +229,22 @@ class Engine:
     def _kind(self, t):
         return SDM_PTR_DEVICE if (t.device.type == "cuda") else (SDM_PTR_DEVICE if not self._on_device else SDM_PTR_HOST)
 
+    def _check_io(self, what, *tensors):
+        """All tensors of one call live in one place: host memory, or THIS engine's GPU (raw pointers cross the C ABI, so a
+        tensor on another device would be read as garbage or fault).  Returns the hipStream_t the caller's work is queued on
+        (torch's current stream of that device; the engine orders itself after it and makes it wait for the outputs)."""
+        devs = {(t.device.type, t.device.index) for t in tensors if t is not None}
+        if len(devs) != 1:
+            raise ValueError(f"{what}: image, trimap and out must share one device, got {sorted(devs)}")
+        (kind, idx), = devs
+        if kind == "cuda":
+            if not self._on_device or idx != self.device:
+                raise ValueError(f"{what}: tensors live on cuda:{idx}, this engine drives cuda:{self.device}")
+            return C.c_void_p(torch.cuda.current_stream(idx).cuda_stream)
+        if kind != "cpu":
+            raise ValueError(f"{what}: unsupported device {kind}")
+        return None
+
     def forward(self, image_b3ss: torch.Tensor, trimap_b1ss: torch.Tensor, is_trans=None, coords=None, out=None, sync=True,
                 point_coords=None, use_attention_mask=True):
         """SDMatte.forward(data): image [B,3,S,S] in [-1,1], aux prompt image (trimap / bbox_mask / mask / point_mask) [B,1,S,S]
@@ -214,6 +255,9 @@ class Engine:
         trimap_b1ss = trimap_b1ss.float().contiguous()
         if out is None:
             out = torch.empty(B, 1, SH, SW, dtype=torch.float32, device=image_b3ss.device)
+        elif out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != B * SH * SW:
+            raise ValueError("forward: out must be a contiguous fp32 tensor of B*SH*SW elements")
+        stream = self._check_io("forward", image_b3ss, trimap_b1ss, out)
         it = np.ascontiguousarray(np.zeros(B, np.int32) if is_trans is None else np.asarray(is_trans, np.int32).reshape(B))
         if point_coords is not None:
             co = np.ascontiguousarray(np.asarray(point_coords, np.float32).reshape(B, -1))
@@ -223,7 +267,7 @@ class Engine:
             kind, dim = 0, 4
         self._check(self.lib.sdm_forward_rect(self.h, _ptr(image_b3ss), _ptr(trimap_b1ss), B, SH, SW, it.ctypes.data_as(C.c_void_p),
                                               co.ctypes.data_as(C.c_void_p) if co is not None else None, dim, kind,
-                                              1 if use_attention_mask else 0, _ptr(out), self._kind(image_b3ss), None), "sdm_forward_rect")
+                                              1 if use_attention_mask else 0, _ptr(out), self._kind(image_b3ss), stream), "sdm_forward_rect")
         if sync:
             self.synchronize()
         return out
@@ -233,10 +277,15 @@ class Engine:
         B, H, W, _ = image_bhwc.shape
         image_bhwc = image_bhwc.float().contiguous()
         trimap_bhw = trimap_bhw.float().contiguous()
+        if tuple(trimap_bhw.shape) != (B, H, W):
+            raise ValueError(f"apply_matte: trimap must be [B,H,W] = {(B, H, W)}, got {tuple(trimap_bhw.shape)}")
         if out is None:
             out = torch.empty(B, H, W, dtype=torch.float32, device=image_bhwc.device)
+        elif out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != B * H * W:
+            raise ValueError("apply_matte: out must be a contiguous fp32 tensor of B*H*W elements")
+        stream = self._check_io("apply_matte", image_bhwc, trimap_bhw, out)
         self._check(self.lib.sdm_apply_matte(self.h, _ptr(image_bhwc), _ptr(trimap_bhw), B, H, W, int(S), 1 if is_transparent else 0,
-                                             _ptr(out), self._kind(image_bhwc), None), "sdm_apply_matte")
+                                             _ptr(out), self._kind(image_bhwc), stream), "sdm_apply_matte")
         if sync:
             self.synchronize()
         return out

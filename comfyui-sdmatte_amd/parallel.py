@@ -17,20 +17,21 @@ def shard_range(total: int, world: int, rank: int):
 
 
 def broadcast_weights(engine, src: int = 0, device=None):
-    """Rank `src` has loaded a checkpoint into `engine`; every other rank receives the packed blob."""
+    """Rank `src` has loaded a checkpoint into `engine`; every other rank receives the packed weights: ONE RCCL broadcast of
+    [packed device arena | small host-side embedding tensors] (the host part rides at the tail of the same buffer)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return
     rank = dist.get_rank()
     device = device if device is not None else torch.device("cuda", engine.device)
-    blob = torch.empty(engine.weight_blob_bytes(), dtype=torch.uint8, device=device)
-    hblob = torch.empty(engine.host_blob_bytes(), dtype=torch.uint8)
+    nw, nh = engine.weight_blob_bytes(), engine.host_blob_bytes()
+    buf = torch.empty(nw + nh, dtype=torch.uint8, device=device)
     if rank == src:
-        engine.export_weights(blob, hblob)
-    dist.broadcast(blob, src)
-    hb = hblob.to(device)
-    dist.broadcast(hb, src)
+        hblob = torch.empty(nh, dtype=torch.uint8)
+        engine.export_weights(buf[:nw], hblob)
+        buf[nw:].copy_(hblob)
+    dist.broadcast(buf, src)
     if rank != src:
-        engine.import_weights(blob, hb.cpu())
+        engine.import_weights(buf[:nw], buf[nw:].cpu())
 
 
 def gather_alphas(alpha: torch.Tensor, dst: int = 0):
@@ -103,3 +104,99 @@ def matte_stream(engine, images, trimaps, sizes, is_transparent: bool = False, m
             dist.recv(buf, r)
             out[i] = buf
     return out
+
+
+class MultiGpuEngine:
+    """Single-process fan-out over the GPUs of one node (ComfyUI is ONE process, its node is called from one
+    worker thread - reference sdmatte_nodes.py:257): one engine, one HIP stream and one host thread per device.  The checkpoint
+    is packed once on the first device and the packed arena is copied device to device (xGMI peer copies); a batch is split
+    contiguously (`shard_range`), every shard goes through its device's engine concurrently (the C ABI releases the GIL), and
+    the alphas land in one host tensor.  No collective exists on this path: images are independent."""
+
+    def __init__(self, cfg=None, devices=None, precision=None, stream_f32: bool = True, _engine_factory=None):
+        from .engine import Engine
+        if devices is None:
+            devices = list(range(torch.cuda.device_count()))
+        if not devices:
+            raise RuntimeError("MultiGpuEngine: no GPU given")
+        make = _engine_factory or (lambda d: Engine(cfg, d, stream_f32, precision=precision))
+        self.devices = list(devices)
+        self.engines = [make(d) for d in self.devices]
+        self._owned = list(self.engines)
+        self.device = self.devices[0]
+        self.cfg = self.engines[0].cfg
+        self._on_device = self.engines[0]._on_device
+
+    @classmethod
+    def around(cls, first, other_devices):
+        """Fan-out around an engine that already holds a checkpoint (the node's cached model): engines for `other_devices` are
+        created with the same configuration / precision and receive the packed weights device to device."""
+        from .engine import Engine
+        self = cls.__new__(cls)
+        self.devices = [first.device] + list(other_devices)
+        self.engines = [first] + [Engine(first.cfg, d, bool(first._ccfg.stream_f32), precision=first.precise_mask) for d in other_devices]
+        self._owned = self.engines[1:]
+        self.device, self.cfg, self._on_device = first.device, first.cfg, first._on_device
+        self._copy_weights()
+        return self
+
+    def close(self):
+        for e in self._owned:
+            e.close()
+        self.engines, self._owned = [], []
+
+    def load_state_dict(self, state_dict, strict: bool = False):
+        res = self.engines[0].load_state_dict(state_dict, strict)
+        self._copy_weights()
+        return res
+
+    def _copy_weights(self):
+        e0 = self.engines[0]
+        if len(self.engines) > 1:
+            dev0 = torch.device("cuda", self.devices[0]) if self._on_device else torch.device("cpu")
+            blob = torch.empty(e0.weight_blob_bytes(), dtype=torch.uint8, device=dev0)
+            hblob = torch.empty(e0.host_blob_bytes(), dtype=torch.uint8)
+            e0.export_weights(blob, hblob)
+            for d, e in zip(self.devices[1:], self.engines[1:]):
+                peer = blob.to(torch.device("cuda", d)) if self._on_device else blob      # hipMemcpyPeer over xGMI
+                e.import_weights(peer, hblob)
+
+    def _fan(self, B, call):
+        import threading
+        n = min(len(self.engines), B)
+        errs = [None] * n
+
+        def work(r):
+            try:
+                lo, hi = shard_range(B, n, r)
+                if hi > lo:
+                    call(self.engines[r], self.devices[r], lo, hi)
+            except BaseException as exc:  # noqa: BLE001 - re-raised on the calling thread
+                errs[r] = exc
+
+        threads = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(1, n)]
+        for t in threads:
+            t.start()
+        work(0)
+        for t in threads:
+            t.join()
+        for exc in errs:
+            if exc is not None:
+                raise exc
+
+    def apply_matte(self, image_bhwc, trimap_bhw, S, is_transparent=False):
+        """image [B,H,W,3], trimap [B,H,W] (host or any device) -> alpha [B,H,W] fp32 on the HOST (what the node returns)."""
+        B, H, W, _ = image_bhwc.shape
+        out = torch.empty(B, H, W, dtype=torch.float32)
+        img = image_bhwc.detach().float().cpu().contiguous()
+        tri = trimap_bhw.detach().float().cpu().contiguous()
+
+        def call(eng, dev, lo, hi):
+            # host pointers: the engine copies its shard in on its own stream, runs, copies the alphas out and synchronises
+            eng.apply_matte(img[lo:hi], tri[lo:hi], S, is_transparent, out=out[lo:hi])
+
+        self._fan(B, call)
+        return out
+
+    def last_forward_ms(self):
+        return max(e.last_forward_ms() for e in self.engines)

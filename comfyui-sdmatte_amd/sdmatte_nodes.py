@@ -178,6 +178,23 @@ def get_model(ckpt_name, device):
     return model
 
 
+def _fan_out(model, batch):
+    """Multi-GPU fan-out of one node call: used when the batch has more than one image, more than one GPU is visible and
+    SDMATTE_MULTI_GPU is not "0".  The extra engines live as long as the cached model they were copied from."""
+    if batch < 2 or os.environ.get("SDMATTE_MULTI_GPU", "1") == "0" or not torch.cuda.is_available():
+        return None
+    ndev = torch.cuda.device_count()
+    if ndev < 2:
+        return None
+    fan = getattr(model, "_fan", None)
+    if fan is None:
+        from .parallel import MultiGpuEngine
+        first = model.engine
+        fan = MultiGpuEngine.around(first, [d for d in range(ndev) if d != first.device])
+        model._fan = fan
+    return fan
+
+
 def refine_and_compose(alpha_bhw, image, trimap, output_mode, mask_refine, trimap_constraint):
     """CPU tail of the node, same arithmetic and order as sdmatte_nodes.py:365-397."""
     out = alpha_bhw
@@ -238,7 +255,11 @@ class SDMatteApply:
         if trimap.dim() != 3 or tuple(trimap.shape) != tuple(image.shape[:3]):
             raise ValueError(f"[SDMatte] trimap must be [B,H,W] matching the image, got {tuple(trimap.shape)}")
         model = get_model(ckpt_name, _torch_device())
-        alpha = model.engine.apply_matte(image, trimap, int(inference_size), bool(is_transparent))   # [B,H,W] fp32, same device as input
+        fan = _fan_out(model, image.shape[0])
+        if fan is not None:          # batch split over every visible GPU (one engine + host thread per device)
+            alpha = fan.apply_matte(image, trimap, int(inference_size), bool(is_transparent))
+        else:
+            alpha = model.engine.apply_matte(image, trimap, int(inference_size), bool(is_transparent))   # [B,H,W] fp32, same device as input
         out, matted = refine_and_compose(alpha.detach().cpu(), image, trimap, output_mode, mask_refine, trimap_constraint)
         return (out, matted)
 

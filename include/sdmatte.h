@@ -55,8 +55,24 @@ typedef struct sdm_config {
   float attn_mask_value;
   int32_t stream_f32;      /* 1: residual stream tensors kept in fp32 (default), 0: fp16 */
   int32_t point_embeddings_input_dim;   /* 1680 (meta_arch.py:107-108); 0 = default */
-  int32_t reserved[6];
+  /* Arithmetic precision of the MFMA contractions, one bit per stage (enum sdm_precise_stage).  0 = fp16 operands everywhere
+   * (fast: alpha within ~4e-3 of the fp32 reference path, the rounding floor of ANY fp16-operand evaluation).  A set bit evaluates
+   * that stage with split-fp16 operands (x = hi + lo, 22 significant bits, hi.hi + lo.hi + hi.lo in fp32 accumulators) and keeps
+   * every activation in fp32 between kernels: SDM_PRECISE_ALL reproduces the reference's fp32 CPU path to ~1e-4 (1e-3 is the
+   * parity bar, sdmatte_nodes.py:355-360) at roughly 2.5x the MFMA work. */
+  int32_t precise_mask;
+  int32_t reserved[5];
 } sdm_config;
+
+enum sdm_precise_stage {
+  SDM_PRECISE_VAE_ENC = 1,        /* VAE encoder convs + quant_conv */
+  SDM_PRECISE_VAE_DEC = 2,        /* post_quant_conv + VAE decoder convs */
+  SDM_PRECISE_VAE_ATTN_LIN = 4,   /* q|k|v / to_out linears of the two VAE mid-block attentions */
+  SDM_PRECISE_UNET_RES = 8,       /* U-Net conv_in/out, ResBlock convs, shortcuts, down/up-samplers */
+  SDM_PRECISE_UNET_TF = 16,       /* U-Net transformer linears (proj_in/out, q|k|v, to_out, GEGLU, folded cross K|V) */
+  SDM_PRECISE_UNET_ATTN = 32,     /* U-Net attention cores (QK^T, softmax, PV; head dim 64) */
+  SDM_PRECISE_ALL = 63            /* (the single-head d=512 VAE attention core always runs on fp16 operands) */
+};
 
 /* Fill `cfg` with the SD-2.1-base / SDMatte constants. */
 void sdm_default_config(sdm_config* cfg);
@@ -95,7 +111,13 @@ int sdm_import_host_blob(sdm_ctx* ctx, const void* host_src);
  *   trimap fp32 [B,1,S,S]  = data["trimap"]  (in [-1,1])
  *   is_trans int32 [B]     = data["is_trans"];  coords fp32 [B,4] = data["trimap_coords"] (NULL -> [0,0,1,1])
  *   alpha  fp32 [B,1,S,S]  = return value in [0,1]
- * is_trans / coords are always HOST pointers (tiny).  `stream` is a hipStream_t (NULL = engine stream). */
+ * is_trans / coords are always HOST pointers (tiny).
+ * Stream contract (all sdm_forward* / sdm_apply_matte): kernels run on a stream owned by the engine.  With SDM_PTR_DEVICE,
+ * `stream` is the hipStream_t on which the caller produced the inputs and will consume the outputs - in PyTorch,
+ * torch.cuda.current_stream().cuda_stream; NULL = the device's default stream.  The engine orders its work after everything
+ * queued on that stream at call time (event wait, no host sync) and makes that stream wait for the outputs, so the call
+ * behaves like any other kernel launch on `stream`.  With SDM_PTR_HOST the call copies in, runs, copies out and returns after
+ * a host synchronisation; `stream` is ignored. */
 int sdm_forward(sdm_ctx* ctx, const float* image_b3ss, const float* trimap_b1ss, int B, int S, const int32_t* is_trans,
                 const float* coords_b4, float* alpha_b1ss, int ptr_kind, void* stream);
 

@@ -1,11 +1,11 @@
 """-m gpu: end-to-end parity of the HIP engine against the CPU oracle on the same seeded weights + inputs.
 
-Tolerances.  The north star asks for max|d alpha| <= 1e-3 vs the reference's fp32 CPU path.  Any evaluation
-of this graph with fp16 MFMA operands (the reference's own CUDA autocast path included)
-differs from the fp32 path by more than that on synthetic (untrained, un-saturated) weights: rounding ONLY the
-weights to fp16 inside the fp32 oracle moves alpha by ~3e-3 max / 4e-4 mean (tests/test_precision_floor.py).
-The engine therefore is held to: (a) no further from the fp32 oracle than 1.5x the oracle's own fp16-operand
-emulation, (b) max <= 1e-2 and mean <= 1.5e-3 absolute; measured values are printed and recorded in DESIGN.md."""
+Tolerance = the north star's: max |d alpha| <= 1e-3 against the reference's fp32 CPU path (sdmatte_nodes.py:355-360), asserted
+on the engine's DEFAULT precision ("fp16x3": split-fp16 operands, fp32 activations, fp32 accumulation) for the tiny
+architectures, the full SD-2.1 architecture at 512x512 (BASELINE config #1/#2 graph) and a 768x768 node-level run (config #4).
+The opt-in fast mode (precision="fp16": plain fp16 MFMA operands) cannot meet 1e-3 - rounding ONLY the weights, or ONLY the
+conv/linear inputs, to fp16 inside the fp32 oracle already moves alpha by ~3e-3 - and is held to that measured floor instead
+(test_e2e_fast_mode_stays_at_the_fp16_operand_floor)."""
 import os
 import sys
 
@@ -15,6 +15,8 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+TOL = 1e-3          # BASELINE.json north_star: alpha within 1e-3 max abs of the reference CPU path
 
 
 def _fp16_operand_oracle(O, w, cfgd, data):
@@ -29,75 +31,117 @@ def _fp16_operand_oracle(O, w, cfgd, data):
         F.conv2d, F.linear = oc, ol
 
 
-def _run(pkg, cfg, S, B, seed=1234):
+def _model(cfg, w, precision=None):
+    from comfyui_sdmatte_amd.core import SDMatte
+    m = SDMatte(None, use_aux_input=True, aux_input="trimap", aux_input_list=["trimap"], attn_mask_aux_input=["trimap"], load_weight=False,
+                config=cfg, precision=precision)
+    m.load_state_dict(w, strict=False)
+    m.eval().to("cuda:0")
+    assert not m.missing_keys
+    return m
+
+
+def _run(pkg, cfg, S, B, seed=1234, precision=None):
     from comfyui_sdmatte_amd.weights import synthetic_state_dict
     from comfyui_sdmatte_amd.synth import synthetic_inputs
-    from comfyui_sdmatte_amd.core import SDMatte
     from oracle import sdmatte_oracle as O
     w = synthetic_state_dict(cfg, 0)
     img, tri = synthetic_inputs(B, S, S, seed)
     data = O.preprocess(img, tri, S, False)
     ref = O.sdmatte_forward(w, cfg.as_dict(), data)
-    emu16 = _fp16_operand_oracle(O, w, cfg.as_dict(), data)
-    m = SDMatte(None, use_aux_input=True, aux_input="trimap", aux_input_list=["trimap"], attn_mask_aux_input=["trimap"], load_weight=False,
-                config=cfg)
-    m.load_state_dict(w, strict=False)
-    m.eval().to("cuda:0")
-    assert not m.missing_keys
+    m = _model(cfg, w, precision)
     dcu = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data.items()}
     out = m(dcu).cpu()
     d = (out - ref).abs()
-    floor = (emu16 - ref).abs()
-    print(f"\n[{cfg.name} S={S} B={B}] max|d|={d.max():.3e} mean|d|={d.mean():.3e}  fp16-operand floor: max={floor.max():.3e} mean={floor.mean():.3e}")
-    return m, w, img, tri, data, ref, out, d, floor
+    print(f"\n[{cfg.name} S={S} B={B} precision={precision or 'default'}] max|d|={d.max():.3e} mean|d|={d.mean():.3e} "
+          f"gpu_ms={m.engine.last_forward_ms():.2f}")
+    return m, w, img, tri, data, ref, out, d
 
 
-def _assert_parity(d, floor):
-    # `floor` is ONE realisation of fp16-operand rounding (a different summation order gives another): the mean is a stable
-    # statistic and is held to 1.5x; the max over ~1e4 pixels is heavy-tailed (seed-to-seed spread 3.5e-3 .. 5.8e-3 for the same
-    # kernels) and is held to 2x, plus the absolute caps below
-    assert d.mean().item() <= max(1.5 * floor.mean().item(), 2e-4)
-    assert d.max().item() <= max(2.0 * floor.max().item(), 1e-3)
-    assert d.max().item() <= 1e-2 and d.mean().item() <= 1.5e-3
+def test_default_precision_is_the_parity_mode(pkg):
+    from comfyui_sdmatte_amd import engine
+    assert engine.DEFAULT_PRECISION == "fp16x3" or os.environ.get("SDMATTE_PRECISION")
+    assert engine.precise_mask_of("fp16x3") == engine.PRECISE_ALL and engine.precise_mask_of("fp16") == 0
 
 
 def test_e2e_tiny_core_api(pkg):
     from comfyui_sdmatte_amd.config import SDMatteConfig
-    m, w, img, tri, data, ref, out, d, floor = _run(pkg, SDMatteConfig.tiny(), 64, 3)
-    _assert_parity(d, floor)
-    # batch invariance on the GPU path: image 1 alone == image 1 in the batch
+    m, w, img, tri, data, ref, out, d = _run(pkg, SDMatteConfig.tiny(), 64, 3)
+    assert d.max().item() <= TOL
+    # batch invariance on the GPU path: image 1 alone == image 1 in the batch (B changes tile shapes -> fp32 summation order only)
     d1 = {k: (v[1:2].cuda() if torch.is_tensor(v) else v[1:2]) for k, v in data.items()}
     o1 = m(d1).cpu()
-    # not bitwise: B changes the tile configuration -> fp32 summation order -> occasional fp16 rounding flips
-    assert (o1[0] - out[1]).abs().max().item() < 5e-3 and (o1[0] - out[1]).abs().mean().item() < 5e-4
+    assert (o1[0] - out[1]).abs().max().item() < TOL
     # is_trans flips the opacity embedding -> output must change and still match the oracle
     from oracle import sdmatte_oracle as O
     data_t = dict(data); data_t["is_trans"] = torch.ones_like(data["is_trans"])
     ref_t = O.sdmatte_forward(w, SDMatteConfig.tiny().as_dict(), data_t)
     out_t = m({k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data_t.items()}).cpu()
     assert (ref_t - ref).abs().max().item() > 1e-3
-    assert (out_t - ref_t).abs().max().item() <= 1e-2 and (out_t - ref_t).abs().mean().item() <= 1.5e-3
+    assert (out_t - ref_t).abs().max().item() <= TOL
     m.engine.close()
 
 
 def test_e2e_tiny_s192_ragged_levels(pkg):
     from comfyui_sdmatte_amd.config import SDMatteConfig
     # S=192 -> latent 24, levels 24/12/6/3: token counts 576/144/36/9 (ragged vs the 64-key / 128-query tiles)
-    m, w, img, tri, data, ref, out, d, floor = _run(pkg, SDMatteConfig.tiny(), 192, 1)
-    _assert_parity(d, floor)
+    m, w, img, tri, data, ref, out, d = _run(pkg, SDMatteConfig.tiny(), 192, 1)
+    assert d.max().item() <= TOL
     m.engine.close()
 
 
 def test_e2e_tiny_d512_vae_attention(pkg):
     from comfyui_sdmatte_amd.config import SDMatteConfig
-    m, w, img, tri, data, ref, out, d, floor = _run(pkg, SDMatteConfig.tiny_d512(), 128, 1)
-    _assert_parity(d, floor)
+    m, w, img, tri, data, ref, out, d = _run(pkg, SDMatteConfig.tiny_d512(), 128, 1)
+    assert d.max().item() <= TOL
     m.engine.close()
 
 
+def test_e2e_fast_mode_stays_at_the_fp16_operand_floor(pkg):
+    """precision="fp16" (opt-in): no further from the fp32 oracle than the oracle's own fp16-operand emulation allows."""
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    from oracle import sdmatte_oracle as O
+    cfg = SDMatteConfig.tiny()
+    m, w, img, tri, data, ref, out, d = _run(pkg, cfg, 64, 3, precision="fp16")
+    floor = (_fp16_operand_oracle(O, w, cfg.as_dict(), data) - ref).abs()
+    print(f"fp16-operand floor: max={floor.max():.3e} mean={floor.mean():.3e}")
+    assert d.mean().item() <= max(1.5 * floor.mean().item(), 2e-4)
+    assert d.max().item() <= max(2.0 * floor.max().item(), 1e-3)
+    assert d.max().item() <= 1e-2 and d.mean().item() <= 1.5e-3
+    m.engine.close()
+
+
+def test_e2e_per_stage_precision_attribution(pkg):
+    """Each stage bit of sdm_config::precise_mask on its own lowers the error of the fast mode, and all bits together reach the
+    parity bar (the per-stage table in DESIGN.md 2 comes from the same sweep on the full architecture)."""
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    from comfyui_sdmatte_amd import engine as E
+    from comfyui_sdmatte_amd.weights import synthetic_state_dict
+    from comfyui_sdmatte_amd.synth import synthetic_inputs
+    from oracle import sdmatte_oracle as O
+    cfg = SDMatteConfig.tiny()
+    w = synthetic_state_dict(cfg, 0)
+    img, tri = synthetic_inputs(2, 128, 128, 7)
+    data = O.preprocess(img, tri, 128, False)
+    ref = O.sdmatte_forward(w, cfg.as_dict(), data)
+    rms = {}
+    for mask in (0, E.PRECISE_VAE_ENC, E.PRECISE_VAE_DEC, E.PRECISE_UNET_RES, E.PRECISE_UNET_TF, E.PRECISE_UNET_ATTN, E.PRECISE_ALL):
+        eng = E.Engine(cfg, 0, precision=mask)
+        eng.load_state_dict(w)
+        out = eng.forward(data["image"].cuda(), data["trimap"].cuda(), is_trans=data["is_trans"].numpy()).cpu()
+        dd = out - ref
+        rms[mask] = dd.pow(2).mean().sqrt().item()
+        print(f"precise_mask={mask:2d}: max|d|={dd.abs().max():.3e} rms={rms[mask]:.3e}")
+        if mask == E.PRECISE_ALL:
+            assert dd.abs().max().item() <= TOL
+        eng.close()
+    assert rms[E.PRECISE_ALL] < 0.25 * rms[0]
+    assert rms[E.PRECISE_VAE_ENC] < rms[0] and rms[E.PRECISE_UNET_RES] < rms[0]
+
+
 def test_e2e_node_api_resize_refine_compose(pkg, tmp_path, monkeypatch):
-    """Config #4-like: non-square 100x120 input at S=128 through the real node signature, mask_refine + trimap_constraint,
-    all output modes; checkpoint is a synthetic safetensors file discovered through the registered model folder."""
+    """Node signature on a non-square 100x120 input at S=128 (tiny architecture): mask_refine + trimap_constraint, all output
+    modes; checkpoint is a synthetic safetensors file discovered through the registered model folder."""
     from safetensors.torch import save_file
     from comfyui_sdmatte_amd.config import SDMatteConfig
     from comfyui_sdmatte_amd.weights import synthetic_state_dict
@@ -119,10 +163,10 @@ def test_e2e_node_api_resize_refine_compose(pkg, tmp_path, monkeypatch):
         a, mimg = node.apply_matte("SDMatte_plus.safetensors", img, tri, 128, False, mode, True, 0.8)
         ra, rm = O.apply_matte(w, cfg.as_dict(), img, tri, 128, False, mode, True, 0.8)
         assert a.shape == ra.shape and mimg.shape == rm.shape and a.device.type == "cpu"
-        # refined alpha has hard thresholds (a<0.3 -> 0, x1.2 clamp): compare where both sides are away from a threshold flip
+        # refined alpha has hard thresholds (a<0.3 -> 0, x1.2 clamp): a pixel within the tolerance of a threshold may flip
         diff = (a - ra).abs()
-        frac_bad = (diff > 1e-2).float().mean().item()
-        assert frac_bad < 5e-3, f"{mode}: {frac_bad}"
+        frac_bad = (diff > 1.2 * TOL).float().mean().item()
+        assert frac_bad < 1e-3, f"{mode}: {frac_bad}"
         assert torch.equal(mimg[..., :3], rm[..., :3]) or mode == "matted_rgb"
     with pytest.raises(RuntimeError):
         node.apply_matte("SDMatte_plus.safetensors", img, tri, 128, False, "alpha_only", True, 0.8, force_cpu=True)
@@ -158,7 +202,6 @@ def test_weight_blob_roundtrip_and_rccl_path(pkg):
     """Multi-GPU plumbing on ONE device: (1) export the packed weight blob from one engine and import it into a second one ->
     bit-identical alphas (what every non-zero rank does after the RCCL broadcast); (2) the torch.distributed 'nccl' (= RCCL)
     calls of parallel.py with world_size 1 (broadcast + gather run end to end on the GPU)."""
-    import os
     import torch.distributed as dist
     from comfyui_sdmatte_amd.config import SDMatteConfig
     from comfyui_sdmatte_amd.engine import Engine
@@ -191,21 +234,92 @@ def test_weight_blob_roundtrip_and_rccl_path(pkg):
     e0.close(); e1.close()
 
 
+def test_stream_ordering_against_the_callers_stream(pkg):
+    """The C ABI orders itself after the caller's stream (include/sdmatte.h): inputs that are still being produced by torch kernels
+    on a side stream when the call is made (a long matmul chain, then a non-contiguous view that Engine makes contiguous on
+    that stream) must be seen complete, and the output must be usable on that stream without a host sync."""
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    from comfyui_sdmatte_amd.engine import Engine
+    from comfyui_sdmatte_amd.weights import synthetic_state_dict
+    from comfyui_sdmatte_amd.synth import synthetic_inputs
+    cfg = SDMatteConfig.tiny()
+    eng = Engine(cfg, 0)
+    eng.load_state_dict(synthetic_state_dict(cfg, 0))
+    img, tri = synthetic_inputs(2, 128, 128, seed=3)
+    want = eng.apply_matte(img.cuda(), tri.cuda(), 128).cpu()
+    side = torch.cuda.Stream()
+    big = torch.randn(4096, 4096, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(3):
+        with torch.cuda.stream(side):
+            x = big
+            for _ in range(40):                      # ~100 ms of queued work ahead of the input producers
+                x = (x @ big) * 1e-3
+            # produced late on the side stream, channel-last-of-4 view -> Engine.apply_matte runs .contiguous() on `side` too
+            img4 = torch.cat([img.cuda(non_blocking=True), torch.zeros(2, 128, 128, 1, device="cuda")], dim=-1) + 0.0 * x[0, 0]
+            tri_d = tri.cuda(non_blocking=True) + 0.0 * x[0, 0]
+            got = eng.apply_matte(img4[..., :3], tri_d, 128, sync=False)
+            got2 = got * 1.0                          # consumer on the caller's stream, no host sync in between
+        side.synchronize()
+        assert torch.equal(got2.cpu(), want)
+    with pytest.raises(ValueError):
+        eng.apply_matte(img, tri.cuda(), 128)        # mixed host / device tensors
+    eng.close()
+
+
 @pytest.mark.slow
 def test_e2e_full_model_512(pkg):
     """BASELINE config #1 size on the real SD-2.1 architecture (synthetic weights): 512x512, B=1, vs the fp32 CPU oracle."""
     from comfyui_sdmatte_amd.config import SDMatteConfig
-    m, w, img, tri, data, ref, out, d, floor = _run(pkg, SDMatteConfig.full(), 512, 1)
-    _assert_parity(d, floor)
+    m, w, img, tri, data, ref, out, d = _run(pkg, SDMatteConfig.full(), 512, 1)
+    assert d.max().item() <= TOL
     m.engine.close()
+
+
+@pytest.mark.slow
+def test_e2e_config4_768_sdmatte_plus_node_refine(pkg, tmp_path):
+    """BASELINE config #4: 768x768, a checkpoint named SDMatte_plus.safetensors (full SD-2.1 architecture, synthetic weights)
+    through the ComfyUI node signature with mask_refine + trimap_constraint, vs the oracle."""
+    from safetensors.torch import save_file
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    from comfyui_sdmatte_amd.weights import synthetic_state_dict
+    from comfyui_sdmatte_amd.synth import synthetic_inputs
+    from comfyui_sdmatte_amd import sdmatte_nodes as N
+    from oracle import sdmatte_oracle as O
+    cfg = SDMatteConfig.full()
+    w = synthetic_state_dict(cfg, 0)
+    d = tmp_path / "SDMatte"
+    d.mkdir()
+    save_file({k: v.contiguous() for k, v in w.items()}, str(d / "SDMatte_plus.safetensors"))
+    N.folder_paths.add_model_folder_path("SDMatte", str(d))
+    N._MODEL_CACHE.clear()
+    S = 768
+    img, tri = synthetic_inputs(1, S, S, seed=44)
+    pred = O.sdmatte_forward(w, cfg.as_dict(), O.preprocess(img, tri, S, False))
+    node = N.SDMatteApply()
+    a_raw, _ = node.apply_matte("SDMatte_plus.safetensors", img, tri, S, False, "alpha_only", False, 0.8)
+    r_raw, _ = O.postprocess(pred, img, tri, "alpha_only", False, 0.8)
+    d_raw = (a_raw - r_raw).abs()
+    print(f"\n[config #4 768 raw alpha] max|d|={d_raw.max():.3e} mean|d|={d_raw.mean():.3e}")
+    assert d_raw.max().item() <= TOL
+    a, mimg = node.apply_matte("SDMatte_plus.safetensors", img, tri, S, False, "matted_rgba", True, 0.8)
+    ra, rm = O.postprocess(pred, img, tri, "matted_rgba", True, 0.8)
+    # mask_refine: x1.2 on foreground pixels and a hard a<0.3 -> 0 cut in the unknown band: only pixels whose raw alpha sits
+    # within the tolerance of the cut may differ by more than 1.2 * TOL
+    near_cut = (r_raw - 0.3).abs() <= TOL
+    dd = (a - ra).abs()
+    assert dd[~near_cut].max().item() <= 1.2 * TOL
+    assert near_cut.float().mean().item() < 1e-2
+    assert mimg.shape == rm.shape == (1, S, S, 4) and torch.equal(mimg[..., :3], rm[..., :3])
+    N._MODEL_CACHE.clear()
 
 
 @pytest.mark.slow
 def test_e2e_full_model_1024_properties(pkg, monkeypatch):
     """BASELINE config #2/#3 size (1024x1024, full architecture, synthetic weights).  The fp32 oracle needs minutes per image at this
-    size (profiles/r01_parity_fullsize.json holds that comparison), so the test checks size-independent properties instead:
-    determinism, batch-position independence (image i of a batch == the same image alone, bit for bit: nothing mixes images),
-    range, and that skipping the key tiles whose trimap bias underflows the softmax is bit-identical to walking every tile."""
+    size (bench.py times it; profiles/ holds the comparison), so the test checks size-independent properties instead:
+    determinism, batch-position independence (image i of a batch == the same image alone: nothing mixes images), range, and
+    that skipping the key tiles whose trimap bias underflows the softmax is bit-identical to walking every tile."""
     from comfyui_sdmatte_amd.config import SDMatteConfig
     from comfyui_sdmatte_amd.engine import Engine
     from comfyui_sdmatte_amd.synth import synthetic_inputs
@@ -225,15 +339,137 @@ def test_e2e_full_model_1024_properties(pkg, monkeypatch):
     swapped = eng.apply_matte(img.flip(0), tri.flip(0), S, False).cpu()
     assert torch.equal(swapped.flip(0), a)                         # batch position does not matter
     single = eng.apply_matte(img[1:2].contiguous(), tri[1:2].contiguous(), S, False).cpu()
-    # ... nor does the batch size, up to the fp16-operand floor: a different batch can select other tile shapes for the
-    # low-resolution layers, i.e. another fp32 summation order
+    # ... nor does the batch size: another batch can select other tile shapes for the low-resolution layers, i.e. another
+    # fp32 summation order - far inside the parity tolerance
     ds = (single[0] - a[1]).abs()
     print(f"\n[full 1024 B=1 vs B=2] max|d|={ds.max():.3e} mean|d|={ds.mean():.3e}")
-    assert ds.max().item() <= 5e-3 and ds.mean().item() <= 5e-4
+    assert ds.max().item() <= TOL
     monkeypatch.setenv("SDM_ATTN_DENSE", "1")
     dense = eng.apply_matte(img, tri, S, False).cpu()
     assert torch.equal(dense, a)                                   # exact sparsity: same bits as the dense key walk
     eng.close()
+
+
+def test_e2e_config5_mixed_resolution_stream_matted_rgba(pkg):
+    """BASELINE config #5 on one GPU: a request stream cycling inference sizes 512 / 768 / 1024 through parallel.matte_stream
+    (bucketing by size, equal-shape micro-batches) and the node's matted_rgba composition, vs the oracle (tiny architecture so
+    that the CPU side finishes in seconds; the 8-GPU placement of the same code is covered by the gloo / NCCL tests)."""
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    from comfyui_sdmatte_amd.engine import Engine
+    from comfyui_sdmatte_amd.weights import synthetic_state_dict
+    from comfyui_sdmatte_amd.synth import synthetic_inputs
+    from comfyui_sdmatte_amd import parallel
+    from comfyui_sdmatte_amd.sdmatte_nodes import refine_and_compose
+    from oracle import sdmatte_oracle as O
+    cfg = SDMatteConfig.tiny()
+    w = synthetic_state_dict(cfg, 0)
+    eng = Engine(cfg, 0)
+    eng.load_state_dict(w)
+    sizes = [512, 768, 1024, 512, 768, 512]
+    reqs = []
+    for i, S in enumerate(sizes):
+        im, tr = synthetic_inputs(1, 300 + 40 * (i % 2), 420, seed=100 + i)      # two input shapes, resized to S by the engine
+        reqs.append((im[0], tr[0], S))
+    got = parallel.matte_stream(eng, [r[0].cuda() for r in reqs], [r[1].cuda() for r in reqs], sizes, micro_batch=2)
+    assert len(got) == len(reqs)
+    for (im, tr, S), a in zip(reqs, got):
+        ra, rm = O.apply_matte(w, cfg.as_dict(), im[None], tr[None], S, False, "matted_rgba", False, 0.8)
+        out, matted = refine_and_compose(a.cpu()[None], im[None], tr[None], "matted_rgba", False, 0.8)
+        dd = (out - ra).abs()
+        print(f"[stream S={S} {tuple(im.shape[:2])}] max|d|={dd.max():.3e}")
+        assert dd.max().item() <= TOL and matted.shape == rm.shape and (matted - rm).abs().max().item() <= TOL
+    eng.close()
+
+
+def _nccl_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from __graft_entry__ import load_package
+    load_package()
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    from comfyui_sdmatte_amd.engine import Engine
+    from comfyui_sdmatte_amd.weights import synthetic_state_dict
+    from comfyui_sdmatte_amd.synth import synthetic_inputs
+    from comfyui_sdmatte_amd import parallel
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    cfg = SDMatteConfig.tiny()
+    eng = Engine(cfg, rank)
+    if rank == 0:
+        eng.load_state_dict(synthetic_state_dict(cfg, 0))
+    parallel.broadcast_weights(eng, 0, dev)
+    img, tri = synthetic_inputs(2 * world, 128, 128)
+    lo, hi = parallel.shard_range(2 * world, world, rank)
+    a = eng.apply_matte(img[lo:hi].to(dev), tri[lo:hi].to(dev), 128)
+    outs = parallel.gather_alphas(a, 0)
+    sizes = [128, 192, 128, 192, 128]
+    ims = [synthetic_inputs(1, 96, 80, seed=50 + i) for i in range(len(sizes))]
+    res = parallel.matte_stream(eng, [x[0][0].to(dev) for x in ims], [x[1][0].to(dev) for x in ims], sizes, micro_batch=2, dst=0, device=dev)
+    if rank == 0:
+        q.put((torch.cat([o.cpu() for o in outs], 0), [r.cpu() for r in res]))
+    dist.barrier()
+    dist.destroy_process_group()
+    eng.close()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs (the driver's multi-GPU tier)")
+def test_multi_gpu_rccl_broadcast_shard_gather_and_stream(pkg):
+    """Configs #3/#5 on real RCCL: one process per GPU, weight broadcast, contiguous batch shards, alpha gather and the
+    mixed-resolution request stream, vs the oracle."""
+    import torch.multiprocessing as mp
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    from comfyui_sdmatte_amd.weights import synthetic_state_dict
+    from comfyui_sdmatte_amd.synth import synthetic_inputs
+    from oracle import sdmatte_oracle as O
+    world = min(torch.cuda.device_count(), 8)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_nccl_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, stream = q.get(timeout=900)
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    cfg = SDMatteConfig.tiny()
+    w = synthetic_state_dict(cfg, 0)
+    img, tri = synthetic_inputs(2 * world, 128, 128)
+    ref, _ = O.apply_matte(w, cfg.as_dict(), img, tri, 128, mask_refine=False)
+    assert got.shape == ref.shape and (got - ref).abs().max().item() <= TOL
+    sizes = [128, 192, 128, 192, 128]
+    for i, (S, a) in enumerate(zip(sizes, stream)):
+        im, tr = synthetic_inputs(1, 96, 80, seed=50 + i)
+        r, _ = O.apply_matte(w, cfg.as_dict(), im, tr, S, mask_refine=False)
+        assert (a - r[0]).abs().max().item() <= TOL
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs (the driver's multi-GPU tier)")
+def test_in_process_multi_gpu_fanout(pkg):
+    """The node's single-process fan-out (ComfyUI is one process): one engine + host thread per visible GPU, weights copied
+    device to device, batch split contiguously; same alphas as one engine."""
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    from comfyui_sdmatte_amd.engine import Engine
+    from comfyui_sdmatte_amd.parallel import MultiGpuEngine
+    from comfyui_sdmatte_amd.weights import synthetic_state_dict
+    from comfyui_sdmatte_amd.synth import synthetic_inputs
+    cfg = SDMatteConfig.tiny()
+    w = synthetic_state_dict(cfg, 0)
+    one = Engine(cfg, 0)
+    one.load_state_dict(w)
+    fan = MultiGpuEngine(cfg, list(range(min(torch.cuda.device_count(), 8))))
+    fan.load_state_dict(w)
+    from comfyui_sdmatte_amd.parallel import shard_range
+    img, tri = synthetic_inputs(5, 100, 120)                           # host tensors, uneven split
+    n = min(len(fan.engines), 5)
+    want = torch.cat([one.apply_matte(img[lo:hi].cuda(), tri[lo:hi].cuda(), 128).cpu()
+                      for lo, hi in (shard_range(5, n, r) for r in range(n)) if hi > lo])
+    got = fan.apply_matte(img, tri, 128)
+    assert got.device.type == "cpu" and torch.equal(got, want)       # same bits as one engine fed the same shards
+    one.close(); fan.close()
 
 
 def test_e2e_other_prompt_types(pkg):
@@ -267,7 +503,7 @@ def test_e2e_other_prompt_types(pkg):
         ref = O.sdmatte_forward(w, cfg.as_dict(), data, aux_input=aux_input, **kw)
         d = (out - ref).abs()
         print(f"\n[{aux_input} {kw}] max|d|={d.max():.3e} mean|d|={d.mean():.3e}")
-        assert d.max().item() <= 1e-2 and d.mean().item() <= 1.5e-3
+        assert d.max().item() <= TOL
         m.engine.close()
 
 
@@ -290,5 +526,5 @@ def test_e2e_rectangular_inference(pkg):
         out = eng.forward(data["image"].cuda(), data["trimap"].cuda(), is_trans=data["is_trans"].numpy()).cpu()
         d = (out - ref).abs()
         print(f"\n[rect {H}x{W}] max|d|={d.max():.3e} mean|d|={d.mean():.3e}")
-        assert out.shape == (2, 1, H, W) and d.max().item() <= 1e-2 and d.mean().item() <= 1.5e-3
+        assert out.shape == (2, 1, H, W) and d.max().item() <= TOL
     eng.close()
