@@ -406,20 +406,25 @@ conv_mfma_kernel(ConvParams p) {
   }
   for (int c0 = 0; c0 < Cin; c0 += KC) {
     if (SPLIT) {
+      const bool abl_ld = (p.ablate & 1) != 0, abl_wr = (p.ablate & 2) && c0 > 0, abl_mm = (p.ablate & 4) && c0 > 0;   // bench only
       __syncthreads();            // every wave has finished reading the previous chunk from LDS
-      write_lds_a(As, c0);        // A_hi and A_lo halo tiles
-      write_lds_b(Bs);            // w_hi taps of this chunk
+      if (!abl_wr) {
+        write_lds_a(As, c0);      // A_hi and A_lo halo tiles
+        write_lds_b(Bs);          // w_hi taps of this chunk
+      }
       __syncthreads();
-      issue_loads_b(c0, rsw_lo);  // w_lo taps of this chunk: in flight during the two MFMA passes below
-      mfma_chunk(As);                       // A_hi . w_hi
-      mfma_chunk(As + C::A_BYTES);          // A_lo . w_hi
+      if (!abl_ld) issue_loads_b(c0, rsw_lo);  // w_lo taps of this chunk: in flight during the two MFMA passes below
+      if (!abl_mm) {
+        mfma_chunk(As);                       // A_hi . w_hi
+        mfma_chunk(As + C::A_BYTES);          // A_lo . w_hi
+      }
       __syncthreads();            // every wave is done with the w_hi taps
-      write_lds_b(Bs);
+      if (!abl_wr) write_lds_b(Bs);
       __syncthreads();
       // next chunk's activations and w_hi taps: in flight during the third pass (issued only now, when the B staging
       // registers are free again: the A + B staging sets together with 128 accumulators are what fits in 256 registers)
-      if (c0 + KC < Cin) { issue_loads_a(c0 + KC); issue_loads_b(c0 + KC, rsw); }
-      mfma_chunk(As);                       // A_hi . w_lo
+      if (c0 + KC < Cin && !abl_ld) { issue_loads_a(c0 + KC); issue_loads_b(c0 + KC, rsw); }
+      if (!abl_mm) mfma_chunk(As);            // A_hi . w_lo
       continue;
     }
     if (DB) {

@@ -1809,20 +1809,24 @@ int sdm_profile_get(sdm_ctx* e, int i, const char** name, float* ms, int64_t* la
 // ---- single-operator entry points ----
 int sdm_conv_num_cfgs(int ntaps, int stride) { return conv_num_cfgs(ntaps, stride); }
 
-int sdm_op_conv(sdm_ctx* e, const void* in0, const void* in1, int C0, int C1, int in_f32, int N, int Hin, int Win, int up, int stride,
-                int pad_mode, int ntaps, const float* w, const float* bias, int O, void* out, int out_f32, const void* res, int res_f32,
-                int geglu, float out_scale, int tile_cfg) {
+int sdm_op_conv_ex(sdm_ctx* e, const void* in0, const void* in1, int C0, int C1, int in_f32, int N, int Hin, int Win, int up, int stride,
+                   int pad_mode, int ntaps, const float* w, const float* bias, int O, void* out, int out_f32, const void* res, int res_f32,
+                   int geglu, float out_scale, int tile_cfg, int split, const float* gn_gamma, const float* gn_beta, float gn_eps,
+                   int gn_groups, int gn_silu) {
   if (e) dev_use(e->device);
   if (!e || !in0 || !w || !out) return SDM_ERR_INVALID;
   if (C0 % 16 || C1 % 16) SDM_FAIL(e, SDM_ERR_INVALID, "sdm_op_conv: channel counts must be multiples of 16");
+  if (split && !in_f32) SDM_FAIL(e, SDM_ERR_INVALID, "sdm_op_conv_ex: split precision takes fp32 activations");
   ConvL L;
   L.name = "op"; L.ntaps = ntaps; L.I = C0 + C1; L.O = O; L.Cin_pad = C0 + C1; L.Cout_pad = rup(O, geglu ? 64 : 32); L.geglu = geglu;
-  void* wp = nullptr; void* bp = nullptr;
+  L.split = split ? 1 : 0; L.w_exp = split ? kSplitWeightExp : 0;
+  void* wp = nullptr; void* bp = nullptr; void* wl = nullptr;
   const size_t wbytes = (size_t)L.Cin_pad * ntaps * L.Cout_pad * 2;
   SDM_CHECK_DEV(e, dev_malloc(&wp, wbytes));
   SDM_CHECK_DEV(e, dev_malloc(&bp, (size_t)L.Cout_pad * 4));
+  if (split) { SDM_CHECK_DEV(e, dev_malloc(&wl, wbytes)); dev_memset(wl, 0, wbytes, e->stream); }
   dev_memset(wp, 0, wbytes, e->stream); dev_memset(bp, 0, (size_t)L.Cout_pad * 4, e->stream);
-  L.w = (half_t*)wp; L.b = (float*)bp;
+  L.w = (half_t*)wp; L.b = (float*)bp; L.w_lo = (half_t*)wl;
   const size_t total = (size_t)L.Cin_pad * ntaps * L.Cout_pad;
   SDM_LAUNCH(pack_conv_weight_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 65535)), dim3(256), 0, e->stream, w, L.w, O, L.I, ntaps,
              L.Cin_pad, L.Cout_pad, 0, 0, geglu, ldexpf(1.0f, L.w_exp), L.w_lo);
@@ -1837,16 +1841,88 @@ int sdm_op_conv(sdm_ctx* e, const void* in0, const void* in1, int C0, int C1, in
   tres = tout; tres.p = (void*)res; tres.f32 = res_f32;
   ConvArgs a; a.in0 = &tin0; a.in1 = in1 ? &tin1 : nullptr; a.out = &tout; a.stride = stride; a.pad_mode = pad_mode; a.up = up;
   a.res = res ? &tres : nullptr; a.out_scale = out_scale; a.force_cfg = tile_cfg; a.cout_valid = Cst;
-  e->dry = false;
-  int rc = op_conv(e, L, a);
+  int rc;
+  if (gn_gamma) {
+    // GroupNorm(+SiLU) of the input applied inside the conv's operand staging (the production path of every ResBlock conv):
+    // statistics by the stand-alone kernel, scale/shift table, then the fused-GN instantiation of tile cfg 0 / 4
+    if (ntaps != 9 || stride != 1 || up) { dev_free(wp); dev_free(bp); if (wl) dev_free(wl); SDM_FAIL(e, SDM_ERR_INVALID, "sdm_op_conv_ex: fused GroupNorm needs a 3x3 stride-1 conv"); }
+    if (a.force_cfg != 0 && a.force_cfg != 4) a.force_cfg = (L.Cout_pad <= 32) ? 4 : 0;
+    const int act_prev = e->act_f32;
+    rc = run_two_pass(e, [&]() {
+      T scratch; float* scale; float* shift;
+      TRY(gn_scale_shift(e, in0, in1, C0, C1, in_f32, N, Hin * Win, gn_groups, gn_gamma, gn_beta, gn_eps, nullptr, 0, nullptr, 0, false, &scratch,
+                         &scale, &shift));
+      ConvArgs b = a;
+      b.gn_scale = e->dry ? (const float*)16 : scale; b.gn_shift = shift; b.gn_silu = gn_silu;
+      int r2 = op_conv(e, L, b);
+      tfree(e, scratch);
+      return r2;
+    });
+    e->act_f32 = act_prev;
+  } else {
+    e->dry = false;
+    rc = op_conv(e, L, a);
+  }
   dev_sync(e->stream);
-  dev_free(wp); dev_free(bp);
+  dev_free(wp); dev_free(bp); if (wl) dev_free(wl);
   return rc;
+}
+
+int sdm_op_conv(sdm_ctx* e, const void* in0, const void* in1, int C0, int C1, int in_f32, int N, int Hin, int Win, int up, int stride,
+                int pad_mode, int ntaps, const float* w, const float* bias, int O, void* out, int out_f32, const void* res, int res_f32,
+                int geglu, float out_scale, int tile_cfg) {
+  return sdm_op_conv_ex(e, in0, in1, C0, C1, in_f32, N, Hin, Win, up, stride, pad_mode, ntaps, w, bias, O, out, out_f32, res, res_f32, geglu,
+                        out_scale, tile_cfg, 0, nullptr, nullptr, 0.0f, 32, 0);
+}
+
+/* ---- test hooks for the exact algebraic folds (SURVEY.md 8a "each needs a fold == unfold CPU test") ----------------------- */
+
+/* Run ONE packed layer of the loaded model (by name, e.g. "unet.down_blocks.0.attentions.0.transformer_blocks.0.attn2.kv_folded",
+ * "...attn1.qkv") on an fp32 NHWC input with the layer's padded input channel count; fp32 NHWC output with `Cout` channels. */
+int sdm_debug_run_layer(sdm_ctx* e, const char* layer_name, const float* x, int N, int H, int W, float* out, int Cout) {
+  if (e) dev_use(e->device);
+  if (!e || !layer_name || !x || !out) return SDM_ERR_INVALID;
+  if (!e->finalized) SDM_FAIL(e, SDM_ERR_STATE, "weights not finalised");
+  const ConvL* L = nullptr;
+  for (auto& c : e->convs) if (c.name == layer_name) { L = &c; break; }
+  if (!L) SDM_FAIL(e, SDM_ERR_INVALID, "no packed layer named %s", layer_name);
+  if (Cout % 4 || Cout > L->Cout_pad) SDM_FAIL(e, SDM_ERR_INVALID, "bad Cout %d for layer %s", Cout, layer_name);
+  T tin, tout;
+  tin.p = (void*)x; tin.N = N; tin.H = H; tin.W = W; tin.C = L->Cin_pad; tin.f32 = 1;
+  tout.p = out; tout.N = N; tout.H = H; tout.W = W; tout.C = Cout; tout.f32 = 1;
+  ConvArgs a; a.in0 = &tin; a.out = &tout; a.cout_valid = Cout;
+  e->dry = false;
+  int rc = op_conv(e, *L, a);
+  dev_sync(e->stream);
+  return rc;
+}
+
+/* Folded conv1 bias row (conv1.bias + time_emb_proj(silu(emb)), emb = time_embedding(trans) + bbox_embedding(coords)) of the
+ * i-th ResBlock that has a time embedding, for one (is_trans, box) conditioning; out: cout floats on the HOST. */
+int sdm_debug_temb_row(sdm_ctx* e, int temb_index, int is_trans, const float* coords4, float* out_host, int cout) {
+  if (e) dev_use(e->device);
+  if (!e || !out_host || temb_index < 0 || temb_index >= (int)e->tembs.size()) return SDM_ERR_INVALID;
+  if (!e->finalized) SDM_FAIL(e, SDM_ERR_STATE, "weights not finalised");
+  int32_t it = is_trans;
+  TRY(prepare_variants(e, 1, &it, coords4, 4, 0));
+  Variant v; v.trans = 1 - is_trans; v.kind = 0; v.c.assign(4, 0.0f);
+  const float def[4] = {0.f, 0.f, 1.f, 1.f};
+  for (int k = 0; k < 4; ++k) v.c[k] = coords4 ? coords4[k] : def[k];
+  int idx = -1;
+  for (size_t i = 0; i < e->variants.size(); ++i) if (e->variants[i] == v) idx = (int)i;
+  const TembL& t = e->tembs[(size_t)temb_index];
+  if (idx < 0 || cout > t.cout) SDM_FAIL(e, SDM_ERR_INVALID, "temb row: variant not found / bad cout");
+  SDM_CHECK_DEV(e, dev_memcpy_d2h(out_host, t.table + (size_t)idx * t.cout_pad, (size_t)cout * 4, e->stream));
+  SDM_CHECK_DEV(e, dev_sync(e->stream));
+  return SDM_OK;
 }
 
 /* Bench/ablation helper (not used by the engine): times `iters` launches of one conv with HIP events; returns ms per launch
  * (negative on error).  ablate bits: see ConvParams::ablate. */
 float sdm_bench_conv(sdm_ctx* e, int N, int H, int W, int Cin, int Cout, int ntaps, int stride, int in_f32, int tile_cfg, int ablate, int iters) {
+  // in_f32: bit 0 = fp32 activations, bit 1 = split-precision kernel (implies fp32), bit 2 = fused GroupNorm+SiLU staging
+  const int split = (in_f32 >> 1) & 1, gnf = (in_f32 >> 2) & 1;
+  in_f32 = (in_f32 & 1) | split;
   if (e) dev_use(e->device);
   if (!e) return -1.f;
 #ifdef SDM_EMU
@@ -1854,11 +1930,16 @@ float sdm_bench_conv(sdm_ctx* e, int N, int H, int W, int Cin, int Cout, int nta
 #else
   ConvL L;
   L.name = "bench"; L.ntaps = ntaps; L.I = Cin; L.O = Cout; L.Cin_pad = rup(Cin, 16); L.Cout_pad = rup(Cout, 32);
-  void *wp = nullptr, *bp = nullptr, *in = nullptr, *out = nullptr;
+  void *wp = nullptr, *bp = nullptr, *in = nullptr, *out = nullptr, *wl = nullptr, *gnt = nullptr;
   const int Ho = stride == 2 ? H / 2 : H, Wo = stride == 2 ? W / 2 : W;
   const size_t wbytes = (size_t)L.Cin_pad * ntaps * L.Cout_pad * 2, inb = (size_t)N * H * W * L.Cin_pad * (in_f32 ? 4 : 2),
                outb = (size_t)N * Ho * Wo * L.Cout_pad * 2;
   if (dev_malloc(&wp, wbytes) || dev_malloc(&bp, (size_t)L.Cout_pad * 4) || dev_malloc(&in, inb) || dev_malloc(&out, outb)) return -2.f;
+  if (split) { if (dev_malloc(&wl, wbytes)) return -2.f; SDM_LAUNCH(fill_random_f16_kernel, dim3(2048), dim3(256), 0, e->stream, (half_t*)wl, (long)(wbytes / 2), 19u, 0.0001f); }
+  if (gnf) {      // scale = 1, shift = 0 table [N][Cin] x 2
+    if (dev_malloc(&gnt, (size_t)N * L.Cin_pad * 8)) return -2.f;
+    SDM_LAUNCH(fill_random_f32_kernel, dim3(64), dim3(256), 0, e->stream, (float*)gnt, (long)N * L.Cin_pad * 2, 23u, 1.0f);
+  }
   dev_memset(bp, 0, (size_t)L.Cout_pad * 4, e->stream);
   SDM_LAUNCH(fill_random_f16_kernel, dim3(2048), dim3(256), 0, e->stream, (half_t*)wp, (long)(wbytes / 2), 17u, 0.05f);
   if (in_f32) SDM_LAUNCH(fill_random_f32_kernel, dim3(4096), dim3(256), 0, e->stream, (float*)in, (long)(inb / 4), 5u, 1.0f);
@@ -1871,7 +1952,9 @@ float sdm_bench_conv(sdm_ctx* e, int N, int H, int W, int Cin, int Cout, int nta
   memset(&p, 0, sizeof(p));
   p.in0 = in; p.C0 = L.Cin_pad; p.in_f32 = in_f32; p.N = N; p.Hin = H; p.Win = W; p.Hout = Ho; p.Wout = Wo; p.pad_t = p.pad_l = 1;
   p.M = (long)N * Ho * Wo; p.w = L.w; p.bias = L.b; p.Cout_pad = L.Cout_pad; p.out = out; p.Cout_store = L.Cout_pad; p.Cout_valid = L.Cout_pad;
-  p.out_scale = 1.f; p.ablate = ablate;
+  p.out_scale = 1.f; p.ablate = ablate; p.acc_scale = 1.f;
+  if (split) p.w_lo = (const half_t*)wl;
+  if (gnf) { p.gn_scale = (const float*)gnt; p.gn_shift = (const float*)gnt + (size_t)N * L.Cin_pad; p.gn_silu = 1; }
   int cfg = tile_cfg >= 0 ? tile_cfg : conv_pick_cfg(ntaps, stride, p);
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -1884,6 +1967,8 @@ float sdm_bench_conv(sdm_ctx* e, int N, int H, int W, int Cin, int Cout, int nta
   (void)hipEventElapsedTime(&ms, e0, e1);
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   dev_free(wp); dev_free(bp); dev_free(in); dev_free(out);
+  if (wl) dev_free(wl);
+  if (gnt) dev_free(gnt);
   return ms / (float)iters;
 #endif
 }

@@ -83,7 +83,7 @@ EXPORTS = [
     "sdm_weight_stats", "sdm_missing_key", "sdm_weight_blob_bytes", "sdm_export_weight_blob", "sdm_import_weight_blob",
     "sdm_host_blob_bytes", "sdm_export_host_blob", "sdm_import_host_blob", "sdm_forward", "sdm_forward_ex", "sdm_forward_rect", "sdm_apply_matte",
     "sdm_synchronize", "sdm_last_forward_ms", "sdm_profile_enable", "sdm_profile_count", "sdm_profile_get", "sdm_profile_dump",
-    "sdm_op_conv", "sdm_conv_num_cfgs", "sdm_bench_conv", "sdm_bench_attn", "sdm_op_groupnorm", "sdm_op_layernorm", "sdm_op_attention", "sdm_op_resize_aa",
+    "sdm_op_conv", "sdm_op_conv_ex", "sdm_debug_run_layer", "sdm_debug_temb_row", "sdm_conv_num_cfgs", "sdm_bench_conv", "sdm_bench_attn", "sdm_op_groupnorm", "sdm_op_layernorm", "sdm_op_attention", "sdm_op_resize_aa",
     "sdm_op_mask_bias",
 ]
 
@@ -122,6 +122,10 @@ class Bindings:
                                       C.POINTER(C.c_double)]),
             "sdm_op_conv": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, i32,
                                   f32, i32]),
+            "sdm_op_conv_ex": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, i32,
+                                     f32, i32, i32, vp, vp, f32, i32, i32]),
+            "sdm_debug_run_layer": (i32, [vp, C.c_char_p, vp, i32, i32, i32, vp, i32]),
+            "sdm_debug_temb_row": (i32, [vp, i32, i32, vp, vp, i32]),
             "sdm_conv_num_cfgs": (i32, [i32, i32]),
             "sdm_bench_conv": (f32, [vp] + [i32] * 11),
             "sdm_bench_attn": (f32, [vp] + [i32] * 7),
@@ -312,8 +316,9 @@ class Engine:
 
     # ---- single operators (parity tests) ---------------------------------------------------------
     def op_conv(self, x0, w, bias=None, x1=None, stride=1, pad_mode=0, up=0, res=None, geglu=False, out_f32=False, out_scale=1.0,
-                tile_cfg=-1):
-        """x0/x1: NHWC fp16|fp32 tensors; w: fp32 OIHW or [O,I]; returns NHWC."""
+                tile_cfg=-1, split=False, gn=None):
+        """x0/x1: NHWC fp16|fp32 tensors; w: fp32 OIHW or [O,I]; returns NHWC.  split=True: split-fp16 operands (fp32 inputs);
+        gn=(gamma, beta, eps, groups, silu): GroupNorm(+SiLU) of the input fused into the conv's operand staging."""
         N, H, W_, C0 = x0.shape
         C1 = x1.shape[-1] if x1 is not None else 0
         ntaps = 9 if (w.dim() == 4 and w.shape[-1] == 3) else 1
@@ -326,11 +331,31 @@ class Engine:
         out = torch.empty(N, Ho, Wo, Cst, dtype=torch.float32 if out_f32 else torch.float16, device=x0.device)
         w = w.float().contiguous()
         b = bias.float().contiguous() if bias is not None else None
-        self._check(self.lib.sdm_op_conv(self.h, _ptr(x0), _ptr(x1), C0, C1, int(x0.dtype == torch.float32), N, H, W_, up, stride,
-                                         pad_mode, ntaps, _ptr(w), _ptr(b), O, _ptr(out), int(out_f32), _ptr(res),
-                                         int(res is not None and res.dtype == torch.float32), int(geglu), float(out_scale), tile_cfg),
-                    "sdm_op_conv")
+        gam = gn[0].float().contiguous() if gn is not None else None
+        bet = gn[1].float().contiguous() if gn is not None else None
+        self._check(self.lib.sdm_op_conv_ex(self.h, _ptr(x0), _ptr(x1), C0, C1, int(x0.dtype == torch.float32), N, H, W_, up, stride,
+                                            pad_mode, ntaps, _ptr(w), _ptr(b), O, _ptr(out), int(out_f32), _ptr(res),
+                                            int(res is not None and res.dtype == torch.float32), int(geglu), float(out_scale), tile_cfg,
+                                            int(split), _ptr(gam), _ptr(bet), float(gn[2]) if gn is not None else 0.0,
+                                            int(gn[3]) if gn is not None else 32, int(gn[4]) if gn is not None else 0),
+                    "sdm_op_conv_ex")
         return out[..., :Creal]
+
+    def debug_run_layer(self, name, x_nhwc, cout):
+        """Test hook: one packed layer of the loaded model on an fp32 NHWC input -> fp32 NHWC [N,H,W,cout]."""
+        N, H, W_, _ = x_nhwc.shape
+        x = x_nhwc.float().contiguous()
+        out = torch.empty(N, H, W_, cout, dtype=torch.float32, device=x.device)
+        self._check(self.lib.sdm_debug_run_layer(self.h, name.encode(), _ptr(x), N, H, W_, _ptr(out), cout), "sdm_debug_run_layer")
+        return out
+
+    def debug_temb_row(self, index, is_trans, coords, cout):
+        """Test hook: folded conv1 bias row of the index-th time-embedded ResBlock for one (is_trans, box) conditioning."""
+        out = np.zeros(cout, np.float32)
+        co = None if coords is None else np.ascontiguousarray(np.asarray(coords, np.float32).reshape(4))
+        self._check(self.lib.sdm_debug_temb_row(self.h, index, int(is_trans), co.ctypes.data_as(C.c_void_p) if co is not None else None,
+                                                out.ctypes.data_as(C.c_void_p), cout), "sdm_debug_temb_row")
+        return torch.from_numpy(out)
 
     def bench_conv(self, N, H, W, Cin, Cout, ntaps=9, stride=1, in_f32=0, tile_cfg=-1, ablate=0, iters=10):
         return float(self.lib.sdm_bench_conv(self.h, N, H, W, Cin, Cout, ntaps, stride, in_f32, tile_cfg, ablate, iters))

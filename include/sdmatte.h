@@ -172,6 +172,18 @@ int sdm_op_conv(sdm_ctx* ctx, const void* in0, const void* in1, int C0, int C1, 
                 int stride, int pad_mode, int ntaps, const float* w, const float* bias, int O, void* out, int out_f32,
                 const void* res, int res_f32, int geglu, float out_scale, int tile_cfg);
 int sdm_conv_num_cfgs(int ntaps, int stride);
+/* The same with (a) split != 0: split-fp16 operands (the precise mode's kernels; fp32 activations only) and (b) gn_gamma != NULL:
+ * GroupNorm(gn_groups, eps)(+SiLU) of the input applied inside the conv's operand staging - the production path of every
+ * ResnetBlock2D conv (3x3, stride 1; tile_cfg 0 or 4). */
+int sdm_op_conv_ex(sdm_ctx* ctx, const void* in0, const void* in1, int C0, int C1, int in_f32, int N, int Hin, int Win, int up,
+                   int stride, int pad_mode, int ntaps, const float* w, const float* bias, int O, void* out, int out_f32,
+                   const void* res, int res_f32, int geglu, float out_scale, int tile_cfg, int split, const float* gn_gamma,
+                   const float* gn_beta, float gn_eps, int gn_groups, int gn_silu);
+/* Test hooks for the exact algebraic folds done at load time (cross-attention K|V fold of aux_conv_in, logit scale in to_q,
+ * time/opacity/bbox embedding constants in the conv1 bias tables): run one packed layer by name on an fp32 NHWC input
+ * (DEVICE pointers; channel count = the layer's padded input channels), and read one folded bias row (HOST output). */
+int sdm_debug_run_layer(sdm_ctx* ctx, const char* layer_name, const float* x_nhwc, int N, int H, int W, float* out_nhwc, int Cout);
+int sdm_debug_temb_row(sdm_ctx* ctx, int temb_index, int is_trans, const float* coords4, float* out_host, int cout);
 /* Bench/ablation helper: ms per launch of one conv (random-ish data), HIP-event timed on the engine stream. */
 float sdm_bench_attn(sdm_ctx* ctx, int B, int heads, int Lq, int Lk, int qt, int ablate, int iters);
 float sdm_bench_conv(sdm_ctx* ctx, int N, int H, int W, int Cin, int Cout, int ntaps, int stride, int in_f32, int tile_cfg, int ablate, int iters);

@@ -25,25 +25,39 @@ def h16(x):
 
 
 def check_conv(eng, dev, N, H, W, Cin, Cout, ntaps=9, stride=1, pad_mode=0, up=0, C1=0, in_f32=False, res=None, out_f32=False,
-               geglu=False, out_scale=1.0, tile_cfg=-1, seed=0, atol=2e-2):
+               geglu=False, out_scale=1.0, tile_cfg=-1, seed=0, atol=4e-3, split=False, gn=None):
+    """gn = (eps, silu): GroupNorm(32)(+SiLU) of the input fused into the conv's operand staging (the ResBlock path).
+    split = True: split-fp16 operands (precise mode) - the reference then sees the un-rounded fp32 operands."""
     g = _g(seed)
-    x = h16(torch.randn(N, Cin + C1, H, W, generator=g))
+    rnd = (lambda t: t) if split else h16
+    x = torch.randn(N, Cin + C1, H, W, generator=g)
+    x = x if (in_f32 and (split or gn is not None)) else h16(x)
     if ntaps == 9:
         w = torch.randn(Cout, Cin + C1, 3, 3, generator=g) / math.sqrt((Cin + C1) * 9)
     else:
         w = torch.randn(Cout, Cin + C1, generator=g) / math.sqrt(Cin + C1)
     b = 0.1 * torch.randn(Cout, generator=g)
     xr = x
+    gn_arg = None
+    if gn is not None:
+        eps, silu = gn
+        gamma = 1 + 0.2 * torch.randn(Cin + C1, generator=g)
+        beta = 0.1 * torch.randn(Cin + C1, generator=g)
+        xr = F.group_norm(x, 32, gamma, beta, eps)
+        if silu:
+            xr = F.silu(xr)
+        xr = rnd(xr)                                   # the normalised value is what gets rounded to the MFMA operand type
+        gn_arg = (gamma.to(dev), beta.to(dev), eps, 32, silu)
     if up:
         xr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
     if ntaps == 9:
         if pad_mode == 1:
             xr = F.pad(xr, (0, 1, 0, 1))
-            ref = F.conv2d(xr, h16(w), b, stride=stride, padding=0)
+            ref = F.conv2d(xr, rnd(w), b, stride=stride, padding=0)
         else:
-            ref = F.conv2d(xr, h16(w), b, stride=stride, padding=1)
+            ref = F.conv2d(xr, rnd(w), b, stride=stride, padding=1)
     else:
-        ref = F.conv2d(xr, h16(w)[:, :, None, None], b)
+        ref = F.conv2d(xr, rnd(w)[:, :, None, None], b)
     if geglu:
         u, gg = ref.chunk(2, dim=1)
         ref = u * F.gelu(gg)
@@ -62,11 +76,11 @@ def check_conv(eng, dev, N, H, W, Cin, Cout, ntaps=9, stride=1, pad_mode=0, up=0
         rr = nhwc(r)
         rr = (rr if res == "f32" else rr.half()).to(dev)
     out = eng.op_conv(x0, w.to(dev), b.to(dev), x1=x1, stride=stride, pad_mode=pad_mode, up=up, res=rr, geglu=geglu, out_f32=out_f32,
-                      out_scale=out_scale, tile_cfg=tile_cfg)
+                      out_scale=out_scale, tile_cfg=tile_cfg, split=split, gn=gn_arg)
     got = nchw(out.float().cpu())
     err = (got - ref).abs().max().item()
     assert err < atol, f"conv mismatch max|d|={err:.4g} (ntaps={ntaps} s={stride} pad={pad_mode} up={up} cfg={tile_cfg} " \
-                       f"N={N} H={H} W={W} Cin={Cin}+{C1} Cout={Cout})"
+                       f"N={N} H={H} W={W} Cin={Cin}+{C1} Cout={Cout} split={split} gn={gn})"
     return err
 
 

@@ -277,7 +277,7 @@ def test_e2e_full_model_512(pkg):
 
 
 @pytest.mark.slow
-def test_e2e_config4_768_sdmatte_plus_node_refine(pkg, tmp_path):
+def test_e2e_config4_768_sdmatte_plus_node_refine(pkg, tmp_path, monkeypatch):
     """BASELINE config #4: 768x768, a checkpoint named SDMatte_plus.safetensors (full SD-2.1 architecture, synthetic weights)
     through the ComfyUI node signature with mask_refine + trimap_constraint, vs the oracle."""
     from safetensors.torch import save_file
@@ -291,7 +291,7 @@ def test_e2e_config4_768_sdmatte_plus_node_refine(pkg, tmp_path):
     d = tmp_path / "SDMatte"
     d.mkdir()
     save_file({k: v.contiguous() for k, v in w.items()}, str(d / "SDMatte_plus.safetensors"))
-    N.folder_paths.add_model_folder_path("SDMatte", str(d))
+    monkeypatch.setattr(N.folder_paths, "get_folder_paths", lambda name: [str(d)])     # only THIS folder (earlier tests registered tiny checkpoints)
     N._MODEL_CACHE.clear()
     S = 768
     img, tri = synthetic_inputs(1, S, S, seed=44)

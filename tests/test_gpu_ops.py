@@ -43,6 +43,36 @@ def test_conv3x3_fusions(eng):
     S.check_conv(eng, DEV, 1, 16, 16, 512, 8, seed=55)                                            # encoder conv_out
 
 
+@pytest.mark.parametrize("cfg,cin,cout,H,W,in_f32,silu", [(0, 128, 128, 40, 96, True, True), (0, 128, 128, 40, 96, False, True),
+                                                            (0, 512, 256, 24, 40, True, True), (0, 320, 320, 33, 35, False, False),
+                                                            (4, 128, 3, 70, 100, True, True), (4, 512, 8, 33, 40, False, True)])
+def test_conv3x3_fused_groupnorm(eng, cfg, cin, cout, H, W, in_f32, silu):
+    """The two fused-GroupNorm instantiations of the 256-pixel tiles (48 % of the step time in round 1) at op level: GroupNorm(32)
+    (+SiLU) applied inside the operand staging == F.group_norm -> F.silu -> fp16 -> conv."""
+    S.check_conv(eng, DEV, 2, H, W, cin, cout, tile_cfg=cfg, in_f32=in_f32, gn=(1e-6, silu), res="f32" if cfg == 0 else None,
+                 out_f32=True, seed=30 + cfg)
+
+
+def test_conv3x3_fused_groupnorm_concat(eng):
+    S.check_conv(eng, DEV, 1, 16, 32, 640, 320, C1=320, in_f32=True, gn=(1e-5, True), tile_cfg=0, out_f32=True, seed=37)    # up-block ResBlock conv1
+
+
+@pytest.mark.parametrize("ntaps,cfg,cin,cout,H,W,gn", [(9, 0, 128, 128, 40, 96, True), (9, 0, 256, 128, 16, 64, False), (9, 1, 320, 320, 16, 64, False),
+                                                        (9, 2, 640, 200, 16, 16, False), (9, 4, 128, 3, 40, 64, True), (1, -1, 320, 960, 1, 4096, False),
+                                                        (1, 1, 1280, 1280, 1, 1024, False), (1, 2, 1024, 640, 1, 300, False), (1, 3, 16, 8, 1, 256, False)])
+def test_conv_split_precision(eng, ntaps, cfg, cin, cout, H, W, gn):
+    """Precise-mode kernels (split-fp16 operands, 3 MFMAs per product) against the fp32 reference on UN-rounded operands: the
+    fp16-operand kernels sit at ~1e-3 on these shapes, the split kernels must be at the fp32-accumulation level."""
+    S.check_conv(eng, DEV, 2 if ntaps == 9 else 1, H, W, cin, cout, ntaps=ntaps, tile_cfg=cfg, in_f32=True, out_f32=True, split=True,
+                 gn=(1e-6, True) if gn else None, res="f32", seed=80 + cfg, atol=3e-5)
+
+
+def test_conv_split_precision_s2_up_geglu(eng):
+    S.check_conv(eng, DEV, 2, 32, 64, 128, 128, stride=2, pad_mode=1, in_f32=True, out_f32=True, split=True, seed=90, atol=3e-5)
+    S.check_conv(eng, DEV, 1, 16, 24, 128, 128, up=1, in_f32=True, out_f32=True, split=True, seed=91, atol=3e-5)
+    S.check_conv(eng, DEV, 1, 1, 1024, 320, 2560, ntaps=1, geglu=True, in_f32=True, out_f32=True, split=True, seed=92, atol=1e-4)
+
+
 @pytest.mark.parametrize("cfg,cin,cout,rows", [(0, 320, 960, 4096), (1, 1280, 1280, 1024), (2, 1024, 640, 300), (3, 16, 8, 256),
                                                (-1, 2560, 1280, 256), (-1, 640, 640, 4096)])
 def test_gemm(eng, cfg, cin, cout, rows):
@@ -53,7 +83,7 @@ def test_gemm_fp32_input_concat_geglu(eng):
     S.check_conv(eng, DEV, 1, 1, 1000, 320, 320, ntaps=1, in_f32=True, seed=70)                   # proj_out reads the fp32 stream
     S.check_conv(eng, DEV, 1, 8, 8, 1280, 1280, ntaps=1, C1=1280, in_f32=True, res=None, out_f32=True, seed=71)  # shortcut on concat
     S.check_conv(eng, DEV, 1, 1, 1024, 320, 2560, ntaps=1, geglu=True, seed=72)                   # GEGLU
-    S.check_conv(eng, DEV, 1, 1, 256, 1280, 10240, ntaps=1, geglu=True, seed=73, atol=3e-2)
+    S.check_conv(eng, DEV, 1, 1, 256, 1280, 10240, ntaps=1, geglu=True, seed=73, atol=8e-3)
 
 
 def test_groupnorm(eng):
