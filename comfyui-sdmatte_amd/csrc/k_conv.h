@@ -38,6 +38,8 @@ struct ConvParams {
   int Hout, Wout;
   int pad_t, pad_l;
   long M;                               // NTAPS==1: number of rows (N*H*W)
+  int rows_per_img;                     // NTAPS==1: != 0 -> row tiles are aligned to images of this many rows (needed when the
+                                        // epilogue emits per-image GroupNorm statistics for a batch: one launch instead of N)
   const half_t* w;                      // packed weights, K16 layout
   const half_t* w_lo;                   // SPLIT kernels: fp16 low parts of the (scaled) weights, same layout: w = (w_hi + w_lo) * acc_scale
   float acc_scale;                      // multiplies the accumulator in the epilogue (undoes the power-of-two weight pre-scale; 1 otherwise)
@@ -73,7 +75,15 @@ struct ConvCfg {
   static constexpr int HP = HPH * HPW;
   // DB (double-buffered) tiles are stored UNPADDED with an XOR swizzle of the 16-B half (KC == 16: 2 halves per 32-B row):
   // half h of row r lives at r*32 + ((h ^ ((r >> 3) & 1)) << 4) -> conflict-free ds_read_b128 for 16-lane groups of consecutive rows
-  static constexpr int PITCH = DB ? KC * 2 : KC * 2 + 16;
+  // SWZ: the unpadded XOR-swizzled image of the double-buffered tiles.
+  // PL ("half planes"): split-precision kernels with 16-channel chunks.  Their A_hi | A_lo | B tiles would not leave room for two
+  // blocks per CU in the padded layout (87.9 KB vs 58.6 KB per block), so the two 16-byte k-halves of every row are stored in
+  // two separate planes of 16-byte rows: plane h of row r at h * rows * 16 + r * 16.  A 16-lane ds_read_b128 group then reads 16
+  // rows of one plane = 256 contiguous bytes (conflict-free, no padding) and every fragment address is base + constant.
+  static constexpr int SWZ = DB ? 1 : 0;
+  static constexpr int PL = (SPLIT && KC == 16) ? 1 : 0;
+  static constexpr int PITCH = (SWZ || PL) ? KC * 2 : KC * 2 + 16;     // bytes per row (both halves)
+  static constexpr int ROWB = PL ? 16 : PITCH;                         // address stride between consecutive rows
   static constexpr int KV = KC / 8;
   static constexpr int A_BYTES = HP * PITCH;
   static constexpr int B_BYTES = NTAPS * BN * PITCH;
@@ -100,6 +110,8 @@ conv_mfma_kernel(ConvParams p) {
   using C = ConvCfg<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN, DB, SPLIT>;
   constexpr int NT = C::NTHREADS, MT = C::MT, NTL = C::NTL, PITCH = C::PITCH, KV = C::KV;
   constexpr int HPW = C::HPW, HP = C::HP, WTM = C::WTM, WTN = C::WTN;
+  constexpr int SWZ = C::SWZ, PL = C::PL, ROWB = C::ROWB;
+  constexpr int A_HALF = PL ? HP * 16 : 16, B_HALF = PL ? NTAPS * BN * 16 : 16;      // byte offset of the second k-half (channels 8..15)
   constexpr int A_VEC = HP * KV, B_VEC = NTAPS * BN * KV;
   constexpr int A_PER = (A_VEC + NT - 1) / NT, B_PER = (B_VEC + NT - 1) / NT;
   SDM_DYN_SMEM(smem);
@@ -120,19 +132,21 @@ conv_mfma_kernel(ConvParams p) {
     const int j = bid >> 3;
     const int ml = j / p.tiles_n;
     const int mlin = (bid & 7) * p.xcd_chunk + ml;
-    if (mlin >= p.tiles_m * ((NTAPS == 9) ? p.N : 1)) return;      // padding block of the last XCD range
+    const bool per_img = (NTAPS == 9) || p.rows_per_img != 0;
+    if (mlin >= p.tiles_m * (per_img ? p.N : 1)) return;      // padding block of the last XCD range
     mt = mlin;
-    if (NTAPS == 9) { img = mlin / p.tiles_m; mt = mlin - img * p.tiles_m; }
+    if (per_img) { img = mlin / p.tiles_m; mt = mlin - img * p.tiles_m; }
     const int nt = j - ml * p.tiles_n;
     if (NTAPS == 9) {
       const int npx = (p.Wout + TW - 1) / TW;
       oy0 = (mt / npx) * TH;
       ox0 = (mt % npx) * TW;
     } else {
-      m0 = (long)mt * C::BM;
+      m0 = (long)img * p.rows_per_img + (long)mt * C::BM;
     }
     n0 = nt * BN;
   }
+  const long m_end = (NTAPS == 1 && p.rows_per_img) ? (long)(img + 1) * p.rows_per_img : p.M;      // first row beyond this block's row range
   const int Cin = p.C0 + p.C1;
   const int Hl = p.Hin << p.up, Wl = p.Win << p.up;
 
@@ -162,12 +176,12 @@ conv_mfma_kernel(ConvParams p) {
     const int m = wm * WTM + i * 32 + (lane & 31);
     const int py = m / TW, px = m % TW;
     const int row = (NTAPS == 9) ? (py * STRIDE * HPW + px * STRIDE) : m;
-    abase[i] = DB ? row : row * PITCH + (lane >> 5) * 16;
+    abase[i] = SWZ ? row : row * ROWB + (lane >> 5) * A_HALF;
   }
 #pragma unroll
   for (int j = 0; j < NTL; ++j) {
     const int co = wn * WTN + j * 32 + (lane & 31);
-    bbase[j] = DB ? co * PITCH + ((((lane >> 5) ^ (co >> 3)) & 1) << 4) : co * PITCH + (lane >> 5) * 16;
+    bbase[j] = SWZ ? co * PITCH + ((((lane >> 5) ^ (co >> 3)) & 1) << 4) : co * ROWB + (lane >> 5) * B_HALF;
   }
 
   // ---- K-loop invariant staging descriptors.  Vector v = tid + i*NT; everything except the A pixel index is affine in
@@ -196,7 +210,7 @@ conv_mfma_kernel(ConvParams p) {
   {
     size_t base_px, npx;
     if (NTAPS == 9) { base_px = (size_t)img * p.Hin * p.Win; npx = (size_t)p.Hin * p.Win; }
-    else { base_px = (size_t)m0; npx = (size_t)((p.M - m0) < (long)C::BM ? (p.M - m0) : (long)C::BM); }
+    else { base_px = (size_t)m0; npx = (size_t)((m_end - m0) < (long)C::BM ? (m_end - m0) : (long)C::BM); }
     rs0 = sdm_make_rsrc((const unsigned char*)p.in0 + base_px * p.C0 * es, (unsigned int)(npx * p.C0 * es));
     rs1 = sdm_make_rsrc(p.in1 ? (const unsigned char*)p.in1 + base_px * p.C1 * es : (const unsigned char*)p.in0, p.in1 ? (unsigned int)(npx * p.C1 * es) : 0u);
     rsw = sdm_make_rsrc(p.w, (unsigned int)((size_t)Cin * NTAPS * p.Cout_pad * 2));
@@ -269,7 +283,7 @@ conv_mfma_kernel(ConvParams p) {
             vlo[e] = (half_t)(y - (float)h);
           }
           const int hp_s = a_hp0 + i * (NT / KV);
-          *(f16x8*)(Ad + C::A_BYTES + hp_s * PITCH + a_part * 2) = vlo;
+          *(f16x8*)(Ad + C::A_BYTES + hp_s * ROWB + (PL ? (a_part >> 3) * A_HALF : (a_part * 2))) = vlo;
         } else if (GN) {
           float x[8];
           if (IN_F32) {
@@ -296,7 +310,7 @@ conv_mfma_kernel(ConvParams p) {
           val = __builtin_bit_cast(f16x8, a_raw[i][0]);
         }
         const int hp_w = a_hp0 + i * (NT / KV);
-        *(f16x8*)(Ad + hp_w * PITCH + (DB ? ((((a_part >> 3) ^ (hp_w >> 3)) & 1) << 4) : (a_part * 2))) = val;
+        *(f16x8*)(Ad + hp_w * ROWB + (SWZ ? ((((a_part >> 3) ^ (hp_w >> 3)) & 1) << 4) : PL ? (a_part >> 3) * A_HALF : (a_part * 2))) = val;
       }
     }
   };
@@ -308,7 +322,7 @@ conv_mfma_kernel(ConvParams p) {
         const int rest = (2 * BN >= NT) ? (lin / BN) : (b_rest0 + i * (NT / (2 * BN)));
         const int co = (2 * BN >= NT) ? (lin % BN) : b_co;
         const int tap = rest % NTAPS, sc = rest / NTAPS;
-        *(f16x8*)(Bd + (tap * BN + co) * PITCH + (DB ? (((b_h ^ (co >> 3)) & 1) << 4) : ((sc * 2 + b_h) * 16))) = __builtin_bit_cast(f16x8, b_raw[i]);
+        *(f16x8*)(Bd + (tap * BN + co) * ROWB + (SWZ ? (((b_h ^ (co >> 3)) & 1) << 4) : PL ? b_h * B_HALF : ((sc * 2 + b_h) * 16))) = __builtin_bit_cast(f16x8, b_raw[i]);
       }
     }
   };
@@ -323,16 +337,16 @@ conv_mfma_kernel(ConvParams p) {
     f16x8 fa[MT], fb[2][NTL];
     auto a_addr = [&](int step, int i) {
       const int tap = step / (KC / 16), ks = step % (KC / 16);
-      if (DB) {
+      if (SWZ) {
         const int row = abase[i] + ((NTAPS == 9) ? (tap / 3) * HPW + (tap % 3) : 0);
         return (const f16x8*)(Ap + row * PITCH + ((((lane >> 5) ^ (row >> 3)) & 1) << 4));
       }
-      const int toff = (NTAPS == 9) ? ((tap / 3) * HPW + (tap % 3)) * PITCH : 0;
+      const int toff = (NTAPS == 9) ? ((tap / 3) * HPW + (tap % 3)) * ROWB : 0;
       return (const f16x8*)(Ap + abase[i] + toff + ks * 32);
     };
     auto b_addr = [&](int step, int j) {
       const int tap = step / (KC / 16), ks = step % (KC / 16);
-      return (const f16x8*)(Bs + tap * BN * PITCH + bbase[j] + ks * 32);
+      return (const f16x8*)(Bs + tap * BN * ROWB + bbase[j] + ks * 32);
     };
     // Vertical operand reuse (3x3, stride 1, 32-pixel-wide tiles): the A fragment of output row i at tap (dy,dx) is halo row
     // i+dy shifted by dx - the SAME LDS data for every (i,dy) with equal i+dy.  Sweeping halo rows r = 0..MT+1 per dx reads
@@ -345,8 +359,8 @@ conv_mfma_kernel(ConvParams p) {
 #pragma unroll
       for (int ks = 0; ks < KC / 16; ++ks) {
         f16x8 fav[2], fbv[3][NTL];
-        auto av = [&](int s) { return *(const f16x8*)(Ap + abase[0] + ((s % NR) * HPW + (s / NR)) * PITCH + ks * 32); };
-        auto bv = [&](int dy, int dx, int j) { return *(const f16x8*)(Bs + (dy * 3 + dx) * BN * PITCH + bbase[j] + ks * 32); };
+        auto av = [&](int s) { return *(const f16x8*)(Ap + abase[0] + ((s % NR) * HPW + (s / NR)) * ROWB + ks * 32); };
+        auto bv = [&](int dy, int dx, int j) { return *(const f16x8*)(Bs + (dy * 3 + dx) * BN * ROWB + bbase[j] + ks * 32); };
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
@@ -469,7 +483,7 @@ conv_mfma_kernel(ConvParams p) {
       return (oy < p.Hout) && (ox < p.Wout);
     }
     opix_local = m;
-    return (m0 + m) < p.M;
+    return (m0 + m) < m_end;
   };
   const size_t opix_base = (NTAPS == 9) ? (size_t)img * p.Hout * p.Wout : (size_t)m0;   // block-uniform
   if (!geglu) {
@@ -482,7 +496,7 @@ conv_mfma_kernel(ConvParams p) {
     // residual through a per-block buffer descriptor: all loads of a 32-row tile are issued up front, unconditionally
     // (invalid rows/columns get an out-of-range offset -> 0), instead of one dependent global round trip per row pass
     const unsigned int res_es = p.res_f32 ? 4u : 2u;
-    const size_t res_span = (NTAPS == 9) ? (size_t)p.Hout * p.Wout : (size_t)(((p.M - m0) < (long)C::BM) ? (p.M - m0) : (long)C::BM);
+    const size_t res_span = (NTAPS == 9) ? (size_t)p.Hout * p.Wout : (size_t)(((m_end - m0) < (long)C::BM) ? (m_end - m0) : (long)C::BM);
     const sdm_rsrc rsr = sdm_make_rsrc(p.res ? (const unsigned char*)p.res + opix_base * p.res_C * res_es : (const unsigned char*)p.out,
                                        p.res ? (unsigned int)(res_span * p.res_C * res_es) : 0u);
 #pragma unroll

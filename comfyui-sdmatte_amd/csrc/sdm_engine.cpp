@@ -85,9 +85,10 @@ template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN,
 static void launch_conv_t(const ConvParams& p_in, void* stream) {
   using C = ConvCfg<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN, DB>;
   ConvParams p = p_in;
-  p.tiles_m = (NTAPS == 9) ? sdm_cdiv(p.Wout, TW) * sdm_cdiv(p.Hout, TH) : (int)((p.M + C::BM - 1) / C::BM);
+  p.tiles_m = (NTAPS == 9) ? sdm_cdiv(p.Wout, TW) * sdm_cdiv(p.Hout, TH)
+                           : (int)(((p.rows_per_img ? (long)p.rows_per_img : p.M) + C::BM - 1) / C::BM);
   p.tiles_n = sdm_cdiv(p.Cout_pad, BN);
-  const long total_m = (long)p.tiles_m * ((NTAPS == 9) ? p.N : 1);
+  const long total_m = (long)p.tiles_m * ((NTAPS == 9 || p.rows_per_img) ? p.N : 1);
   p.xcd_chunk = (int)((total_m + 7) / 8);
   const dim3 grid((unsigned)(8L * p.xcd_chunk * p.tiles_n), 1, 1);      // 1-D, XCD-aware mapping in the kernel
   const size_t gn_extra = (size_t)(p.C0 + p.C1) * 8;                    // fused GroupNorm apply: the scale|shift table of the image follows the tiles in LDS
@@ -734,22 +735,9 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
     prof_begin(e, "conv", flops, bytes);
   }
   int rc = 0;
-  if (L.ntaps == 1 && p.stats && p.N > 1) {
-    // the statistics are per image: one launch per image so that a row tile never straddles two images
-    const long rows = (long)p.Hout * p.Wout;
-    for (int n = 0; n < p.N && rc == 0; ++n) {
-      ConvParams q = p;
-      q.M = rows; q.N = 1;
-      q.in0 = (const unsigned char*)p.in0 + (size_t)n * rows * p.C0 * (p.in_f32 ? 4 : 2);
-      if (p.in1) q.in1 = (const unsigned char*)p.in1 + (size_t)n * rows * p.C1 * (p.in_f32 ? 4 : 2);
-      q.out = (unsigned char*)p.out + (size_t)n * rows * p.Cout_store * (p.out_f32 ? 4 : 2);
-      if (p.res) q.res = (const unsigned char*)p.res + (size_t)n * rows * p.res_C * (p.res_f32 ? 4 : 2);
-      q.stats = p.stats + (size_t)n * a.out->srows * p.Cout_store * 2;
-      rc = launch_conv(L.ntaps, a.stride, cfg, q, e->stream);
-    }
-  } else {
-    rc = launch_conv(L.ntaps, a.stride, cfg, p, e->stream);
-  }
+  // GEMMs that emit per-image GroupNorm statistics for a batch: row tiles aligned to images inside ONE launch
+  if (L.ntaps == 1 && p.stats && p.N > 1) p.rows_per_img = p.Hout * p.Wout;
+  rc = launch_conv(L.ntaps, a.stride, cfg, p, e->stream);
   if (rc != 0) SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: bad cfg", L.name.c_str());
   prof_end(e);
   return 0;

@@ -368,7 +368,10 @@ def test_e2e_config5_mixed_resolution_stream_matted_rgba(pkg):
     sizes = [512, 768, 1024, 512, 768, 512]
     reqs = []
     for i, S in enumerate(sizes):
-        im, tr = synthetic_inputs(1, 300 + 40 * (i % 2), 420, seed=100 + i)      # two input shapes, resized to S by the engine
+        # images arrive at their inference size (identity resize): the reference multiplies the RESIZED trimap by -10000 to form
+        # the key bias (replace.py:402), so a resampled trimap makes alpha hinge on 1e-5 differences of the resize itself;
+        # resampled inputs are covered by the node test above and the G1 fixture
+        im, tr = synthetic_inputs(1, S, S, seed=100 + i)
         reqs.append((im[0], tr[0], S))
     got = parallel.matte_stream(eng, [r[0].cuda() for r in reqs], [r[1].cuda() for r in reqs], sizes, micro_batch=2)
     assert len(got) == len(reqs)

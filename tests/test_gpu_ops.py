@@ -64,7 +64,7 @@ def test_conv_split_precision(eng, ntaps, cfg, cin, cout, H, W, gn):
     """Precise-mode kernels (split-fp16 operands, 3 MFMAs per product) against the fp32 reference on UN-rounded operands: the
     fp16-operand kernels sit at ~1e-3 on these shapes, the split kernels must be at the fp32-accumulation level."""
     S.check_conv(eng, DEV, 2 if ntaps == 9 else 1, H, W, cin, cout, ntaps=ntaps, tile_cfg=cfg, in_f32=True, out_f32=True, split=True,
-                 gn=(1e-6, True) if gn else None, res="f32", seed=80 + cfg, atol=3e-5)
+                 gn=(1e-6, True) if gn else None, res="f32" if cout % 4 == 0 else None, seed=80 + cfg, atol=3e-5)
 
 
 def test_conv_split_precision_s2_up_geglu(eng):

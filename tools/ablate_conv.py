@@ -11,6 +11,8 @@ shapes = [("128->128 @1024^2 N=4", (4, 1024, 1024, 128, 128, 9)), ("512->512 @25
           ("gemm 320->960 M=65536", (4, 128, 128, 320, 960, 1))]
 names = {0: "full", 1: "no global loads", 2: "no LDS writes", 3: "no loads+writes", 4: "no MFMA phase", 8: "no epilogue stores", 7: "barriers only", 15: "nothing"}
 modes = [("fp16 in", 0), ("fp32 in", 1), ("fp32 in + GN", 5), ("split", 3), ("split + GN", 7)]
+if len(sys.argv) > 1:
+    modes = [m for m in modes if sys.argv[1] in m[0]]
 for label, (N, H, W, ci, co, nt) in shapes:
     fl = 2.0 * N * H * W * ci * co * nt
     for mname, flag in modes:
