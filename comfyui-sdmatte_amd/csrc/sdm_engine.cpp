@@ -95,14 +95,15 @@ static void launch_conv_t(const ConvParams& p_in, void* stream) {
   if constexpr (!DB) {
     if (p.w_lo) {                  // precise mode: split-fp16 operands (fp32 activations only)
       using CS = ConvCfg<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN, 0, 1>;
+      static const size_t lds_pad = getenv("SDM_SPLIT_LDS_PAD") ? (size_t)atoi(getenv("SDM_SPLIT_LDS_PAD")) : 0;   // experiment hook: extra dynamic LDS (forces 1 block per CU)
       if (GNOK && p.gn_scale) {
         auto k = conv_mfma_kernel<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN, 1, 0, GNOK, 1>;
-        SDM_SET_SMEM(k, CS::SMEM + 1024 * 8);
-        SDM_LAUNCH(k, grid, dim3(CS::NTHREADS), (size_t)CS::SMEM + gn_extra, stream, p);
+        SDM_SET_SMEM(k, 160 * 1024);
+        SDM_LAUNCH(k, grid, dim3(CS::NTHREADS), (size_t)CS::SMEM + gn_extra + lds_pad, stream, p);
       } else {
         auto k = conv_mfma_kernel<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN, 1, 0, 0, 1>;
-        SDM_SET_SMEM(k, CS::SMEM);
-        SDM_LAUNCH(k, grid, dim3(CS::NTHREADS), CS::SMEM, stream, p);
+        SDM_SET_SMEM(k, 160 * 1024);
+        SDM_LAUNCH(k, grid, dim3(CS::NTHREADS), CS::SMEM + lds_pad, stream, p);
       }
       return;
     }
