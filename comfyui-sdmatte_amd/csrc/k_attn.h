@@ -591,24 +591,37 @@ __global__ void __launch_bounds__(256) attn_active_tiles_kernel(const float* __r
   if (tid == 0) o[0] = n;
 }
 
-// V [b][key][head*D + d]  ->  V^T [b][head][d][key] (key padded to ldvt with zeros). 64x64 tiles.
+// V [b][key][head*D + d]  ->  V^T [b][head][d][key] (key padded to ldvt with zeros).  64 keys x 64 d per block: 16-byte
+// global loads along d, 16-byte global stores along the keys; the transposition goes through a 64 x 65-dword LDS tile (one
+// value per dword, so that both the row-wise writes and the column-wise reads are 4-byte accesses with at most 2-way conflicts).
 __global__ void __launch_bounds__(256) transpose_v_kernel(const half_t* __restrict__ v, long v_bs, int ldv, half_t* __restrict__ vt,
                                                           long vt_bs, long vt_hs, int ldvt, int Lk, int D) {
-  SDM_SHARED half_t tile[64][66];
+  SDM_SHARED float tile[64][65];
   const int b = blockIdx.z;
   const int dblocks = D / 64;
   const int head = blockIdx.y / dblocks, d0 = (blockIdx.y % dblocks) * 64;
   const int k0 = blockIdx.x * 64;
   const int tid = threadIdx.x;
-  for (int i = tid; i < 64 * 64; i += 256) {
-    const int key = i >> 6, d = i & 63;
-    half_t x = (half_t)0.0f;
-    if (k0 + key < Lk) x = v[(size_t)b * v_bs + (size_t)(k0 + key) * ldv + head * D + d0 + d];
-    tile[key][d] = x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {                      // 512 vectors of 8 d: vector = (key, d-octet)
+    const int vec = tid + i * 256;
+    const int key = vec >> 3, oct = vec & 7;
+    f16x8 x;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = (half_t)0.0f;
+    if (k0 + key < Lk) x = *(const f16x8*)(v + (size_t)b * v_bs + (size_t)(k0 + key) * ldv + head * D + d0 + oct * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) tile[key][oct * 8 + e] = (float)x[e];
   }
   __syncthreads();
-  for (int i = tid; i < 64 * 64; i += 256) {
-    const int d = i >> 6, key = i & 63;
-    if (k0 + key < ldvt) vt[(size_t)b * vt_bs + (size_t)head * vt_hs + (size_t)(d0 + d) * ldvt + k0 + key] = tile[key][d];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {                      // 512 vectors of 8 keys: vector = (d, key-octet)
+    const int vec = tid + i * 256;
+    const int d = vec >> 3, oct = vec & 7;
+    f16x8 y;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) y[e] = (half_t)tile[oct * 8 + e][d];
+    if (k0 + oct * 8 < ldvt)                         // ldvt is a multiple of 64: whole octets
+      *(f16x8*)(vt + (size_t)b * vt_bs + (size_t)head * vt_hs + (size_t)(d0 + d) * ldvt + k0 + oct * 8) = y;
   }
 }

@@ -196,8 +196,12 @@ __global__ void __launch_bounds__(512) gn_apply_kernel(GnSrc s, const float* __r
   }
 }
 
-// LayerNorm over the last dim C (multiple of 64, <= 64*LN_MAXV), one wave per row, fp32/fp16 in -> fp16 (or fp32) out.
+// LayerNorm over the last dim C (multiple of 64, <= 64*SDM_LN_MAXV), one wave per row, fp32/fp16 in -> fp16 (or fp32) out.
+// Every lane owns 4-channel vectors (16-byte loads of the fp32 stream, 8/16-byte stores): vector v of the row belongs to lane
+// v % 64, so a row of C channels is C/256 (rounded up) fully coalesced wave loads.  Two-pass statistics in registers
+// (mean, then centred sum of squares: the same arithmetic as F.layer_norm).
 #define SDM_LN_MAXV 20
+#define SDM_LN_MAXQ (SDM_LN_MAXV / 4)
 __global__ void __launch_bounds__(256) layernorm_kernel(const void* __restrict__ x, int in_f32, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, void* __restrict__ out, int out_f32, long rows, int C,
                                                         float eps) {
@@ -205,35 +209,56 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const void* __restrict__
   const long row = (long)blockIdx.x * (blockDim.x >> 6) + wave;
   const bool active = row < rows;
   const long rr = active ? row : rows - 1;     // keep every lane in the shuffles
-  const int nv = C / 64;
-  float v[SDM_LN_MAXV];
+  const int nq = C / 4;                        // 4-channel vectors per row
+  f32x4 v[SDM_LN_MAXQ];
   float s = 0.0f;
 #pragma unroll
-  for (int i = 0; i < SDM_LN_MAXV; ++i) {
-    if (i < nv) {
-      const size_t idx = (size_t)rr * C + i * 64 + lane;
-      v[i] = in_f32 ? ((const float*)x)[idx] : (float)((const half_t*)x)[idx];
-      s += v[i];
+  for (int i = 0; i < SDM_LN_MAXQ; ++i) {
+    const int q = i * 64 + lane;
+    v[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (q < nq) {
+      const size_t idx = (size_t)rr * C + (size_t)q * 4;
+      if (in_f32) {
+        v[i] = *(const f32x4*)((const float*)x + idx);
+      } else {
+        const f16x4 h = *(const f16x4*)((const half_t*)x + idx);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[i][e] = (float)h[e];
+      }
+      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
   }
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
   const float mean = s / (float)C;
-  float q = 0.0f;
+  float qs = 0.0f;
 #pragma unroll
-  for (int i = 0; i < SDM_LN_MAXV; ++i)
-    if (i < nv) { const float d = v[i] - mean; q += d * d; }
+  for (int i = 0; i < SDM_LN_MAXQ; ++i)
+    if (i * 64 + lane < nq) {
 #pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) q += __shfl_xor(q, m);
-  const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+      for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; qs += d * d; }
+    }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) qs += __shfl_xor(qs, m);
+  const float rstd = 1.0f / sqrtf(qs / (float)C + eps);
   if (!active) return;
 #pragma unroll
-  for (int i = 0; i < SDM_LN_MAXV; ++i) {
-    if (i < nv) {
-      const int c = i * 64 + lane;
-      const float y = (v[i] - mean) * rstd * gamma[c] + beta[c];
-      if (out_f32) ((float*)out)[(size_t)row * C + c] = y;
-      else ((half_t*)out)[(size_t)row * C + c] = (half_t)y;
+  for (int i = 0; i < SDM_LN_MAXQ; ++i) {
+    const int q = i * 64 + lane;
+    if (q < nq) {
+      const f32x4 g = *(const f32x4*)(gamma + q * 4), b = *(const f32x4*)(beta + q * 4);
+      f32x4 y;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+      const size_t idx = (size_t)row * C + (size_t)q * 4;
+      if (out_f32) {
+        *(f32x4*)((float*)out + idx) = y;
+      } else {
+        f16x4 h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = (half_t)y[e];
+        *(f16x4*)((half_t*)out + idx) = h;
+      }
     }
   }
 }
