@@ -107,7 +107,16 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qf[qt][ks][j] = (half_t)((float)qf[qt][ks][j] * p.scale_log2e);
+        for (int j = 0; j < 8; ++j) {
+          if (PREC) {                 // scale the fp32 value hi + lo, then split again
+            const float qs = ((float)qf[qt][ks][j] + (float)qfl[PREC ? qt : 0][ks][j]) * p.scale_log2e;
+            const half_t h = (half_t)qs;
+            qf[qt][ks][j] = h;
+            qfl[PREC ? qt : 0][ks][j] = (half_t)(qs - (float)h);
+          } else {
+            qf[qt][ks][j] = (half_t)((float)qf[qt][ks][j] * p.scale_log2e);
+          }
+        }
     }
   }
   f32x16 o[QT][2], ls[QT];        // ls: running softmax denominators, accumulated on the matrix pipe (ones . P^T)

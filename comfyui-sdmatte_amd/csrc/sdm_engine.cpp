@@ -1012,12 +1012,16 @@ static int linear(sdm_ctx* e, int layer, const T& in, T* out, int Cout, int out_
 static int vae_attention(sdm_ctx* e, const VaeAttnB& a, const T& x, T* out) {
   T hn, qkv, ao;
   TRY(op_gn(e, e->norms[a.gn], x, nullptr, 0, e->cfg.vae_eps, &hn));
-  TRY(linear(e, a.qkv, hn, &qkv, 3 * a.C, 0));          // the single-head d=512 core always takes fp16 operands
+  // the single-head d=512 core always takes fp16 operands; a 64-channel VAE (test architectures) runs on the d=64 kernels and
+  // follows the U-Net attention-core precision bit
+  const int pa = ((e->cfg.precise_mask & SDM_PRECISE_UNET_ATTN) && a.C == 64) ? 1 : 0;
+  TRY(linear(e, a.qkv, hn, &qkv, 3 * a.C, pa ? 2 : 0));
   tfree(e, hn);
   ao = talloc(e, x.N, x.H, x.W, a.C, e->act_f32);
   const int L = x.H * x.W;
   const half_t* q = (const half_t*)qkv.p;
-  AttnPrec ap; ap.out_f32 = ao.f32;
+  AttnPrec ap; ap.out_f32 = ao.f32; ap.prec = pa;
+  ap.q_lo = ap.k_lo = ap.v_lo = (long)qkv.rows() * qkv.C;
   TRY(op_attention_raw(e, q, 3 * a.C, q ? q + a.C : nullptr, 3 * a.C, q ? q + 2 * a.C : nullptr, 3 * a.C, nullptr, x.N, 1, L, L, a.C,
                        ao.p, a.C, false, nullptr, ap));
   tfree(e, qkv);
