@@ -108,11 +108,12 @@ def main():
     precision = args.precision or E.DEFAULT_PRECISION
     other = "fp16" if precision != "fp16" else "fp16x3"
     eng = E.Engine(cfg, local_rank, precision=precision)
-    t_load0 = time.time()
     sd = None
     if rank == 0:
         sd = synthetic_state_dict(cfg, 0)
-        missing, _ = eng.load_state_dict(sd)
+    t_load0 = time.time()
+    if rank == 0:
+        missing, _ = eng.load_state_dict(sd)          # fp32 host tensors -> pinned staging ring -> HIP pack kernels (hi | lo planes)
         assert not missing, missing[:4]
     if world > 1:
         # RCCL broadcast of the packed weight blob (+ the small host-side embedding tensors at its tail)

@@ -12,6 +12,8 @@ is applied when `aux_input` is listed in `attn_mask_aux_input`.  What stays unsu
 NotImplementedError: noise / multi-step inference, the CLIP text context, random prompt choice
 (aux_input=None), partial attention-mask / context stage lists.
 """
+import os
+
 import torch
 
 from .config import SDMatteConfig
@@ -88,8 +90,15 @@ class SDMatte:
         self.missing_keys, self.ignored = self.engine.load_state_dict(self._pending)
         self._pending = None
         if self.missing_keys:
-            print(f"[SDMatte] warning: {len(self.missing_keys)} expected tensors absent from the checkpoint "
-                  f"(first: {self.missing_keys[0]}); they stay zero (strict=False semantics)")
+            # The reference loads with strict=False and would silently keep its random initialisation; a native engine would run
+            # on zeros.  A checkpoint that lacks tensors the graph consumes is a wrong / truncated file: fail loudly
+            # (SDMATTE_ALLOW_MISSING_KEYS=1 restores the lenient behaviour for experiments).
+            msg = (f"[SDMatte] {len(self.missing_keys)} tensors the model needs are absent from the checkpoint "
+                   f"(first: {', '.join(self.missing_keys[:3])})")
+            if os.environ.get("SDMATTE_ALLOW_MISSING_KEYS") == "1":
+                print(msg + "; they stay zero")
+            else:
+                raise RuntimeError(msg)
 
     def __call__(self, data):
         return self.forward(data)

@@ -121,6 +121,8 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
   }
   f32x16 o[QT][2], ls[QT];        // ls: running softmax denominators, accumulated on the matrix pipe (ones . P^T)
   float m_i[QT];
+  float lsum = 0.0f;              // PREC: the denominator is summed on the VALU instead (the matrix pipe is the bottleneck there,
+                                  // and the fp32 sum of the un-split probabilities is exact to fp32)
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     m_i[qt] = SDM_NEG_BIG;
@@ -252,6 +254,12 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[qt][kt][r] = sdm_exp2(s[qt][kt][r] - mnew);
+      if (PREC) {
+        float ts0 = 0.0f, ts1 = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ts0 += s[qt][0][r]; ts1 += s[qt][1][r]; }
+        lsum = lsum * alpha + (ts0 + ts1);
+      }
       // the running max stops moving after the first tiles: skip the O / denominator rescale when no lane of the wave needs it
       if (__any(alpha != 1.0f)) {
 #pragma unroll
@@ -279,9 +287,10 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) pfl[j] = (half_t)(s[0][kt][8 * u + j] - (float)pf[0][j]);
         }
+        if (!PREC) {
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) ls[qt] = SDM_MFMA_32x32x16_F16(ones, pf[qt], ls[qt]);      // every row = sum_k P[k][q]
-        if (PREC) ls[0] = SDM_MFMA_32x32x16_F16(ones, pfl, ls[0]);
+          for (int qt = 0; qt < QT; ++qt) ls[qt] = SDM_MFMA_32x32x16_F16(ones, pf[qt], ls[qt]);      // every row = sum_k P[k][q]
+        }
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           const unsigned char* vp = Vs + (dt * 32 + l31) * PV + (kt * 32 + 16 * u + 4 * hi) * 2;
@@ -315,7 +324,7 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
     unsigned char* stf = smem + wave * (32 * PS);
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-      const float inv = 1.0f / ls[qt][0];
+      const float inv = 1.0f / (PREC ? (lsum + __shfl_xor(lsum, 32)) : ls[qt][0]);      // lanes l and l^32 hold the two key halves of query l&31
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -339,7 +348,7 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
   }
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
-    const float l = ls[qt][0];      // all 32 rows of the ones.P^T tile hold the same sum over every key (both lane halves included)
+    const float l = PREC ? (lsum + __shfl_xor(lsum, 32)) : ls[qt][0];      // all 32 rows of the ones.P^T tile hold the same sum over every key (both lane halves included)
     const float inv = 1.0f / l;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)

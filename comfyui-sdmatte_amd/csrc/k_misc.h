@@ -138,6 +138,36 @@ __global__ void resize_planes_kernel(const float* __restrict__ in, float* __rest
   out[i] = x;
 }
 
+// Node tail at the ORIGINAL resolution (sdmatte_nodes.py:365-397): mask_refine with the input trimap, then the output image.
+//   refine: fg = tri > c; bg = tri < 1-c; unknown = !(fg|bg); a[bg] = 0; a[fg] = clamp(1.2*a, 0, 1); a[(a < 0.3) & unknown] = 0
+//   mode 0 alpha_only : matted = zeros_like(image) [B,H,W,3];  mode 1 matted_rgba : cat(image, a) [B,H,W,4];
+//   mode 2 matted_rgb : image * ((tri > 0.2) & (a > 0.1)) [B,H,W,3]
+// Every operation is a single fp32 compare / multiply / select, so the result is bit-identical to the reference's CPU tensor ops.
+__global__ void refine_compose_kernel(const float* __restrict__ img, const float* __restrict__ tri, float* __restrict__ alpha,
+                                      float* __restrict__ matted, long npix, int mode, int refine, float c, float one_minus_c) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix) return;
+  float a = alpha[i];
+  const float t = tri[i];
+  if (refine) {
+    const bool fg = t > c, bg = t < one_minus_c, unk = !(fg || bg);
+    if (bg) a = 0.0f;
+    if (fg) a = fminf(fmaxf(a * 1.2f, 0.0f), 1.0f);
+    if (a < 0.3f && unk) a = 0.0f;
+    alpha[i] = a;
+  }
+  const float r = img[i * 3 + 0], g = img[i * 3 + 1], b = img[i * 3 + 2];
+  if (mode == 1) {
+    f32x4 o = {r, g, b, a};
+    *(f32x4*)(matted + i * 4) = o;
+  } else if (mode == 2) {
+    const float gate = (t > 0.2f && a > 0.1f) ? 1.0f : 0.0f;
+    matted[i * 3 + 0] = r * gate; matted[i * 3 + 1] = g * gate; matted[i * 3 + 2] = b * gate;
+  } else {
+    matted[i * 3 + 0] = 0.0f; matted[i * 3 + 1] = 0.0f; matted[i * 3 + 2] = 0.0f;
+  }
+}
+
 __global__ void scale_copy_kernel(const float* __restrict__ in, float* __restrict__ out, long n, float mult) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = in[i] * mult;

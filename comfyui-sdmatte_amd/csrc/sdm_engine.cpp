@@ -62,8 +62,9 @@ static const char* dev_errstr(int e) { return hipGetErrorString((hipError_t)e); 
       (void)hipGetDevice(&dev_);                                                                                 \
       const unsigned long long bit_ = 1ull << (dev_ & 63);                                                       \
       if (!(done_.load(std::memory_order_relaxed) & bit_)) {                                                     \
-        (void)hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
-        done_.fetch_or(bit_, std::memory_order_relaxed);                                                         \
+        const hipError_t r_ = hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+        if (r_ != hipSuccess) fprintf(stderr, "[sdmatte] hipFuncSetAttribute(%d bytes of LDS) failed: %s\n", (int)(bytes), hipGetErrorString(r_)); \
+        else done_.fetch_or(bit_, std::memory_order_relaxed);                                                    \
       }                                                                                                          \
     }                                                                                                            \
   } while (0)
@@ -74,7 +75,10 @@ static inline int rup(int a, int b) { return ((a + b - 1) / b) * b; }
 #ifdef SDM_EMU
 static inline void dev_use(int) {}
 #else
-static inline void dev_use(int device) { (void)hipSetDevice(device); }
+static inline void dev_use(int device) {
+  const hipError_t r = hipSetDevice(device);
+  if (r != hipSuccess) fprintf(stderr, "[sdmatte] hipSetDevice(%d) failed: %s\n", device, hipGetErrorString(r));   // the next HIP call of the entry point reports it through its status
+}
 #endif
 static inline size_t rupz(size_t a, size_t b) { return ((a + b - 1) / b) * b; }
 
@@ -266,7 +270,7 @@ struct T {  // NHWC activation tensor living in the arena
 
 // activation element formats (T::f32): 0 fp16, 1 fp32, 2 two fp16 planes hi | lo (split-precision attention operands)
 static inline size_t fmt_bytes(int f) { return f ? 4 : 2; }
-static const int kMaxVariants = 8;
+static const int kMinVariantRows = 8;     // initial rows of the per-ResBlock bias tables (one row per distinct conditioning); grows on demand
 // conditioning of one image: opacity class + either 4 box coordinates (kind 0: bbox_embedding) or N point coordinates
 // (kind 1: point_embedding), meta_arch.py:147-197 / replace.py:446-457
 struct Variant {
@@ -300,6 +304,17 @@ struct sdm_ctx {
   bool finalized = false;
   void* stage = nullptr;
   size_t stage_bytes = 0;
+  // asynchronous weight pipeline: a ring of (pinned host, device) staging pairs; tensor i+1 is converted
+  // into pinned memory on the CPU while tensor i is copied and packed on the GPU - no host synchronisation per tensor
+  struct LoadSlot {
+    void* host = nullptr; void* dev = nullptr; size_t cap = 0; bool busy = false;
+#ifndef SDM_EMU
+    hipEvent_t done = nullptr;
+#endif
+  };
+  static const int kLoadSlots = 3;
+  LoadSlot load_ring[kLoadSlots];
+  int load_next = 0;
   // model structure
   int enc_conv_in, enc_norm_out, enc_conv_out, quant, post_quant, dec_conv_in, dec_norm_out, dec_conv_out;
   std::vector<std::vector<ResB>> enc_res, dec_res;
@@ -316,6 +331,7 @@ struct sdm_ctx {
   size_t h_time1w, h_time1b, h_time2w, h_time2b, h_bbox1w, h_bbox1b, h_bbox2w, h_bbox2b, h_auxw, h_auxb;
   size_t h_point1w, h_point1b, h_point2w, h_point2b;
   std::vector<Variant> variants;
+  int variant_cap = 0;         // rows allocated in every TembL::table
   int act_f32 = 0;             // precise_mask != 0: every activation that is fp16 in the fast graph is kept in fp32
   int* d_bias_sel = nullptr;   // [max batch]
   int bias_sel_cap = 0;
@@ -740,6 +756,9 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
   if (L.ntaps == 1 && p.stats && p.N > 1) p.rows_per_img = p.Hout * p.Wout;
   rc = launch_conv(L.ntaps, a.stride, cfg, p, e->stream);
   if (rc != 0) SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: bad cfg", L.name.c_str());
+#ifndef SDM_EMU
+  { const hipError_t le = hipGetLastError(); if (le != hipSuccess) SDM_FAIL(e, SDM_ERR_HIP, "conv %s: launch failed: %s", L.name.c_str(), hipGetErrorString(le)); }
+#endif
   prof_end(e);
   return 0;
 }
@@ -887,10 +906,7 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
     }
     if (D == 64) {
       prof_begin(e, "attn_d64", flops, bytes, adesc);
-      // 64 queries per wave when that still leaves >= 2 blocks per CU, else 32
-      const char* force_qt = getenv("SDM_ATTN_QT");       // test hook: force the 64-query-per-wave variant (measured slower)
-      const bool qt2 = force_qt && force_qt[0] == '2' && !ap.prec;
-      const int qrows = qt2 ? 256 : 128;
+      const int qrows = 128;          // 4 waves x 32 queries (a 64-queries-per-wave variant was measured slower and spilled: removed)
       p.batch = B; p.heads = heads; p.nq_blocks = sdm_cdiv(Lq, qrows); p.q_chunks = 8;     // B*heads*8 units: always a multiple of 8
       const int qb = sdm_cdiv(p.nq_blocks, p.q_chunks);
       const unsigned nblk = (unsigned)(B * heads * p.q_chunks * qb);                         // 1-D grid, XCD-aware mapping in the kernel
@@ -899,7 +915,6 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
         SDM_SET_SMEM(kp, ATTN64P_SMEM);
         SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(256), ATTN64P_SMEM, e->stream, p);
       }
-      else if (qt2) { SDM_LAUNCH(attn_d64_kernel<2>, dim3(nblk, 1, 1), dim3(256), ATTN64_SMEM, e->stream, p); }
       else { SDM_LAUNCH(attn_d64_kernel<1>, dim3(nblk, 1, 1), dim3(256), ATTN64_SMEM, e->stream, p); }
       prof_end(e);
     } else {
@@ -1172,21 +1187,39 @@ static int prepare_variants(sdm_ctx* e, int B, const int32_t* is_trans, const fl
       if (e->variants[i] == v) return (int)i;
     return -1;
   };
-  for (int attempt = 0; attempt < 2; ++attempt) {
-    bool overflow = false;
-    for (int b = 0; b < B && !overflow; ++b) {
+  {   // distinct conditionings of THIS batch; the tables hold at least that many rows (plus what is cached from earlier calls)
+    std::vector<Variant> uniq;
+    for (int b = 0; b < B; ++b) {
+      bool seen = false;
+      for (auto& u : uniq) if (u == want[b]) { seen = true; break; }
+      if (!seen) uniq.push_back(want[b]);
+    }
+    int missing = 0;
+    for (auto& u : uniq) if (find(u) < 0) ++missing;
+    if ((int)e->variants.size() + missing > e->variant_cap) {
+      // not enough rows: drop the cached rows (they are recomputed on demand) and, if this batch alone needs more, grow the tables
+      e->variants.clear();
+      if ((int)uniq.size() > e->variant_cap) {
+        const int cap = std::max(rup((int)uniq.size(), 8), kMinVariantRows);
+        SDM_CHECK_DEV(e, dev_sync(e->stream));
+        for (auto& t : e->tembs) {
+          if (t.table) dev_free(t.table);
+          void* q = nullptr;
+          if (dev_malloc(&q, (size_t)cap * t.cout_pad * 4) != 0) { t.table = nullptr; e->variant_cap = 0; SDM_FAIL(e, SDM_ERR_NOMEM, "cannot allocate %d conditioning rows", cap); }
+          t.table = (float*)q;
+        }
+        e->variant_cap = cap;
+      }
+    }
+    for (int b = 0; b < B; ++b) {
       int f = find(want[b]);
       if (f < 0) {
-        if ((int)e->variants.size() >= kMaxVariants) { overflow = true; break; }
         e->variants.push_back(want[b]);
         f = (int)e->variants.size() - 1;
         TRY(compute_variant_tables(e, f));
       }
       sel[b] = f;
     }
-    if (!overflow) break;
-    if (attempt == 1) SDM_FAIL(e, SDM_ERR_INVALID, "more than %d distinct (is_trans, coordinates) combinations in one batch", kMaxVariants);
-    e->variants.clear();   // cache full of stale combinations: start over for this batch
   }
   if (B > e->bias_sel_cap) {
     if (e->d_bias_sel) dev_free(e->d_bias_sel);
@@ -1351,8 +1384,12 @@ static int ensure_buf(sdm_ctx* e, void** p, size_t* cap, size_t need) {
 
 // mode 0: core API (NCHW preprocessed, S x S); mode 1: node API (BHWC image + BHW trimap at H x W)
 // mode 0 takes the inference size as (SH, SW) = (H, W) and S is ignored; mode 1 resizes H x W to S x S like the node.
+// node tail (mode 1 only): mask_refine + output composition on the GPU, sdmatte_nodes.py:365-397
+struct NodeTail { int output_mode = 0, mask_refine = 0; float c = 0.8f; float* matted = nullptr; int channels() const { return output_mode == 1 ? 4 : 3; } };
+
 static int forward_impl(sdm_ctx* e, int mode, const float* image, const float* trimap, int B, int H, int W, int S, const int32_t* is_trans,
-                        const float* cond, int cond_dim, int cond_kind, bool use_mask, float* out, int ptr_kind, void* stream_arg) {
+                        const float* cond, int cond_dim, int cond_kind, bool use_mask, float* out, int ptr_kind, void* stream_arg,
+                        const NodeTail* tail = nullptr) {
   if (!e->finalized) SDM_FAIL(e, SDM_ERR_STATE, "weights not finalised: call sdm_load_tensor(...) and sdm_finalize_weights first");
   const int SH = (mode == 0) ? H : S, SW = (mode == 0) ? W : S;
   if (B <= 0 || SH <= 0 || SW <= 0 || SH % 64 || SW % 64)
@@ -1372,14 +1409,17 @@ static int forward_impl(sdm_ctx* e, int mode, const float* image, const float* t
 #endif
   const size_t in_img = (size_t)B * H * W * 3 * 4;          // mode 0: [B,3,SH,SW]; mode 1: [B,H,W,3]
   const size_t in_tri = (size_t)B * H * W * 4;
-  const size_t out_bytes = (size_t)B * H * W * 4;
+  const size_t alpha_bytes = (size_t)B * H * W * 4;
+  const size_t out_bytes = alpha_bytes * (tail ? 1 + tail->channels() : 1);      // host hand-over: alpha, then the composed image
   const float* d_img = image; const float* d_tri = trimap; float* d_out = out;
+  float* d_matted = tail ? tail->matted : nullptr;
   if (ptr_kind == SDM_PTR_HOST) {
     TRY(ensure_buf(e, &e->io_in, &e->io_in_bytes, in_img + in_tri));
     TRY(ensure_buf(e, &e->io_out, &e->io_out_bytes, out_bytes));
     SDM_CHECK_DEV(e, dev_memcpy_h2d(e->io_in, image, in_img, e->stream));
     SDM_CHECK_DEV(e, dev_memcpy_h2d((unsigned char*)e->io_in + in_img, trimap, in_tri, e->stream));
     d_img = (const float*)e->io_in; d_tri = (const float*)((unsigned char*)e->io_in + in_img); d_out = (float*)e->io_out;
+    if (tail) d_matted = (float*)((unsigned char*)e->io_out + alpha_bytes);
   }
   TRY(prepare_variants(e, B, is_trans, cond, cond_dim, cond_kind));
   for (int pass = 0; pass < 2; ++pass) {
@@ -1417,6 +1457,9 @@ static int forward_impl(sdm_ctx* e, int mode, const float* image, const float* t
       } else {
         SDM_LAUNCH(resize_planes_kernel, dim3((unsigned)(((long)B * H * W + 255) / 256)), dim3(256), 0, e->stream, (const float*)alpha.p, d_out, B,
                    S, S, H, W, 1);
+        if (tail)
+          SDM_LAUNCH(refine_compose_kernel, dim3((unsigned)(((long)B * H * W + 255) / 256)), dim3(256), 0, e->stream, d_img, d_tri, d_out, d_matted,
+                     (long)B * H * W, tail->output_mode, tail->mask_refine, tail->c, (float)(1.0 - (double)tail->c));
       }
     }
     tfree(e, alpha); tfree(e, plane); tfree(e, x16);
@@ -1426,7 +1469,8 @@ static int forward_impl(sdm_ctx* e, int mode, const float* image, const float* t
   (void)hipEventRecord(e->ev1, (hipStream_t)e->stream);
 #endif
   if (ptr_kind == SDM_PTR_HOST) {
-    SDM_CHECK_DEV(e, dev_memcpy_d2h(out, e->io_out, out_bytes, e->stream));
+    SDM_CHECK_DEV(e, dev_memcpy_d2h(out, e->io_out, alpha_bytes, e->stream));
+    if (tail) SDM_CHECK_DEV(e, dev_memcpy_d2h(tail->matted, (unsigned char*)e->io_out + alpha_bytes, out_bytes - alpha_bytes, e->stream));
     SDM_CHECK_DEV(e, dev_sync(e->stream));
   }
 #ifndef SDM_EMU
@@ -1463,6 +1507,8 @@ static int run_two_pass(sdm_ctx* e, F body) {
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
+static void load_ring_release(sdm_ctx* e);
+
 extern "C" {
 
 void sdm_default_config(sdm_config* c) {
@@ -1521,7 +1567,7 @@ int sdm_create(sdm_ctx** out, int device_id, const sdm_config* cfg) {
 #endif
   // weight arena (+ temb tables)
   void* p = nullptr;
-  if (dev_malloc(&p, e->warena_bytes) != 0) { g_create_err = "cannot allocate weight arena"; delete e; return SDM_ERR_NOMEM; }
+  if (dev_malloc(&p, e->warena_bytes) != 0) { g_create_err = "cannot allocate weight arena"; sdm_destroy(e); return SDM_ERR_NOMEM; }
   e->warena = (unsigned char*)p;
   dev_memset(e->warena, 0, e->warena_bytes, e->stream);
   for (auto& L : e->convs) {
@@ -1531,10 +1577,11 @@ int sdm_create(sdm_ctx** out, int device_id, const sdm_config* cfg) {
   for (auto& n : e->norms) { n.g = (float*)(e->warena + n.g_off); n.b = (float*)(e->warena + n.b_off); }
   for (auto& t : e->tembs) {
     void* q = nullptr;
-    if (dev_malloc(&q, (size_t)kMaxVariants * t.cout_pad * 4) != 0) { g_create_err = "cannot allocate temb tables"; delete e; return SDM_ERR_NOMEM; }
+    if (dev_malloc(&q, (size_t)kMinVariantRows * t.cout_pad * 4) != 0) { g_create_err = "cannot allocate temb tables"; sdm_destroy(e); return SDM_ERR_NOMEM; }
     t.table = (float*)q;
-    dev_memset(q, 0, (size_t)kMaxVariants * t.cout_pad * 4, e->stream);
+    dev_memset(q, 0, (size_t)kMinVariantRows * t.cout_pad * 4, e->stream);
   }
+  e->variant_cap = kMinVariantRows;
   dev_sync(e->stream);
   *out = e;
   return SDM_OK;
@@ -1547,6 +1594,7 @@ void sdm_destroy(sdm_ctx* e) {
   if (e->warena) dev_free(e->warena);
   if (e->arena) dev_free(e->arena);
   if (e->stage) dev_free(e->stage);
+  load_ring_release(e);
   if (e->io_in) dev_free(e->io_in);
   if (e->io_out) dev_free(e->io_out);
   if (e->d_bias_sel) dev_free(e->d_bias_sel);
@@ -1594,28 +1642,56 @@ int sdm_load_tensor(sdm_ctx* e, const char* name, int dtype, int ndim, const int
     float* dst = e->hostblob.data() + s.host_off;
     for (size_t i = 0; i < n; ++i) dst[i] = to_f32(host_ptr, dtype, i);
   } else {
-    // stage as fp32 on the device, then pack with a kernel
+    // convert to fp32 into a pinned staging slot, copy + pack asynchronously on the engine stream; the slot is reused only after
+    // its event has fired (the ring keeps kLoadSlots tensors in flight)
+    float* dsrc = nullptr;
+#ifndef SDM_EMU
+    sdm_ctx::LoadSlot& sl = e->load_ring[e->load_next];
+    e->load_next = (e->load_next + 1) % sdm_ctx::kLoadSlots;
+    if (sl.busy) { SDM_CHECK_DEV(e, (int)hipEventSynchronize(sl.done)); sl.busy = false; }
+    if (sl.cap < n * 4) {
+      if (sl.host) (void)hipHostFree(sl.host);
+      if (sl.dev) dev_free(sl.dev);
+      sl.host = sl.dev = nullptr; sl.cap = 0;
+      const size_t cap = std::max(rupz(n * 4, (size_t)1 << 20), (size_t)8 << 20);
+      if (hipHostMalloc(&sl.host, cap, hipHostMallocDefault) != hipSuccess || dev_malloc(&sl.dev, cap) != 0) SDM_FAIL(e, SDM_ERR_NOMEM, "weight staging alloc failed");
+      sl.cap = cap;
+      if (!sl.done) SDM_CHECK_DEV(e, (int)hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    }
+    float* hs = (float*)sl.host;
+    if (dtype == SDM_F32) memcpy(hs, host_ptr, n * 4);
+    else for (size_t i = 0; i < n; ++i) hs[i] = to_f32(host_ptr, dtype, i);
+    SDM_CHECK_DEV(e, dev_memcpy_h2d(sl.dev, hs, n * 4, e->stream));
+    dsrc = (float*)sl.dev;
+#else
     if (ensure_buf(e, &e->stage, &e->stage_bytes, std::max(n * 4, (size_t)1 << 20)) != 0) return SDM_ERR_NOMEM;
     std::vector<float> tmp;
     const void* src = host_ptr;
     if (dtype != SDM_F32) { tmp.resize(n); for (size_t i = 0; i < n; ++i) tmp[i] = to_f32(host_ptr, dtype, i); src = tmp.data(); }
     SDM_CHECK_DEV(e, dev_memcpy_h2d(e->stage, src, n * 4, e->stream));
+    dsrc = (float*)e->stage;
+#endif
     if (s.kind == SLOT_CONV_W) {
       ConvL& L = e->convs[s.layer];
       const int O = (int)s.shape[0], I = (int)s.shape[1];
       const size_t total = (size_t)L.Cin_pad * L.ntaps * L.Cout_pad;
       SDM_LAUNCH(pack_conv_weight_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 65535)), dim3(256), 0, e->stream,
-                 (const float*)e->stage, L.w, O, I, L.ntaps, L.Cin_pad, L.Cout_pad, s.ci_off, s.co_off, L.geglu,
+                 (const float*)dsrc, L.w, O, I, L.ntaps, L.Cin_pad, L.Cout_pad, s.ci_off, s.co_off, L.geglu,
                  s.w_scale * ldexpf(1.0f, L.w_exp), L.w_lo);
     } else if (s.kind == SLOT_CONV_B) {
       ConvL& L = e->convs[s.layer];
-      SDM_LAUNCH(pack_bias_kernel, dim3(sdm_cdiv(L.Cout_pad, 256)), dim3(256), 0, e->stream, (const float*)e->stage, L.b, (int)s.shape[0],
+      SDM_LAUNCH(pack_bias_kernel, dim3(sdm_cdiv(L.Cout_pad, 256)), dim3(256), 0, e->stream, (const float*)dsrc, L.b, (int)s.shape[0],
                  L.Cout_pad, s.co_off, L.geglu);
     } else {
       NormL& nn = e->norms[s.layer];
-      SDM_CHECK_DEV(e, dev_memcpy_d2d(s.kind == SLOT_NORM_G ? nn.g : nn.b, e->stage, n * 4, e->stream));
+      SDM_CHECK_DEV(e, dev_memcpy_d2d(s.kind == SLOT_NORM_G ? nn.g : nn.b, dsrc, n * 4, e->stream));
     }
-    SDM_CHECK_DEV(e, dev_sync(e->stream));   // staging buffer and `tmp` are reused by the next call
+#ifndef SDM_EMU
+    SDM_CHECK_DEV(e, (int)hipEventRecord(sl.done, (hipStream_t)e->stream));
+    sl.busy = true;
+#else
+    SDM_CHECK_DEV(e, dev_sync(e->stream));
+#endif
   }
   if (!s.loaded) { s.loaded = true; e->n_loaded++; }
   return 1;
@@ -1669,9 +1745,25 @@ static int fold_cross_kv(sdm_ctx* e) {
   return 0;
 }
 
+static void load_ring_release(sdm_ctx* e) {
+#ifndef SDM_EMU
+  for (auto& sl : e->load_ring) {
+    if (sl.busy) { (void)hipEventSynchronize(sl.done); sl.busy = false; }
+    if (sl.host) (void)hipHostFree(sl.host);
+    if (sl.dev) dev_free(sl.dev);
+    if (sl.done) (void)hipEventDestroy(sl.done);
+    sl.host = sl.dev = nullptr; sl.cap = 0; sl.done = nullptr;
+  }
+#else
+  (void)e;
+#endif
+}
+
 int sdm_finalize_weights(sdm_ctx* e) {
   if (e) dev_use(e->device);
   if (!e) return SDM_ERR_INVALID;
+  SDM_CHECK_DEV(e, dev_sync(e->stream));
+  load_ring_release(e);          // the checkpoint is in: give the pinned / device staging ring back
   { int rc = fold_cross_kv(e); if (rc) return rc; }
   e->missing.clear();
   for (auto& k : e->slot_order) if (!e->slots[k].loaded) e->missing.push_back(k);
@@ -1753,6 +1845,32 @@ int sdm_apply_matte(sdm_ctx* e, const float* image, const float* trimap, int B, 
   if (!e || !image || !trimap || !alpha) return SDM_ERR_INVALID;
   std::vector<int32_t> it((size_t)std::max(B, 1), is_transparent ? 1 : 0);
   return forward_impl(e, 1, image, trimap, B, H, W, S, it.data(), nullptr, 4, 0, true, alpha, ptr_kind, stream);
+}
+
+/* Give the activation arena and the I/O staging buffers back to the driver (weights stay resident).  The next forward
+ * re-allocates what it needs. */
+int sdm_release_memory(sdm_ctx* e) {
+  if (e) dev_use(e->device);
+  if (!e) return SDM_ERR_INVALID;
+  SDM_CHECK_DEV(e, dev_sync(e->stream));
+  if (e->arena) { dev_free(e->arena); e->arena = nullptr; e->arena_bytes = 0; }
+  if (e->io_in) { dev_free(e->io_in); e->io_in = nullptr; e->io_in_bytes = 0; }
+  if (e->io_out) { dev_free(e->io_out); e->io_out = nullptr; e->io_out_bytes = 0; }
+  if (e->stage) { dev_free(e->stage); e->stage = nullptr; e->stage_bytes = 0; }
+  return SDM_OK;
+}
+int64_t sdm_resident_bytes(sdm_ctx* e) {
+  return e ? (int64_t)(e->warena_bytes + e->arena_bytes + e->io_in_bytes + e->io_out_bytes + e->stage_bytes) : 0;
+}
+
+int sdm_apply_matte_node(sdm_ctx* e, const float* image, const float* trimap, int B, int H, int W, int S, int is_transparent, int output_mode,
+                         int mask_refine, float trimap_constraint, float* alpha, float* matted, int ptr_kind, void* stream) {
+  if (e) dev_use(e->device);
+  if (!e || !image || !trimap || !alpha || !matted) return SDM_ERR_INVALID;
+  if (output_mode < 0 || output_mode > 2) SDM_FAIL(e, SDM_ERR_INVALID, "unknown output mode %d", output_mode);
+  std::vector<int32_t> it((size_t)std::max(B, 1), is_transparent ? 1 : 0);
+  NodeTail tail; tail.output_mode = output_mode; tail.mask_refine = mask_refine ? 1 : 0; tail.c = trimap_constraint; tail.matted = matted;
+  return forward_impl(e, 1, image, trimap, B, H, W, S, it.data(), nullptr, 4, 0, true, alpha, ptr_kind, stream, &tail);
 }
 
 int sdm_synchronize(sdm_ctx* e) {
@@ -1985,14 +2103,14 @@ float sdm_bench_attn(sdm_ctx* e, int B, int heads, int Lq, int Lk, int qt, int a
   p.q = (const half_t*)q; p.q_bs = (long)Lq * C; p.ldq = C; p.k = (const half_t*)k; p.k_bs = (long)Lk * C; p.ldk = C;
   p.vt = (const half_t*)vt; p.vt_hs = (long)64 * ldvt; p.vt_bs = heads * p.vt_hs; p.ldvt = ldvt; p.o = (half_t*)o; p.o_bs = (long)Lq * C; p.ldo = C;
   p.Lq = Lq; p.Lk = Lk; p.scale_log2e = 0.125f * SDM_LOG2E; p.ablate = ablate;
-  p.batch = B; p.heads = heads; p.nq_blocks = sdm_cdiv(Lq, qt == 2 ? 256 : 128); p.q_chunks = 8;
+  (void)qt;
+  p.batch = B; p.heads = heads; p.nq_blocks = sdm_cdiv(Lq, 128); p.q_chunks = 8;
   const unsigned nblk = (unsigned)(B * heads * p.q_chunks * sdm_cdiv(p.nq_blocks, p.q_chunks));
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   for (int i = 0; i <= iters; ++i) {
     if (i == 1) (void)hipEventRecord(e0, (hipStream_t)e->stream);
-    if (qt == 2) { SDM_LAUNCH(attn_d64_kernel<2>, dim3(nblk), dim3(256), ATTN64_SMEM, e->stream, p); }
-    else { SDM_LAUNCH(attn_d64_kernel<1>, dim3(nblk), dim3(256), ATTN64_SMEM, e->stream, p); }
+    SDM_LAUNCH(attn_d64_kernel<1>, dim3(nblk), dim3(256), ATTN64_SMEM, e->stream, p);
   }
   (void)hipEventRecord(e1, (hipStream_t)e->stream);
   (void)hipStreamSynchronize((hipStream_t)e->stream);

@@ -81,8 +81,8 @@ def to_c_config(cfg: SDMatteConfig, stream_f32: bool = True, precision=None) -> 
 EXPORTS = [
     "sdm_default_config", "sdm_create", "sdm_destroy", "sdm_last_error", "sdm_load_tensor", "sdm_finalize_weights",
     "sdm_weight_stats", "sdm_missing_key", "sdm_weight_blob_bytes", "sdm_export_weight_blob", "sdm_import_weight_blob",
-    "sdm_host_blob_bytes", "sdm_export_host_blob", "sdm_import_host_blob", "sdm_forward", "sdm_forward_ex", "sdm_forward_rect", "sdm_apply_matte",
-    "sdm_synchronize", "sdm_last_forward_ms", "sdm_profile_enable", "sdm_profile_count", "sdm_profile_get", "sdm_profile_dump",
+    "sdm_host_blob_bytes", "sdm_export_host_blob", "sdm_import_host_blob", "sdm_forward", "sdm_forward_ex", "sdm_forward_rect", "sdm_apply_matte", "sdm_apply_matte_node",
+    "sdm_synchronize", "sdm_release_memory", "sdm_resident_bytes", "sdm_last_forward_ms", "sdm_profile_enable", "sdm_profile_count", "sdm_profile_get", "sdm_profile_dump",
     "sdm_op_conv", "sdm_op_conv_ex", "sdm_debug_run_layer", "sdm_debug_temb_row", "sdm_conv_num_cfgs", "sdm_bench_conv", "sdm_bench_attn", "sdm_op_groupnorm", "sdm_op_layernorm", "sdm_op_attention", "sdm_op_resize_aa",
     "sdm_op_mask_bias",
 ]
@@ -113,7 +113,10 @@ class Bindings:
             "sdm_forward_ex": (i32, [vp, vp, vp, i32, i32, vp, vp, i32, i32, i32, vp, i32, vp]),
             "sdm_forward_rect": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, i32, i32, i32, vp, i32, vp]),
             "sdm_apply_matte": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, vp]),
+            "sdm_apply_matte_node": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, i32, vp]),
             "sdm_synchronize": (i32, [vp]),
+            "sdm_release_memory": (i32, [vp]),
+            "sdm_resident_bytes": (i64, [vp]),
             "sdm_last_forward_ms": (f32, [vp]),
             "sdm_profile_enable": (i32, [vp, i32]),
             "sdm_profile_count": (i32, [vp]),
@@ -294,11 +297,42 @@ class Engine:
             self.synchronize()
         return out
 
+    OUTPUT_MODES = {"alpha_only": 0, "matted_rgba": 1, "matted_rgb": 2}
+
+    def apply_matte_node(self, image_bhwc, trimap_bhw, S, is_transparent, output_mode, mask_refine, trimap_constraint, sync=True):
+        """The whole node body in one C-ABI call: preprocess, model, resize back, mask_refine and output composition, all on
+        the GPU.  Returns (alpha [B,H,W], matted [B,H,W,3|4]) on the inputs' device."""
+        if output_mode not in self.OUTPUT_MODES:
+            raise ValueError(f"unknown output_mode {output_mode!r}")
+        B, H, W, _ = image_bhwc.shape
+        image_bhwc = image_bhwc.float().contiguous()
+        trimap_bhw = trimap_bhw.float().contiguous()
+        if tuple(trimap_bhw.shape) != (B, H, W):
+            raise ValueError(f"apply_matte_node: trimap must be [B,H,W] = {(B, H, W)}, got {tuple(trimap_bhw.shape)}")
+        mode = self.OUTPUT_MODES[output_mode]
+        alpha = torch.empty(B, H, W, dtype=torch.float32, device=image_bhwc.device)
+        matted = torch.empty(B, H, W, 4 if mode == 1 else 3, dtype=torch.float32, device=image_bhwc.device)
+        stream = self._check_io("apply_matte_node", image_bhwc, trimap_bhw, alpha, matted)
+        self._check(self.lib.sdm_apply_matte_node(self.h, _ptr(image_bhwc), _ptr(trimap_bhw), B, H, W, int(S), 1 if is_transparent else 0, mode,
+                                                  1 if mask_refine else 0, float(trimap_constraint), _ptr(alpha), _ptr(matted),
+                                                  self._kind(image_bhwc), stream), "sdm_apply_matte_node")
+        if sync:
+            self.synchronize()
+        return alpha, matted
+
     def synchronize(self):
         self._check(self.lib.sdm_synchronize(self.h), "sdm_synchronize")
 
     def last_forward_ms(self):
         return float(self.lib.sdm_last_forward_ms(self.h))
+
+    def resident_bytes(self):
+        """Device memory held by the engine (weights + activation arena + I/O staging), invisible to torch's allocator."""
+        return int(self.lib.sdm_resident_bytes(self.h))
+
+    def release_memory(self):
+        """Free the activation arena and staging buffers (weights stay); the next call re-allocates what it needs."""
+        self._check(self.lib.sdm_release_memory(self.h), "sdm_release_memory")
 
     def profile(self, on: bool):
         self.lib.sdm_profile_enable(self.h, 1 if on else 0)

@@ -198,5 +198,24 @@ class MultiGpuEngine:
         self._fan(B, call)
         return out
 
+    def apply_matte_node(self, image_bhwc, trimap_bhw, S, is_transparent, output_mode, mask_refine, trimap_constraint):
+        """The whole node body (incl. mask_refine + output composition on each GPU) for a batch split over the devices;
+        returns (alpha [B,H,W], matted [B,H,W,3|4]) on the HOST."""
+        from .engine import Engine
+        B, H, W, _ = image_bhwc.shape
+        ch = 4 if Engine.OUTPUT_MODES[output_mode] == 1 else 3
+        alpha = torch.empty(B, H, W, dtype=torch.float32)
+        matted = torch.empty(B, H, W, ch, dtype=torch.float32)
+        img = image_bhwc.detach().float().cpu().contiguous()
+        tri = trimap_bhw.detach().float().cpu().contiguous()
+
+        def call(eng, dev, lo, hi):
+            a, m = eng.apply_matte_node(img[lo:hi], tri[lo:hi], S, is_transparent, output_mode, mask_refine, trimap_constraint)
+            alpha[lo:hi].copy_(a)
+            matted[lo:hi].copy_(m)
+
+        self._fan(B, call)
+        return alpha, matted
+
     def last_forward_ms(self):
         return max(e.last_forward_ms() for e in self.engines)

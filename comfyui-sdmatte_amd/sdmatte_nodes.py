@@ -7,8 +7,9 @@ signature (sdmatte_nodes.py:217-257), same `NODE_CLASS_MAPPINGS` / `NODE_DISPLAY
   * the model is the hand-written HIP engine (engine.py -> libsdmatte_hip.so), not diffusers modules;
   * the built model is cached per (checkpoint path, mtime, device) instead of being rebuilt and re-read on every
     call (the reference does both per call, :286-323);
-  * resize / normalise / forward / resize-back / clamp run on the GPU in one C-ABI call; `mask_refine` and the
-    output composition stay on the CPU tensors exactly as in the reference (:365-397);
+  * resize / normalise / forward / resize-back / clamp / `mask_refine` / output composition (:339-397) run on the GPU in
+    one C-ABI call (`sdm_apply_matte_node`); `refine_and_compose` below is the same tail on CPU tensors, kept as the
+    bit-exact restatement the tests compare with;
   * `force_cpu=True` is rejected: this node has no CPU path (the reference's own force_cpu branch cannot run either:
     meta_arch.py hard-codes `.cuda()`).
 """
@@ -178,6 +179,32 @@ def get_model(ckpt_name, device):
     return model
 
 
+def _trim_engine_memory(model):
+    """The engine's activation arena lives outside torch's / ComfyUI's allocators and is sized by the largest call so far.  Give it
+    back after the call when it is large (SDMATTE_KEEP_ARENA_GB, default 8), so that other nodes of the workflow can use the memory;
+    the packed weights stay resident (that is the point of the model cache)."""
+    try:
+        limit = float(os.environ.get("SDMATTE_KEEP_ARENA_GB", "8")) * 2 ** 30
+        engines = [model.engine] + (list(model._fan.engines[1:]) if getattr(model, "_fan", None) is not None else [])
+        for eng in engines:
+            if eng.resident_bytes() - eng.weight_blob_bytes() > limit:
+                eng.release_memory()
+    except Exception as exc:  # noqa: BLE001 - best effort, like the reference's empty_cache block (sdmatte_nodes.py:399-403)
+        print(f"[SDMatte] note: could not trim engine memory ({exc})")
+
+
+def unload_models():
+    """Drop the cached engine(s): every byte the node holds on the GPU is released."""
+    with _CACHE_LOCK:
+        for model in list(_MODEL_CACHE.values()):
+            fan = getattr(model, "_fan", None)
+            if fan is not None:
+                fan.close()
+            if model.engine is not None:
+                model.engine.close()
+        _MODEL_CACHE.clear()
+
+
 def _fan_out(model, batch):
     """Multi-GPU fan-out of one node call: used when the batch has more than one image, more than one GPU is visible and
     SDMATTE_MULTI_GPU is not "0".  The extra engines live as long as the cached model they were copied from."""
@@ -256,11 +283,14 @@ class SDMatteApply:
             raise ValueError(f"[SDMatte] trimap must be [B,H,W] matching the image, got {tuple(trimap.shape)}")
         model = get_model(ckpt_name, _torch_device())
         fan = _fan_out(model, image.shape[0])
-        if fan is not None:          # batch split over every visible GPU (one engine + host thread per device)
-            alpha = fan.apply_matte(image, trimap, int(inference_size), bool(is_transparent))
-        else:
-            alpha = model.engine.apply_matte(image, trimap, int(inference_size), bool(is_transparent))   # [B,H,W] fp32, same device as input
-        out, matted = refine_and_compose(alpha.detach().cpu(), image, trimap, output_mode, mask_refine, trimap_constraint)
+        # one C-ABI call per device: resize / normalise / model / resize back / clamp AND mask_refine + output composition, all on
+        # the GPU at the original resolution (bit-identical to the reference's CPU tail, tests/test_emu_e2e.py); with several GPUs
+        # the batch is split over them (one engine + host thread per device)
+        runner = fan if fan is not None else model.engine
+        out, matted = runner.apply_matte_node(image, trimap, int(inference_size), bool(is_transparent), output_mode, bool(mask_refine),
+                                              float(trimap_constraint))
+        out, matted = out.detach().cpu(), matted.detach().cpu()
+        _trim_engine_memory(model)
         return (out, matted)
 
 

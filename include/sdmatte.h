@@ -146,6 +146,19 @@ int sdm_forward_rect(sdm_ctx* ctx, const float* image_b3hw, const float* aux_b1h
 int sdm_apply_matte(sdm_ctx* ctx, const float* image_bhwc, const float* trimap_bhw, int B, int H, int W, int S,
                     int is_transparent, float* alpha_bhw, int ptr_kind, void* stream);
 
+/* The whole node in one call: sdm_apply_matte followed, at the original resolution and on the GPU, by
+ * mask_refine (trimap_constraint; sdmatte_nodes.py:365-380) and the output composition (sdmatte_nodes.py:382-397):
+ * output_mode 0 = alpha_only (matted = zeros [B,H,W,3]), 1 = matted_rgba ([B,H,W,4] = image | alpha), 2 = matted_rgb
+ * ([B,H,W,3] = image gated by (trimap > 0.2) & (alpha > 0.1)).  Bit-identical to the reference's CPU tensor arithmetic. */
+int sdm_apply_matte_node(sdm_ctx* ctx, const float* image_bhwc, const float* trimap_bhw, int B, int H, int W, int S, int is_transparent,
+                         int output_mode, int mask_refine, float trimap_constraint, float* alpha_bhw, float* matted_bhwc, int ptr_kind,
+                         void* stream);
+
+/* Memory the engine holds outside any framework allocator: packed weights + activation arena (sized by the largest batch /
+ * resolution seen) + I/O staging.  sdm_release_memory frees everything but the weights (the next forward re-allocates). */
+int64_t sdm_resident_bytes(sdm_ctx* ctx);
+int sdm_release_memory(sdm_ctx* ctx);
+
 /* Block until everything queued on the engine stream has finished. */
 int sdm_synchronize(sdm_ctx* ctx);
 

@@ -57,6 +57,31 @@ def test_emu_precise_mode_meets_parity_bar(pkg, monkeypatch):
     assert dp.mean().item() < dfast.mean().item()
 
 
+def test_emu_gpu_node_tail_bit_exact_vs_reference_fixture(pkg, golden_dir):
+    """sdm_apply_matte_node = sdm_apply_matte + mask_refine + output composition on the device.  For every
+    (output mode, refine, constraint) case of fixture G1, on the fixture's image + trimap: the device tail applied to the engine's
+    own alpha == `refine_and_compose` applied to the same alpha on the CPU, bit for bit; `refine_and_compose` itself is pinned
+    bit-exactly to what the REFERENCE node produced (tests/test_node_cpu.py::test_cpu_tail_bit_exact_vs_reference)."""
+    import numpy as np
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    from comfyui_sdmatte_amd.weights import synthetic_state_dict
+    from comfyui_sdmatte_amd.sdmatte_nodes import refine_and_compose
+    g = np.load(os.path.join(golden_dir, "g1_node_prepost.npz"))
+    image, tri = torch.from_numpy(g["image"]), torch.from_numpy(g["trimap"])
+    cfg = SDMatteConfig.tiny()
+    eng = _emu_engine(cfg)
+    eng.load_state_dict(synthetic_state_dict(cfg, 0))
+    raw = eng.apply_matte(image, tri, 64)                          # the engine's own resized + clamped alpha for these inputs
+    for tag in g["cases"]:
+        mode, refine, c = str(tag).split("__")
+        a, m = eng.apply_matte_node(image, tri, 64, False, mode, refine == "refine1", int(c[1:]) / 10.0)
+        wa, wm = refine_and_compose(raw.clone(), image, tri, mode, refine == "refine1", int(c[1:]) / 10.0)   # bit-exact vs G1 (test_node_cpu)
+        assert torch.equal(a, wa) and torch.equal(m, wm), str(tag)
+    with pytest.raises(ValueError):
+        eng.apply_matte_node(image, tri, 64, False, "nope", True, 0.8)
+    eng.close()
+
+
 def test_emu_single_process_fan_out(pkg):
     """MultiGpuEngine (the node's single-process multi-GPU path) with two emulator engines standing in for two devices: weights
     packed once and copied, uneven contiguous split, host threads, same bits as one engine."""
@@ -78,6 +103,9 @@ def test_emu_single_process_fan_out(pkg):
     assert (got - one.apply_matte(img, tri, 64)).abs().max().item() < 5e-3
     got1 = fan.apply_matte(img[:1], tri[:1], 64)                     # fewer images than devices
     assert torch.equal(got1, one.apply_matte(img[:1], tri[:1], 64))
+    fa, fm = fan.apply_matte_node(img, tri, 64, False, "matted_rgba", True, 0.8)      # the node body (GPU tail) through the fan-out
+    oa, om = one.apply_matte_node(img[:2], tri[:2], 64, False, "matted_rgba", True, 0.8)
+    assert torch.equal(fa[:2], oa) and torch.equal(fm[:2], om) and fm.shape == (3, 64, 64, 4)
     with pytest.raises(ValueError):                                  # errors propagate from the worker threads
         fan.apply_matte(img, tri[:, :32], 64)
     one.close(); fan.close()

@@ -97,12 +97,6 @@ def test_attention_d64_skips_underflowing_key_tiles(emu_engine, monkeypatch):
     assert torch.equal(sparse, dense)
 
 
-def test_attention_d64_64q_per_wave(emu_engine, monkeypatch):
-    monkeypatch.setenv("SDM_ATTN_QT", "2")
-    S.check_attention(emu_engine, DEV, 1, 2, 150, 200, 64, use_bias=True, fused_stride=True, seed=5)
-    S.check_attention(emu_engine, DEV, 1, 1, 64, 192, 64, use_bias=False, spike=True, seed=6)
-
-
 def test_attention_d512(emu_engine):
     S.check_attention(emu_engine, DEV, 1, 1, 40, 64, 512, use_bias=False, atol=5e-3)
     S.check_attention(emu_engine, DEV, 1, 1, 33, 50, 512, use_bias=False, atol=5e-3, seed=2)   # ragged last key tile (clamped DMA rows + mask)

@@ -125,12 +125,6 @@ def test_attention_d64_skips_underflowing_key_tiles(eng, monkeypatch):
     assert torch.equal(sparse, dense)
 
 
-def test_attention_d64_64q_per_wave(eng, monkeypatch):
-    monkeypatch.setenv("SDM_ATTN_QT", "2")
-    S.check_attention(eng, DEV, 1, 2, 150, 200, 64, use_bias=True, fused_stride=True, seed=5)
-    S.check_attention(eng, DEV, 1, 1, 64, 192, 64, use_bias=False, spike=True, seed=6)
-
-
 def test_attention_d512(eng):
     S.check_attention(eng, DEV, 1, 1, 1024, 1024, 512, use_bias=False, atol=5e-3)
     S.check_attention(eng, DEV, 2, 1, 200, 320, 512, use_bias=False, atol=5e-3, seed=1)
