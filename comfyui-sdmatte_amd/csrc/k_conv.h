@@ -41,6 +41,7 @@ struct ConvParams {
   int rows_per_img;                     // NTAPS==1: != 0 -> row tiles are aligned to images of this many rows (needed when the
                                         // epilogue emits per-image GroupNorm statistics for a batch: one launch instead of N)
   const half_t* w;                      // packed weights, K16 layout
+  const half_t* w_dma;                  // DMAB kernels: the 3x3 weights in stage order [Cin/16][dx][hi|lo][k-half][dy][Cout_pad][8] (see pack_conv_weight_dma_kernel)
   const half_t* w_lo;                   // SPLIT kernels: fp16 low parts of the (scaled) weights, same layout: w = (w_hi + w_lo) * acc_scale
   float acc_scale;                      // multiplies the accumulator in the epilogue (undoes the power-of-two weight pre-scale; 1 otherwise)
   size_t out_lo_off;                    // out_f32 == 2: element offset of the low-part plane behind the high-part plane
@@ -65,7 +66,7 @@ struct ConvParams {
                                         // layer (reduced by gn_partials_scale_shift_kernel); NTAPS==9 or one image per launch
 };
 
-template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN, int DB = 0, int SPLIT = 0>
+template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN, int DB = 0, int SPLIT = 0, int DMAB = 0>
 struct ConvCfg {
   static constexpr int NTHREADS = 64 * WM * WN;
   static constexpr int BM = TH * TW;
@@ -81,19 +82,24 @@ struct ConvCfg {
   // two separate planes of 16-byte rows: plane h of row r at h * rows * 16 + r * 16.  A 16-lane ds_read_b128 group then reads 16
   // rows of one plane = 256 contiguous bytes (conflict-free, no padding) and every fragment address is base + constant.
   static constexpr int SWZ = DB ? 1 : 0;
-  static constexpr int PL = (SPLIT && KC == 16) ? 1 : 0;
+  static constexpr int PL = ((SPLIT && KC == 16) || DMAB) ? 1 : 0;
   static constexpr int PITCH = (SWZ || PL) ? KC * 2 : KC * 2 + 16;     // bytes per row (both halves)
   static constexpr int ROWB = PL ? 16 : PITCH;                         // address stride between consecutive rows
   static constexpr int KV = KC / 8;
   static constexpr int A_BYTES = HP * PITCH;
   static constexpr int B_BYTES = NTAPS * BN * PITCH;
   static constexpr int STG_BYTES = WM * WN * 32 * WTN * 4;
-  static constexpr int TILE_BYTES = (SPLIT ? 2 : 1) * A_BYTES + B_BYTES;   // one K-chunk of A halo (SPLIT: high and low parts) + B taps
+  // DMAB (weights by LDS-DMA): two A tiles (fp16: double buffer; SPLIT: hi | lo) + a ring of 4 weight stages, one stage = the 3 taps
+  // of one kernel column dx for BN output channels in half-plane layout (2 x 3 x BN rows of 16 B)
+  static constexpr int DMA_SLOT = 96 * BN, DMA_SLOTS = 4;
+  static constexpr int TILE_BYTES = DMAB ? 2 * A_BYTES + DMA_SLOTS * DMA_SLOT
+                                         : (SPLIT ? 2 : 1) * A_BYTES + B_BYTES;   // one K-chunk of A halo (SPLIT: high and low parts) + B taps
   static constexpr int SMEM = ((DB ? 2 : 1) * TILE_BYTES) > STG_BYTES ? ((DB ? 2 : 1) * TILE_BYTES) : STG_BYTES;
   static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of 32x32");
   static_assert(KC % 16 == 0, "KC multiple of the MFMA K (16)");
   static_assert(!DB || KC == 16, "swizzled double-buffered tiles assume 2 halves per row");
   static_assert(!(DB && SPLIT), "the split-operand kernels use the single-buffered tile");
+  static_assert(!DMAB || (NTAPS == 9 && STRIDE == 1 && TW == 32 && KC == 16 && BN == 128 && WM * WN == 4 && !DB), "DMA-weight pipeline: 256 x 128 tile only");
 };
 
 // SPLIT = 1 ("precise" mode): every operand enters the MFMAs as a pair of fp16 values hi + lo (22 significant
@@ -102,12 +108,19 @@ struct ConvCfg {
 // fp16-normal) when they were packed: w * 2^k = w_hi + w_lo.  Per K-chunk the accumulators receive
 //   A_hi.B_hi + A_lo.B_hi   (B tile = w_hi),   then   A_hi.B_lo   (B tile re-staged with w_lo);
 // the lo.lo term (2^-22 relative) is dropped.  fp32 accumulation as before; the epilogue multiplies by acc_scale = 2^-k.
-template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN, int IN_F32, int DB, int GN, int SPLIT = 0>
+//
+// DMAB = 1: the weights never pass through registers.  They are packed in "stage" order - one stage = the three taps (dy) of one
+// kernel column dx for one 16-channel chunk (and, for SPLIT, one of the hi / lo parts) - and arrive by LDS-DMA (`buffer_load ... lds`)
+// into a ring of 4 stages, three stages ahead of the one being multiplied; the MFMA loop sweeps one kernel column per stage
+// (24 MFMAs per wave, vertical A-fragment reuse as before), ONE raw s_barrier per stage with a counted vmcnt, so DMAs stay in
+// flight across barriers.  fp16-operand kernels double-buffer the activation halo tile in LDS as well (written while the previous
+// chunk is still being multiplied); SPLIT kernels keep A_hi | A_lo single-buffered and re-stage them between two barriers per chunk.
+template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN, int IN_F32, int DB, int GN, int SPLIT = 0, int DMAB = 0>
 // second argument = minimum waves per SIMD: the big 4-wave tiles keep 2 blocks/CU resident (2 waves/SIMD, <= 256 registers)
-__global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BN == 128) ? 2 : 1)
+__global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BN == 128) ? 2 : (WM * WN == 4 && BN == 64 && KC == 16 && TW == 32) ? 3 : 1)
 conv_mfma_kernel(ConvParams p) {
   static_assert(!SPLIT || IN_F32, "split operands are produced from fp32 activations");
-  using C = ConvCfg<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN, DB, SPLIT>;
+  using C = ConvCfg<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN, DB, SPLIT, DMAB>;
   constexpr int NT = C::NTHREADS, MT = C::MT, NTL = C::NTL, PITCH = C::PITCH, KV = C::KV;
   constexpr int HPW = C::HPW, HP = C::HP, WTM = C::WTM, WTN = C::WTN;
   constexpr int SWZ = C::SWZ, PL = C::PL, ROWB = C::ROWB;
@@ -412,6 +425,106 @@ conv_mfma_kernel(ConvParams p) {
     }
   };
 
+  if (DMAB) {
+    constexpr int SLOT = C::DMA_SLOT, NPR = SPLIT ? 2 : 1, PLANE = 3 * BN * 16;      // PLANE: one k-half plane of a stage (3 dy x BN rows)
+    unsigned char* Aring = smem;
+    unsigned char* Bring = smem + 2 * C::A_BYTES;
+    const int nchunks = Cin / 16, nst = nchunks * 3 * NPR;
+    const sdm_rsrc rsd = sdm_make_rsrc(p.w_dma, (unsigned int)((size_t)Cin * 9 * NPR * p.Cout_pad * 2));
+    const int wv = SDM_UNIFORM_I(wave);
+    const unsigned int dma_voff = (unsigned int)((n0 + lane) * 16);
+    const unsigned int stage_rows = (unsigned int)p.Cout_pad * 16u;                  // bytes of one (k-half, dy) row group
+    // 12 pieces of 1 KB per stage: piece q = (k-half, dy, 64-channel half); this wave issues pieces 3*wave .. 3*wave+2
+    auto dma_stage = [&](int s) {
+      unsigned char* dst = Bring + (s & 3) * SLOT;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int q = wv * 3 + k, half = q / 6, dy = (q >> 1) % 3, ch = q & 1;
+        const unsigned int row = (unsigned int)((s * 2 + half) * 3 + dy);          // s enumerates (chunk, dx, part) in memory order
+        sdm_glds16_buf(rsd, dma_voff + (unsigned int)(ch * 1024), row * stage_rows, dst + half * PLANE + dy * (BN * 16) + ch * 1024);
+      }
+    };
+    int bq[NTL];
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) bq[j] = (lane >> 5) * PLANE + (wn * WTN + j * 32 + (lane & 31)) * 16;
+    // one kernel column: halo rows r = 0..MT+1 of column dx against the three taps (dy, dx); output row i = r - dy
+    auto sweep = [&](const unsigned char* Ap, const unsigned char* Bp, int dx) {
+      constexpr int NR = MT + 2;
+      f16x8 fav[2], fbv[3][NTL];
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) fbv[dy][j] = *(const f16x8*)(Bp + bq[j] + dy * (BN * 16));
+      fav[0] = *(const f16x8*)(Ap + abase[0] + dx * 16);
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        if (r + 1 < NR) fav[(r + 1) & 1] = *(const f16x8*)(Ap + abase[0] + ((r + 1) * HPW + dx) * 16);
+        SDM_SCHED_FENCE();
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const int i = r - dy;
+          if (i >= 0 && i < MT) {
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) acc[i][j] = SDM_MFMA_32x32x16_F16(fav[r & 1], fbv[dy][j], acc[i][j]);
+          }
+        }
+        SDM_SCHED_FENCE();
+      }
+    };
+    // end of a stage: the NEXT stage's weights (this wave's pieces) have landed, LDS writes of this wave are done, then the barrier.
+    // vmcnt is counted: every stage issued after stage s+1 adds 3 DMAs per wave, and only those may still be in flight
+    auto stage_end = [&](int s) {
+      if (s + 3 < nst) SDM_WAIT_VMCNT(6);
+      else if (s + 2 < nst) SDM_WAIT_VMCNT(3);
+      else SDM_WAIT_VMCNT0();
+      SDM_WAIT_LGKMCNT0();
+      SDM_RAW_BARRIER();
+    };
+    issue_loads_a(0);
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+      if (s < nst) dma_stage(s);
+    if (GN) __syncthreads();      // gn_tab filled (no DMA data is consumed yet; this only delays the first write)
+    write_lds_a(Aring, 0);
+    SDM_WAIT_VMCNT0();
+    SDM_WAIT_LGKMCNT0();
+    SDM_RAW_BARRIER();
+    for (int c = 0; c < nchunks; ++c) {
+      const bool more = c + 1 < nchunks;
+      if (SPLIT) {
+        const unsigned char* Ahi = Aring;
+        const unsigned char* Alo = Aring + C::A_BYTES;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int s = (c * 3 + dx) * 2;
+          if (dx == 0 && more) issue_loads_a((c + 1) * 16);
+          if (s + 3 < nst) dma_stage(s + 3);
+          sweep(Ahi, Bring + (s & 3) * SLOT, dx);           // A_hi . w_hi
+          sweep(Alo, Bring + (s & 3) * SLOT, dx);           // A_lo . w_hi
+          stage_end(s);
+          if (s + 4 < nst) dma_stage(s + 4);
+          sweep(Ahi, Bring + ((s + 1) & 3) * SLOT, dx);     // A_hi . w_lo
+          stage_end(s + 1);
+        }
+        if (more) {                 // every wave is past the last read of A(c): re-stage the halo tiles for chunk c+1
+          write_lds_a(Aring, (c + 1) * 16);
+          SDM_WAIT_LGKMCNT0();
+          SDM_RAW_BARRIER();
+        }
+      } else {
+        const unsigned char* Acur = Aring + (c & 1) * C::A_BYTES;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int s = c * 3 + dx;
+          if (dx == 0 && more) issue_loads_a((c + 1) * 16);
+          if (s + 3 < nst) dma_stage(s + 3);
+          sweep(Acur, Bring + (s & 3) * SLOT, dx);
+          if (dx == 2 && more) write_lds_a(Aring + ((c + 1) & 1) * C::A_BYTES, (c + 1) * 16);   // the other A buffer: last read in chunk c-1
+          stage_end(s);
+        }
+      }
+    }
+  } else {
   issue_loads(0);
   if (DB) {                      // double-buffered tiles: chunk 0 is staged up front, ONE barrier per K-chunk afterwards
     if (GN) __syncthreads();     // gn_tab filled
@@ -462,6 +575,8 @@ conv_mfma_kernel(ConvParams p) {
       __syncthreads();
     }
   }
+
+  }   // !DMAB
 
   // ---- epilogue: per-wave PRIVATE fp32 staging tile (32 x WTN) in LDS -> coalesced row stores ----
   if (!DB) __syncthreads();      // all waves are done with the A/B tiles (DB: the loop ended with a barrier)
@@ -674,6 +789,31 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, half_t* __r
     const half_t hi = (half_t)vs;
     wp[idx] = hi;
     if (wp_lo) wp_lo[idx] = (half_t)(vs - (float)hi);
+  }
+}
+
+// 3x3 weights in the stage order of the DMAB kernels: [Cin_pad/16][dx][part][k-half][dy][Cout_pad][8], part = hi (| lo when
+// nparts == 2: the fp16 pair of the pre-scaled weight, as in pack_conv_weight_kernel).  One stage = (chunk, dx, part) =
+// 2 x 3 x Cout_pad rows of 16 bytes; the BN rows of one (k-half, dy) of an output-channel tile are contiguous, so a DMA
+// instruction copies 64 of them (1 KB) straight into the LDS half-plane image.
+__global__ void pack_conv_weight_dma_kernel(const float* __restrict__ w, half_t* __restrict__ wd, int O, int I, int Cin_pad, int Cout_pad,
+                                            int ci_off, float scale, int nparts) {
+  const size_t total = (size_t)Cin_pad * 9 * Cout_pad * nparts;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int k8 = idx % 8;
+    size_t t = idx / 8;
+    const int co = t % Cout_pad; t /= Cout_pad;
+    const int dy = t % 3; t /= 3;
+    const int half = t % 2; t /= 2;
+    const int part = t % nparts; t /= nparts;
+    const int dx = t % 3;
+    const int chunk = t / 3;
+    const int ci = chunk * 16 + half * 8 + k8 - ci_off;
+    float v = 0.0f;
+    if (co < O && ci >= 0 && ci < I) v = w[((size_t)co * I + ci) * 9 + dy * 3 + dx];
+    const float vs = v * scale;
+    const half_t hi = (half_t)vs;
+    wd[idx] = part == 0 ? hi : (half_t)(vs - (float)hi);
   }
 }
 

@@ -97,6 +97,7 @@ static inline void sdm_glds16_buf(sdm_rsrc r, unsigned int voff, unsigned int so
 #define SDM_OPAQUE_I(x) ((void)0)
 #define SDM_PIN_HERE_V4(a, b, c, d) ((void)0)
 #define SDM_WAIT_VMCNT0() ((void)0)
+#define SDM_WAIT_VMCNT(n) ((void)0)
 #define SDM_WAIT_LGKMCNT0() ((void)0)
 #define SDM_RAW_BARRIER() __syncthreads()
 #else
@@ -117,6 +118,8 @@ __device__ __forceinline__ void sdm_glds16_buf(sdm_rsrc r, unsigned int voff, un
 // below a later branch, out of the block whose instruction interleave is being pinned)
 #define SDM_PIN_HERE_V4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
 #define SDM_WAIT_VMCNT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// counted wait: at most n vector-memory operations of this wave (loads, LDS-DMAs, stores) may still be outstanding afterwards
+#define SDM_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define SDM_WAIT_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define SDM_RAW_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 #endif

@@ -137,11 +137,11 @@ static void launch_conv_t(const ConvParams& p_in, void* stream) {
 }
 
 struct ConvCfgInfo { int TH, TW, BN, KC, WM; };
-static const ConvCfgInfo kCfg3s1[] = {{8, 32, 128, 16, 2}, {4, 32, 64, 32, 4}, {8, 8, 64, 16, 2}, {16, 32, 128, 16, 4}, {8, 32, 32, 16, 4}};
+static const ConvCfgInfo kCfg3s1[] = {{8, 32, 128, 16, 2}, {4, 32, 64, 32, 4}, {8, 8, 64, 16, 2}, {16, 32, 128, 16, 4}, {8, 32, 32, 16, 4}, {8, 32, 64, 16, 2}};
 static const ConvCfgInfo kCfg3s2[] = {{4, 32, 64, 16, 4}, {8, 8, 64, 16, 2}, {4, 32, 128, 16, 2}, {8, 32, 128, 16, 4}};
 static const ConvCfgInfo kCfg1[] = {{8, 32, 128, 64, 2}, {4, 32, 64, 64, 4}, {8, 8, 64, 64, 2}, {8, 8, 64, 16, 2}, {8, 32, 128, 32, 2}};
 
-static int conv_num_cfgs(int ntaps, int stride) { return ntaps == 9 ? (stride == 1 ? 5 : 4) : 5; }
+static int conv_num_cfgs(int ntaps, int stride) { return ntaps == 9 ? (stride == 1 ? 6 : 4) : 5; }
 static const ConvCfgInfo* conv_cfg_table(int ntaps, int stride) { return ntaps == 9 ? (stride == 1 ? kCfg3s1 : kCfg3s2) : kCfg1; }
 
 static bool conv_cfg_ok(const ConvCfgInfo& c, const ConvParams& p) {
@@ -181,6 +181,9 @@ static int conv_pick_cfg(int ntaps, int stride, const ConvParams& p) {
       // thin outputs (conv_out layers, Cout <= 32): the same 256-pixel tile with 32 output channels instead of 128 (HBM-bound
       // layers: 128 -> 3 @1024^2 1.33 -> 0.63 ms)
       if (ntaps == 9 && stride == 1 && i == 0 && p.Cout_pad <= 32 && conv_cfg_ok(t[4], p)) return 4;
+      // fewer than two rounds of the 256x128 tile (2 blocks per CU): the 256x64 tile (3 blocks per CU, twice the blocks) fills the
+      // chip better - measured +5..17 % on the U-Net layers (320 ch @128^2, 640 @64^2, 1280 @32^2), -3..10 % on the large VAE layers
+      if (ntaps == 9 && stride == 1 && i == 0 && blocks < 1024 && p.Cout_pad > 64 && conv_cfg_ok(t[5], p)) return 5;
       // stride 2: 256 pixels x 128 channels on 8 waves halves the input re-reads per output channel (+25 % on the VAE
       // down-samplers) once there is a block for every CU
       if (ntaps == 9 && stride == 2 && i == 0 && conv_cfg_ok(t[3], p) &&
@@ -195,14 +198,41 @@ static int conv_pick_cfg(int ntaps, int stride, const ConvParams& p) {
   return best;
 }
 
+// 256 px x 128 co, 3x3 stride 1, weights through the LDS-DMA stage ring (k_conv.h, DMAB): fp16 / fp32 activations, optional fused
+// GroupNorm, optional split precision
+static void launch_conv_dma(const ConvParams& p_in, void* stream) {
+  ConvParams p = p_in;
+  p.tiles_m = sdm_cdiv(p.Wout, 32) * sdm_cdiv(p.Hout, 8);
+  p.tiles_n = sdm_cdiv(p.Cout_pad, 128);
+  const long total_m = (long)p.tiles_m * p.N;
+  p.xcd_chunk = (int)((total_m + 7) / 8);
+  const dim3 grid((unsigned)(8L * p.xcd_chunk * p.tiles_n), 1, 1);
+  const bool gn = p.gn_scale != nullptr, split = p.w_lo != nullptr;
+  const size_t gn_extra = gn ? (size_t)(p.C0 + p.C1) * 8 : 0;
+#define SDM_DMA_CASE(F32, GNF, SPL)                                                                          \
+  do {                                                                                                       \
+    using CD = ConvCfg<9, 1, 8, 32, 128, 16, 2, 2, 0, SPL, 1>;                                               \
+    auto k = conv_mfma_kernel<9, 1, 8, 32, 128, 16, 2, 2, F32, 0, GNF, SPL, 1>;                              \
+    SDM_SET_SMEM(k, 160 * 1024);                                                                             \
+    SDM_LAUNCH(k, grid, dim3(CD::NTHREADS), (size_t)CD::SMEM + gn_extra, stream, p);                         \
+  } while (0)
+  if (split) { if (gn) SDM_DMA_CASE(1, 1, 1); else SDM_DMA_CASE(1, 0, 1); }
+  else if (p.in_f32) { if (gn) SDM_DMA_CASE(1, 1, 0); else SDM_DMA_CASE(1, 0, 0); }
+  else { if (gn) SDM_DMA_CASE(0, 1, 0); else SDM_DMA_CASE(0, 0, 0); }
+#undef SDM_DMA_CASE
+}
+
 static int launch_conv(int ntaps, int stride, int cfg, const ConvParams& p, void* stream) {
   if (ntaps == 9 && stride == 1) {
     switch (cfg) {
-      case 0: launch_conv_t<9, 1, 8, 32, 128, 16, 2, 2, 0, 1>(p, stream); return 0;   // the only tile with the fused-GroupNorm variant
+      case 0:
+        if (p.w_dma) { launch_conv_dma(p, stream); return 0; }
+        launch_conv_t<9, 1, 8, 32, 128, 16, 2, 2, 0, 1>(p, stream); return 0;   // 256 px x 128 co, fused-GroupNorm variant
       case 1: launch_conv_t<9, 1, 4, 32, 64, 32, 4, 1>(p, stream); return 0;
       case 2: launch_conv_t<9, 1, 8, 8, 64, 16, 2, 1>(p, stream); return 0;
       case 3: launch_conv_t<9, 1, 16, 32, 128, 16, 4, 2, 1>(p, stream); return 0;   // 512 px x 128 co, 8 waves, swizzled double-buffered LDS tiles
       case 4: launch_conv_t<9, 1, 8, 32, 32, 16, 4, 1, 0, 1>(p, stream); return 0;   // 256 px x 32 co: thin-output convs (conv_out), fused GroupNorm
+      case 5: launch_conv_t<9, 1, 8, 32, 64, 16, 2, 2, 0, 1>(p, stream); return 0;   // 256 px x 64 co: 3 blocks per CU, for layers with few tiles; fused GroupNorm
     }
   } else if (ntaps == 9 && stride == 2) {
     switch (cfg) {
@@ -236,6 +266,9 @@ struct ConvL {
   int stage = 0, split = 0, w_exp = 0;
   size_t wlo_off = 0;
   half_t* w_lo = nullptr;
+  // 3x3 layers wide enough for the 256x128 tile also keep their weights in the stage order of the DMA-weight kernels
+  size_t wdma_off = 0, wdma_bytes = 0;
+  half_t* w_dma = nullptr;
 };
 static const int kSplitWeightExp = 8;      // pre-scale 2^8: typical |w| ~ 1e-2 .. 1 -> low parts ~ 1e-3 .. 1e-1 * 2^-4: fp16-normal
 struct NormL {
@@ -395,6 +428,10 @@ struct Builder {
     L.stage = stage;
     L.split = (e->cfg.precise_mask & stage) ? 1 : 0;
     if (L.split) { L.w_exp = kSplitWeightExp; L.wlo_off = woff; woff += rupz((size_t)L.Cin_pad * ntaps * L.Cout_pad * 2, 256); }
+    if (ntaps == 9 && L.Cout_pad >= 128 && !geglu) {
+      L.wdma_bytes = (size_t)L.Cin_pad * 9 * L.Cout_pad * 2 * (L.split ? 2 : 1);
+      L.wdma_off = woff; woff += rupz(L.wdma_bytes, 256);
+    }
     e->convs.push_back(L);
     return (int)e->convs.size() - 1;
   }
@@ -724,7 +761,7 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
   int cfg = a.force_cfg >= 0 ? a.force_cfg : conv_pick_cfg(L.ntaps, a.stride, p);
   if (cfg < 0 || cfg >= conv_num_cfgs(L.ntaps, a.stride) || !conv_cfg_ok(conv_cfg_table(L.ntaps, a.stride)[cfg], p))
     SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: no tile configuration for Cin=%d+%d (cfg %d)", L.name.c_str(), p.C0, p.C1, cfg);
-  if (a.gn_scale && !(L.ntaps == 9 && a.stride == 1 && (cfg == 0 || cfg == 4) && p.C0 + p.C1 <= 1024))
+  if (a.gn_scale && !(L.ntaps == 9 && a.stride == 1 && (cfg == 0 || cfg == 4 || cfg == 5) && p.C0 + p.C1 <= 1024))
     SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: fused GroupNorm requested for an unsupported tile configuration", L.name.c_str());
   if (a.out->want_stats) {
     if (L.geglu || a.out_ch_off || p.out_f32 == 2) SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: fused statistics unsupported with this epilogue", L.name.c_str());
@@ -736,6 +773,9 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
     a.out->soff = sb.off; a.out->sbytes = sb.bytes; a.out->stats = (float*)sb.p;
     p.stats = a.out->stats;
   }
+  // weights by LDS-DMA (256x128 tile, 3x3 stride 1): the layer keeps a stage-ordered copy of its weights for that kernel
+  static const bool dma_off = getenv("SDM_CONV_DMA") && getenv("SDM_CONV_DMA")[0] == '0';      // A/B hook
+  if (!dma_off && L.ntaps == 9 && a.stride == 1 && cfg == 0 && L.w_dma && (!L.split || p.in_f32)) p.w_dma = L.w_dma;
   if (e->dry) return 0;
   const double flops = 2.0 * (double)p.M * L.O * L.I * L.ntaps;
   const double bytes = (double)a.in0->rows() * L.Cin_pad * (p.in_f32 ? 4 : 2) + (double)p.M * p.Cout_valid * (p.out_f32 ? 4 : 2) +
@@ -957,7 +997,7 @@ static bool conv_can_fuse_gn(sdm_ctx* e, const ConvL& L, const T& x, const T* x2
   p.C0 = x.C; p.C1 = x2 ? x2->C : 0; p.in_f32 = x.f32; p.N = x.N; p.Hin = x.H; p.Win = x.W; p.Hout = x.H; p.Wout = x.W; p.Cout_pad = L.Cout_pad;
   p.M = x.rows();
   const int cfg = conv_pick_cfg(9, 1, p);
-  return cfg == 0 || cfg == 4;        // the two 256-pixel tiles that carry the fused-GroupNorm variant
+  return cfg == 0 || cfg == 4 || cfg == 5;        // the 256-pixel tiles that carry the fused-GroupNorm variant
   (void)e;
 }
 
@@ -1573,6 +1613,7 @@ int sdm_create(sdm_ctx** out, int device_id, const sdm_config* cfg) {
   for (auto& L : e->convs) {
     L.w = (half_t*)(e->warena + L.w_off); L.b = (float*)(e->warena + L.b_off);
     if (L.split) L.w_lo = (half_t*)(e->warena + L.wlo_off);
+    if (L.wdma_bytes) L.w_dma = (half_t*)(e->warena + L.wdma_off);
   }
   for (auto& n : e->norms) { n.g = (float*)(e->warena + n.g_off); n.b = (float*)(e->warena + n.b_off); }
   for (auto& t : e->tembs) {
@@ -1678,6 +1719,11 @@ int sdm_load_tensor(sdm_ctx* e, const char* name, int dtype, int ndim, const int
       SDM_LAUNCH(pack_conv_weight_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 65535)), dim3(256), 0, e->stream,
                  (const float*)dsrc, L.w, O, I, L.ntaps, L.Cin_pad, L.Cout_pad, s.ci_off, s.co_off, L.geglu,
                  s.w_scale * ldexpf(1.0f, L.w_exp), L.w_lo);
+      if (L.w_dma) {
+        const size_t tot2 = total * (L.split ? 2 : 1);
+        SDM_LAUNCH(pack_conv_weight_dma_kernel, dim3((unsigned)std::min<size_t>((tot2 + 255) / 256, 65535)), dim3(256), 0, e->stream,
+                   (const float*)dsrc, L.w_dma, O, I, L.Cin_pad, L.Cout_pad, s.ci_off, s.w_scale * ldexpf(1.0f, L.w_exp), L.split ? 2 : 1);
+      }
     } else if (s.kind == SLOT_CONV_B) {
       ConvL& L = e->convs[s.layer];
       SDM_LAUNCH(pack_bias_kernel, dim3(sdm_cdiv(L.Cout_pad, 256)), dim3(256), 0, e->stream, (const float*)dsrc, L.b, (int)s.shape[0],
@@ -1737,6 +1783,9 @@ static int fold_cross_kv(sdm_ctx* e) {
     const size_t total = (size_t)L.Cin_pad * 9 * L.Cout_pad;
     SDM_LAUNCH(pack_conv_weight_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 65535)), dim3(256), 0, e->stream, (const float*)e->stage,
                L.w, 2 * C, 4, 9, L.Cin_pad, L.Cout_pad, 4, 0, 0, ldexpf(1.0f, L.w_exp), L.w_lo);
+    if (L.w_dma)
+      SDM_LAUNCH(pack_conv_weight_dma_kernel, dim3((unsigned)std::min<size_t>((total * (L.split ? 2 : 1) + 255) / 256, 65535)), dim3(256), 0, e->stream,
+                 (const float*)e->stage, L.w_dma, 2 * C, 4, L.Cin_pad, L.Cout_pad, 4, ldexpf(1.0f, L.w_exp), L.split ? 2 : 1);
     SDM_CHECK_DEV(e, dev_sync(e->stream));
     SDM_CHECK_DEV(e, dev_memcpy_h2d(e->stage, bf.data(), bf.size() * 4, e->stream));
     SDM_LAUNCH(pack_bias_kernel, dim3(sdm_cdiv(L.Cout_pad, 256)), dim3(256), 0, e->stream, (const float*)e->stage, L.b, 2 * C, L.Cout_pad, 0, 0);
@@ -1942,6 +1991,14 @@ int sdm_op_conv_ex(sdm_ctx* e, const void* in0, const void* in1, int C0, int C1,
   SDM_LAUNCH(pack_conv_weight_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 65535)), dim3(256), 0, e->stream, w, L.w, O, L.I, ntaps,
              L.Cin_pad, L.Cout_pad, 0, 0, geglu, ldexpf(1.0f, L.w_exp), L.w_lo);
   if (bias) SDM_LAUNCH(pack_bias_kernel, dim3(sdm_cdiv(L.Cout_pad, 256)), dim3(256), 0, e->stream, bias, L.b, O, L.Cout_pad, 0, geglu);
+  void* wd = nullptr;
+  if (ntaps == 9 && L.Cout_pad >= 128 && !geglu) {      // stage-ordered copy for the DMA-weight kernel (tile cfg 0), as in the engine
+    const size_t tot2 = total * (split ? 2 : 1);
+    SDM_CHECK_DEV(e, dev_malloc(&wd, tot2 * 2));
+    L.w_dma = (half_t*)wd;
+    SDM_LAUNCH(pack_conv_weight_dma_kernel, dim3((unsigned)std::min<size_t>((tot2 + 255) / 256, 65535)), dim3(256), 0, e->stream, w, L.w_dma, O, L.I,
+               L.Cin_pad, L.Cout_pad, 0, ldexpf(1.0f, L.w_exp), split ? 2 : 1);
+  }
   int Ho = Hin << up, Wo = Win << up;
   if (stride == 2) { Ho /= 2; Wo /= 2; }
   const int Cst = rup(geglu ? O / 2 : O, 4);   // rows are stored with 4-channel vectors
@@ -1955,9 +2012,9 @@ int sdm_op_conv_ex(sdm_ctx* e, const void* in0, const void* in1, int C0, int C1,
   int rc;
   if (gn_gamma) {
     // GroupNorm(+SiLU) of the input applied inside the conv's operand staging (the production path of every ResBlock conv):
-    // statistics by the stand-alone kernel, scale/shift table, then the fused-GN instantiation of tile cfg 0 / 4
+    // statistics by the stand-alone kernel, scale/shift table, then the fused-GN instantiation of tile cfg 0 / 4 / 5
     if (ntaps != 9 || stride != 1 || up) { dev_free(wp); dev_free(bp); if (wl) dev_free(wl); SDM_FAIL(e, SDM_ERR_INVALID, "sdm_op_conv_ex: fused GroupNorm needs a 3x3 stride-1 conv"); }
-    if (a.force_cfg != 0 && a.force_cfg != 4) a.force_cfg = (L.Cout_pad <= 32) ? 4 : 0;
+    if (a.force_cfg != 0 && a.force_cfg != 4 && a.force_cfg != 5) a.force_cfg = (L.Cout_pad <= 32) ? 4 : 0;
     const int act_prev = e->act_f32;
     rc = run_two_pass(e, [&]() {
       T scratch; float* scale; float* shift;
@@ -1976,6 +2033,7 @@ int sdm_op_conv_ex(sdm_ctx* e, const void* in0, const void* in1, int C0, int C1,
   }
   dev_sync(e->stream);
   dev_free(wp); dev_free(bp); if (wl) dev_free(wl);
+  if (wd) dev_free(wd);
   return rc;
 }
 
@@ -2064,6 +2122,14 @@ float sdm_bench_conv(sdm_ctx* e, int N, int H, int W, int Cin, int Cout, int nta
   p.in0 = in; p.C0 = L.Cin_pad; p.in_f32 = in_f32; p.N = N; p.Hin = H; p.Win = W; p.Hout = Ho; p.Wout = Wo; p.pad_t = p.pad_l = 1;
   p.M = (long)N * Ho * Wo; p.w = L.w; p.bias = L.b; p.Cout_pad = L.Cout_pad; p.out = out; p.Cout_store = L.Cout_pad; p.Cout_valid = L.Cout_pad;
   p.out_scale = 1.f; p.ablate = ablate; p.acc_scale = 1.f;
+  void* wdm = nullptr;
+  static const bool bench_dma_off = getenv("SDM_CONV_DMA") && getenv("SDM_CONV_DMA")[0] == '0';
+  if (!bench_dma_off && ntaps == 9 && stride == 1 && L.Cout_pad >= 128) {
+    const size_t nb = wbytes * (split ? 2 : 1);
+    if (dev_malloc(&wdm, nb)) return -2.f;
+    SDM_LAUNCH(fill_random_f16_kernel, dim3(2048), dim3(256), 0, e->stream, (half_t*)wdm, (long)(nb / 2), 29u, 0.05f);
+    p.w_dma = (const half_t*)wdm;
+  }
   if (split) p.w_lo = (const half_t*)wl;
   if (gnf) { p.gn_scale = (const float*)gnt; p.gn_shift = (const float*)gnt + (size_t)N * L.Cin_pad; p.gn_silu = 1; }
   int cfg = tile_cfg >= 0 ? tile_cfg : conv_pick_cfg(ntaps, stride, p);
@@ -2080,6 +2146,7 @@ float sdm_bench_conv(sdm_ctx* e, int N, int H, int W, int Cin, int Cout, int nta
   dev_free(wp); dev_free(bp); dev_free(in); dev_free(out);
   if (wl) dev_free(wl);
   if (gnt) dev_free(gnt);
+  if (wdm) dev_free(wdm);
   return ms / (float)iters;
 #endif
 }

@@ -187,7 +187,7 @@ int sdm_op_conv(sdm_ctx* ctx, const void* in0, const void* in1, int C0, int C1, 
 int sdm_conv_num_cfgs(int ntaps, int stride);
 /* The same with (a) split != 0: split-fp16 operands (the precise mode's kernels; fp32 activations only) and (b) gn_gamma != NULL:
  * GroupNorm(gn_groups, eps)(+SiLU) of the input applied inside the conv's operand staging - the production path of every
- * ResnetBlock2D conv (3x3, stride 1; tile_cfg 0 or 4). */
+ * ResnetBlock2D conv (3x3, stride 1; tile_cfg 0, 4 or 5). */
 int sdm_op_conv_ex(sdm_ctx* ctx, const void* in0, const void* in1, int C0, int C1, int in_f32, int N, int Hin, int Win, int up,
                    int stride, int pad_mode, int ntaps, const float* w, const float* bias, int O, void* out, int out_f32,
                    const void* res, int res_f32, int geglu, float out_scale, int tile_cfg, int split, const float* gn_gamma,

@@ -26,10 +26,24 @@ def emu_engine(pkg):
 DEV = "cpu"
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
 def test_conv3x3_s1_all_tile_cfgs(emu_engine, cfg):
     cin = 32 if cfg == 1 else 16
     S.check_conv(emu_engine, DEV, 1, 9, 35, cin, 40, tile_cfg=cfg, seed=cfg)
+
+
+def test_conv3x3_split_precision_and_fused_groupnorm(emu_engine):
+    """Precise-mode kernels (split-fp16 operands, half-plane LDS layout) and the fused GroupNorm+SiLU staging at op level."""
+    for cfg in (0, 5, 2):
+        S.check_conv(emu_engine, DEV, 1, 9, 35, 32, 40, tile_cfg=cfg, in_f32=True, out_f32=True, split=True, res="f32", seed=40 + cfg, atol=2e-5)
+    for cfg in (0, 4, 5):
+        S.check_conv(emu_engine, DEV, 1, 9, 35, 32, 40 if cfg != 4 else 3, tile_cfg=cfg, in_f32=True, out_f32=True, split=True, gn=(1e-6, True),
+                     seed=50 + cfg, atol=2e-5)
+        S.check_conv(emu_engine, DEV, 1, 9, 35, 32, 40 if cfg != 4 else 3, tile_cfg=cfg, in_f32=(cfg != 0), out_f32=True, gn=(1e-5, cfg != 5),
+                     seed=60 + cfg)
+    S.check_conv(emu_engine, DEV, 1, 7, 11, 64, 72, ntaps=1, tile_cfg=4, in_f32=True, out_f32=True, split=True, seed=70, atol=2e-5)      # KC=32 fp32 GEMM tile
+    S.check_conv(emu_engine, DEV, 1, 5, 13, 64, 128, ntaps=1, geglu=True, tile_cfg=1, in_f32=True, out_f32=True, split=True, seed=71, atol=5e-5)
+    S.check_conv(emu_engine, DEV, 2, 5, 13, 64, 96, ntaps=1, tile_cfg=2, in_f32=True, out_f32=True, res="f32", seed=72)                 # batch of 2 (image-aligned row tiles are an engine path; plain here)
 
 
 def test_conv3x3_thin_output_tile(emu_engine):
