@@ -252,6 +252,40 @@ conv_mfma_kernel(ConvParams p) {
       if (IN_F32) a_raw[i][IN_F32 ? 1 : 0] = sdm_buffer_load16(rs, off, 16);
     }
   };
+  // DMAB: the same loads, invisible to the compiler's vmcnt bookkeeping (it would drain the weight DMAs at every use)
+  const sdm_rsrc_raw rq0 = sdm_make_rsrc_raw((const unsigned char*)p.in0 + ((NTAPS == 9) ? (size_t)img * p.Hin * p.Win : (size_t)m0) * p.C0 * es,
+                                             (unsigned int)((size_t)p.Hin * p.Win * p.C0 * es));
+  const sdm_rsrc_raw rq1 = sdm_make_rsrc_raw(p.in1 ? (const unsigned char*)p.in1 + (size_t)img * p.Hin * p.Win * p.C1 * es : (const unsigned char*)p.in0,
+                                             p.in1 ? (unsigned int)((size_t)p.Hin * p.Win * p.C1 * es) : 0u);
+  auto issue_loads_a_asm = [&](int c0) {
+    const bool second = c0 >= p.C0;
+    const sdm_rsrc_raw rq = second ? rq1 : rq0;
+    const unsigned int Cs = (unsigned int)(second ? p.C1 : p.C0) * es;
+    const unsigned int cc = (unsigned int)((second ? c0 - p.C0 : c0) + a_part) * es;
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      const unsigned int off = a_pix[i] >= 0 ? (unsigned int)a_pix[i] * Cs + cc : SDM_BUF_INVALID;
+      if (i == 0) SDM_ASM_BUFFER_LOAD16_FIRST(a_raw[i][0], off, rq, 0);
+      else SDM_ASM_BUFFER_LOAD16(a_raw[i][0], off, rq, 0);
+      if (IN_F32) SDM_ASM_BUFFER_LOAD16(a_raw[i][IN_F32 ? 1 : 0], off, rq, 16);
+    }
+  };
+  // the loads above have landed: stage_end() of the two stages in between waited for everything older than the last two
+  // weight DMAs.  The (free) counted wait names every destination register so that no consumer is scheduled above it.
+  auto a_loads_landed = [&]() {
+#ifndef SDM_EMU
+    static_assert(!DMAB || A_PER <= 3, "register list of the wait statement");
+    if (IN_F32) {
+      if (A_PER == 3) asm volatile("s_waitcnt vmcnt(9)" : "+v"(a_raw[0][0]), "+v"(a_raw[0][IN_F32 ? 1 : 0]), "+v"(a_raw[A_PER > 1 ? 1 : 0][0]),
+                                   "+v"(a_raw[A_PER > 1 ? 1 : 0][IN_F32 ? 1 : 0]), "+v"(a_raw[A_PER > 2 ? 2 : 0][0]), "+v"(a_raw[A_PER > 2 ? 2 : 0][IN_F32 ? 1 : 0]) :: "memory");
+      else asm volatile("s_waitcnt vmcnt(9)" : "+v"(a_raw[0][0]), "+v"(a_raw[0][IN_F32 ? 1 : 0]), "+v"(a_raw[A_PER > 1 ? 1 : 0][0]),
+                        "+v"(a_raw[A_PER > 1 ? 1 : 0][IN_F32 ? 1 : 0]) :: "memory");
+    } else {
+      if (A_PER == 3) asm volatile("s_waitcnt vmcnt(9)" : "+v"(a_raw[0][0]), "+v"(a_raw[A_PER > 1 ? 1 : 0][0]), "+v"(a_raw[A_PER > 2 ? 2 : 0][0]) :: "memory");
+      else asm volatile("s_waitcnt vmcnt(9)" : "+v"(a_raw[0][0]), "+v"(a_raw[A_PER > 1 ? 1 : 0][0]) :: "memory");
+    }
+#endif
+  };
   auto issue_loads_b = [&](int c0, const sdm_rsrc rsb) {
     const unsigned int chunk_row0 = (unsigned int)(c0 / 16) * NTAPS;
 #pragma unroll
@@ -473,8 +507,16 @@ conv_mfma_kernel(ConvParams p) {
     };
     // end of a stage: the NEXT stage's weights (this wave's pieces) have landed, LDS writes of this wave are done, then the barrier.
     // vmcnt is counted: every stage issued after stage s+1 adds 3 DMAs per wave, and only those may still be in flight
-    auto stage_end = [&](int s) {
-      if (s + 3 < nst) SDM_WAIT_VMCNT(6);
+    const bool ab_ald = (p.ablate & 32) != 0, ab_awr = (p.ablate & 64) != 0;      // bench only: skip only the A loads / only the A writes
+    const bool ab_a = (p.ablate & 1) != 0, ab_dma = (p.ablate & 2) != 0, ab_mm = (p.ablate & 4) != 0, ab_bar = (p.ablate & 16) != 0;   // bench only
+    // a_fly: the activation loads of the next chunk were issued after the DMAs of stage s+1 and are not needed yet - they may stay
+    // in flight too (3 loads per thread, 6 for fp32 activations)
+    auto stage_end = [&](int s, bool a_fly) {
+      if (ab_bar) return;
+      if (s + 3 < nst) {
+        if (a_fly) { if (IN_F32) SDM_WAIT_VMCNT(12); else SDM_WAIT_VMCNT(9); }
+        else SDM_WAIT_VMCNT(6);
+      }
       else if (s + 2 < nst) SDM_WAIT_VMCNT(3);
       else SDM_WAIT_VMCNT0();
       SDM_WAIT_LGKMCNT0();
@@ -497,16 +539,19 @@ conv_mfma_kernel(ConvParams p) {
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
           const int s = (c * 3 + dx) * 2;
-          if (dx == 0 && more) issue_loads_a((c + 1) * 16);
-          if (s + 3 < nst) dma_stage(s + 3);
-          sweep(Ahi, Bring + (s & 3) * SLOT, dx);           // A_hi . w_hi
-          sweep(Alo, Bring + (s & 3) * SLOT, dx);           // A_lo . w_hi
-          stage_end(s);
-          if (s + 4 < nst) dma_stage(s + 4);
-          sweep(Ahi, Bring + ((s + 1) & 3) * SLOT, dx);     // A_hi . w_lo
-          stage_end(s + 1);
+          if (dx == 0 && more && !ab_a) issue_loads_a_asm((c + 1) * 16);
+          if (s + 3 < nst && !ab_dma) dma_stage(s + 3);
+          if (!ab_mm) {
+            sweep(Ahi, Bring + (s & 3) * SLOT, dx);           // A_hi . w_hi
+            sweep(Alo, Bring + (s & 3) * SLOT, dx);           // A_lo . w_hi
+          }
+          stage_end(s, dx == 0 && more && !ab_a);
+          if (s + 4 < nst && !ab_dma) dma_stage(s + 4);
+          if (!ab_mm) sweep(Ahi, Bring + ((s + 1) & 3) * SLOT, dx);     // A_hi . w_lo
+          stage_end(s + 1, dx == 0 && more && !ab_a);
         }
-        if (more) {                 // every wave is past the last read of A(c): re-stage the halo tiles for chunk c+1
+        if (more && !ab_a) {        // every wave is past the last read of A(c): re-stage the halo tiles for chunk c+1
+          a_loads_landed();
           write_lds_a(Aring, (c + 1) * 16);
           SDM_WAIT_LGKMCNT0();
           SDM_RAW_BARRIER();
@@ -516,11 +561,13 @@ conv_mfma_kernel(ConvParams p) {
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
           const int s = c * 3 + dx;
-          if (dx == 0 && more) issue_loads_a((c + 1) * 16);
-          if (s + 3 < nst) dma_stage(s + 3);
-          sweep(Acur, Bring + (s & 3) * SLOT, dx);
-          if (dx == 2 && more) write_lds_a(Aring + ((c + 1) & 1) * C::A_BYTES, (c + 1) * 16);   // the other A buffer: last read in chunk c-1
-          stage_end(s);
+          if (dx == 0 && more && !ab_a && !ab_ald) issue_loads_a_asm((c + 1) * 16);
+          if (s + 3 < nst && !ab_dma) dma_stage(s + 3);
+          // next chunk's halo tile into the OTHER A buffer (last read in chunk c-1), BEFORE this stage's sweep: the LDS writes
+          // complete under the 24 MFMAs instead of in front of the barrier (measured: the write tail cost 16 % there)
+          if (dx == 2 && more && !ab_a && !ab_awr) { a_loads_landed(); write_lds_a(Aring + ((c + 1) & 1) * C::A_BYTES, (c + 1) * 16); }
+          if (!ab_mm) sweep(Acur, Bring + (s & 3) * SLOT, dx);
+          stage_end(s, dx < 2 && more && !ab_a && !ab_ald);
         }
       }
     }

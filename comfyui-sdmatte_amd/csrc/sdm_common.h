@@ -83,6 +83,33 @@ __device__ __forceinline__ u32x2 sdm_buffer_load8(sdm_rsrc r, unsigned int voff,
 }
 #endif
 
+// ---- buffer loads hidden from the compiler's s_waitcnt bookkeeping (cdna_hip_programming.md 5.7 form (ii)).  hipcc does not count
+//      LDS-DMA operations in its vmcnt scoreboard, so every wait it emits for one of ITS OWN loads drains the whole DMA queue.  A
+//      kernel that keeps DMAs in flight across barriers issues its register loads through these macros and waits for them with
+//      SDM_ASM_LOADS_WAIT (a counted s_waitcnt that names every destination register, so no consumer can be scheduled above it).
+#ifdef SDM_EMU
+typedef sdm_rsrc sdm_rsrc_raw;
+static inline sdm_rsrc_raw sdm_make_rsrc_raw(const void* p, unsigned int bytes) { return sdm_make_rsrc(p, bytes); }
+#define SDM_ASM_BUFFER_LOAD16(dst, voff, rsrc, imm) (dst) = sdm_buffer_load16((rsrc), (voff), (imm))
+#define SDM_ASM_BUFFER_LOAD16_FIRST(dst, voff, rsrc, imm) (dst) = sdm_buffer_load16((rsrc), (voff), (imm))
+#else
+typedef u32x4 sdm_rsrc_raw;      // the four descriptor words, held in SGPRs
+__device__ __forceinline__ sdm_rsrc_raw sdm_make_rsrc_raw(const void* p, unsigned int bytes) {
+  const unsigned long long a = (unsigned long long)p;
+  sdm_rsrc_raw d;
+  d[0] = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)a);
+  d[1] = (unsigned int)__builtin_amdgcn_readfirstlane((int)((unsigned int)(a >> 32) & 0xFFFFu));      // stride 0
+  d[2] = (unsigned int)__builtin_amdgcn_readfirstlane((int)bytes);
+  d[3] = 0x00020000u;
+  return d;
+}
+#define SDM_ASM_BUFFER_LOAD16(dst, voff, rsrc, imm) \
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:" #imm : "=v"(dst) : "v"(voff), "s"(rsrc) : "memory")
+// first load of a batch: the descriptor SGPRs may have been written by a VALU (v_readfirstlane) just before
+#define SDM_ASM_BUFFER_LOAD16_FIRST(dst, voff, rsrc, imm) \
+  asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen offset:" #imm : "=v"(dst) : "v"(voff), "s"(rsrc) : "memory")
+#endif
+
 // ---- LDS-DMA (global -> LDS without staging registers): every lane supplies its own 16-B source address, the
 //      destination is the wave-uniform `lds_base` + lane*16.  Completion is counted on vmcnt: SDM_WAIT_VMCNT0() then a
 //      barrier orders the data for every reader.  SDM_RAW_BARRIER() is s_barrier without the vmcnt(0) drain that

@@ -428,7 +428,10 @@ struct Builder {
     L.stage = stage;
     L.split = (e->cfg.precise_mask & stage) ? 1 : 0;
     if (L.split) { L.w_exp = kSplitWeightExp; L.wlo_off = woff; woff += rupz((size_t)L.Cin_pad * ntaps * L.Cout_pad * 2, 256); }
-    if (ntaps == 9 && L.Cout_pad >= 128 && !geglu) {
+    // stage-ordered copy for the DMA-weight kernel: split-precision layers only (measured +4..6 % there; neutral with fp16 operands,
+    // where the register-staged kernel stays; SDM_CONV_DMA_ALL=1 builds the copy for every wide 3x3 layer)
+    static const bool dma_all = getenv("SDM_CONV_DMA_ALL") != nullptr;
+    if (ntaps == 9 && L.Cout_pad >= 128 && !geglu && (L.split || dma_all)) {
       L.wdma_bytes = (size_t)L.Cin_pad * 9 * L.Cout_pad * 2 * (L.split ? 2 : 1);
       L.wdma_off = woff; woff += rupz(L.wdma_bytes, 256);
     }

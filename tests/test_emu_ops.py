@@ -46,6 +46,20 @@ def test_conv3x3_split_precision_and_fused_groupnorm(emu_engine):
     S.check_conv(emu_engine, DEV, 2, 5, 13, 64, 96, ntaps=1, tile_cfg=2, in_f32=True, out_f32=True, res="f32", seed=72)                 # batch of 2 (image-aligned row tiles are an engine path; plain here)
 
 
+def test_conv3x3_dma_weight_pipeline(emu_engine):
+    """The DMA-weight kernels (256x128 tile, Cout >= 128: stage-ordered weights through the 4-stage LDS ring, double-buffered /
+    split activation tiles): 1 and several K-chunks, a ragged second output-channel tile, fp16 / fp32 / fused GroupNorm / split
+    precision, nearest-upsample + concat."""
+    S.check_conv(emu_engine, DEV, 1, 9, 35, 16, 128, tile_cfg=0, seed=1)
+    S.check_conv(emu_engine, DEV, 2, 10, 40, 48, 160, tile_cfg=0, res="f32", out_f32=True, seed=2)
+    S.check_conv(emu_engine, DEV, 1, 9, 35, 32, 128, tile_cfg=0, in_f32=True, out_f32=True, seed=3)
+    S.check_conv(emu_engine, DEV, 1, 9, 35, 64, 128, tile_cfg=0, in_f32=True, out_f32=True, gn=(1e-6, True), seed=4)
+    S.check_conv(emu_engine, DEV, 1, 17, 33, 32, 128, tile_cfg=0, in_f32=False, out_f32=True, gn=(1e-6, True), seed=5)
+    S.check_conv(emu_engine, DEV, 1, 9, 35, 16, 128, tile_cfg=0, in_f32=True, out_f32=True, split=True, seed=6, atol=2e-5)
+    S.check_conv(emu_engine, DEV, 1, 9, 35, 96, 160, tile_cfg=0, in_f32=True, out_f32=True, split=True, gn=(1e-6, True), seed=7, atol=2e-5)
+    S.check_conv(emu_engine, DEV, 1, 6, 20, 32, 128, C1=32, up=1, tile_cfg=0, in_f32=True, out_f32=True, split=True, seed=8, atol=2e-5)
+
+
 def test_conv3x3_thin_output_tile(emu_engine):
     S.check_conv(emu_engine, DEV, 2, 10, 33, 32, 3, in_f32=True, tile_cfg=4, seed=9)          # conv_out shape: Cout 3 -> one 32-wide tile
 
