@@ -73,9 +73,14 @@ SDM_DEV_INLINE bool attn_block_coords(const AttnParams& p, int bid, int& b, int&
 
 // PREC = 1 (precise mode): q, k and V^T arrive as fp16 pairs hi + lo and the probabilities are split the same way, every
 // product is evaluated as hi.hi + lo.hi + hi.lo into the same fp32 accumulators (3 MFMAs instead of 1; the lo.lo term is 2^-22).
-template <int QT, int PREC = 0>
-__global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
+// NW = waves per block (4 or 8), 32 queries per wave: the 8-wave block shares every K / V^T tile among 256 queries - half the
+// L2 / Infinity-Cache traffic and half the LDS staging work per MFMA of the 4-wave block (K | V of one head in hi | lo planes is
+// 8.4 MB at 16384 keys: it does not fit the 4 MB L2 of an XCD, and 128-query blocks streamed it at ~5 TB/s) - at the same 2
+// waves per SIMD; used when it still yields at least one block per CU.
+template <int QT, int PREC = 0, int NW = 4>
+__global__ void __launch_bounds__(64 * NW, 2) attn_d64_kernel(AttnParams p) {
   static_assert(!PREC || QT == 1, "the split-precision variant keeps one 32-query tile per wave");
+  constexpr int NTH = 64 * NW, VPT = 512 / NTH;                  // threads, 16-byte vectors per thread and tile (K and V^T: 512 each)
   SDM_DYN_SMEM(smem);
   constexpr int PK = ATTN64_PK, PV = ATTN64_PV;
   constexpr int BUF = PREC ? ATTN64P_BUF : ATTN64_BUF;
@@ -87,7 +92,7 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
   const int hi = lane >> 5, l31 = lane & 31;
   int b, head, qblk;
   if (!attn_block_coords(p, blockIdx.x, b, head, qblk)) return;     // padding block of the XCD-aware grid
-  const int q0 = qblk * (128 * QT) + wave * (32 * QT);
+  const int q0 = qblk * (32 * NW * QT) + wave * (32 * QT);
 
   f16x8 qf[QT][4], qfl[PREC ? QT : 1][4];
 #pragma unroll
@@ -142,7 +147,7 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
   const float* bbase = p.bias ? p.bias + (size_t)b * p.bias_bs : nullptr;
   const int ntiles = (p.Lk + 63) / 64;
 
-  f16x8 kreg[2], vreg[2], kregl[PREC ? 2 : 1], vregl[PREC ? 2 : 1];
+  f16x8 kreg[VPT], vreg[VPT], kregl[PREC ? VPT : 1], vregl[PREC ? VPT : 1];
   float breg = 0.0f;
   bool binr = true;
   // without a bias the load still happens (from the K tensor: >= Lk readable floats) and its value is discarded by a select
@@ -152,8 +157,8 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
   auto prefetch = [&](int t) {
     const int k0 = t * 64;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int v = tid + i * 256;
+    for (int i = 0; i < VPT; ++i) {
+      const int v = tid + i * NTH;
       const int row = v >> 3, part = v & 7;
       int kr = k0 + row;
       if (kr > p.Lk - 1) kr = p.Lk - 1;
@@ -175,8 +180,8 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
   auto stage = [&](int buf) {
     unsigned char* base = smem + buf * BUF;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int v = tid + i * 256;
+    for (int i = 0; i < VPT; ++i) {
+      const int v = tid + i * NTH;
       const int row = v >> 3, part = v & 7;
       *(f16x8*)(base + row * PK + part * 16) = kreg[i];
       // V^T rows are only 8-byte aligned (pitch 136): two ds_write_b64
@@ -272,6 +277,10 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
     }
     }
 
+    // next tile into the OTHER LDS buffer (nobody reads it during this iteration) - before the P.V MFMAs when early_stage is set, so
+    // that the LDS writes complete under them instead of in front of the barrier
+    const bool early_stage = (p.ablate & 32) == 0;
+    if (early_stage && t + 1 < nwalk) stage((t + 1) & 1);
     // O^T[d][q] += V^T[d][key] . P^T[key][q]
     if (!(p.ablate & 2)) {
 #pragma unroll
@@ -313,7 +322,7 @@ __global__ void __launch_bounds__(256, 2) attn_d64_kernel(AttnParams p) {
         }
       }
     }
-    if (t + 1 < nwalk) stage((t + 1) & 1);      // the other buffer: nobody reads it during this iteration
+    if (!early_stage && t + 1 < nwalk) stage((t + 1) & 1);
     __syncthreads();
   }
 

@@ -949,16 +949,22 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
     }
     if (D == 64) {
       prof_begin(e, "attn_d64", flops, bytes, adesc);
-      const int qrows = 128;          // 4 waves x 32 queries (a 64-queries-per-wave variant was measured slower and spilled: removed)
+      // 8-wave blocks (256 queries share every K / V^T tile: half the L2 / Infinity-Cache traffic and LDS staging per MFMA) only
+      // where they measured faster: the split-precision variant with >= 4 such blocks per CU (B=4 h=5 L=16384: 4.01 vs 4.25 ms;
+      // h=10 Lq=4096: 2.39 vs 2.24 ms, i.e. slower; the fp16 variant is neutral to -10 %) - profiles/r02_ablate_attn_nw8.txt
+      static const char* force_nw = getenv("SDM_ATTN_NW");          // A/B hook: "4" or "8"
+      const bool nw8 = force_nw ? (force_nw[0] == '8') : (ap.prec && (long)B * heads * sdm_cdiv(Lq, 256) >= 1024);
+      const int qrows = nw8 ? 256 : 128;
       p.batch = B; p.heads = heads; p.nq_blocks = sdm_cdiv(Lq, qrows); p.q_chunks = 8;     // B*heads*8 units: always a multiple of 8
       const int qb = sdm_cdiv(p.nq_blocks, p.q_chunks);
       const unsigned nblk = (unsigned)(B * heads * p.q_chunks * qb);                         // 1-D grid, XCD-aware mapping in the kernel
       if (ap.prec) {
-        auto kp = attn_d64_kernel<1, 1>;
-        SDM_SET_SMEM(kp, ATTN64P_SMEM);
-        SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(256), ATTN64P_SMEM, e->stream, p);
+        if (nw8) { auto kp = attn_d64_kernel<1, 1, 8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(512), ATTN64P_SMEM, e->stream, p); }
+        else { auto kp = attn_d64_kernel<1, 1, 4>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(256), ATTN64P_SMEM, e->stream, p); }
+      } else {
+        if (nw8) { auto kf = attn_d64_kernel<1, 0, 8>; SDM_SET_SMEM(kf, 160 * 1024); SDM_LAUNCH(kf, dim3(nblk, 1, 1), dim3(512), ATTN64P_SMEM, e->stream, p); }
+        else { SDM_LAUNCH((attn_d64_kernel<1, 0, 4>), dim3(nblk, 1, 1), dim3(256), ATTN64_SMEM, e->stream, p); }
       }
-      else { SDM_LAUNCH(attn_d64_kernel<1>, dim3(nblk, 1, 1), dim3(256), ATTN64_SMEM, e->stream, p); }
       prof_end(e);
     } else {
       prof_begin(e, "attn_d512", flops, bytes);
@@ -2162,9 +2168,15 @@ float sdm_bench_attn(sdm_ctx* e, int B, int heads, int Lq, int Lk, int qt, int a
   return -1.f;
 #else
   const int C = heads * 64, ldvt = rup(Lk, 64);
+  const int prec = (qt & 2) ? 1 : 0, nw8 = (qt & 4) ? 1 : 0;          // qt bits: 2 = split-precision variant (hi | lo planes, fp32 output), 4 = 8-wave blocks
   void *q = nullptr, *k = nullptr, *vt = nullptr, *o = nullptr;
-  if (dev_malloc(&q, (size_t)B * Lq * C * 2) || dev_malloc(&k, (size_t)B * Lk * C * 2) || dev_malloc(&vt, (size_t)B * heads * 64 * ldvt * 2) ||
-      dev_malloc(&o, (size_t)B * Lq * C * 2)) return -2.f;
+  if (dev_malloc(&q, (size_t)B * Lq * C * 2 * (1 + prec)) || dev_malloc(&k, (size_t)B * Lk * C * 2 * (1 + prec)) ||
+      dev_malloc(&vt, (size_t)B * heads * 64 * ldvt * 2 * (1 + prec)) || dev_malloc(&o, (size_t)B * Lq * C * (prec ? 4 : 2))) return -2.f;
+  if (prec) {
+    SDM_LAUNCH(fill_random_f16_kernel, dim3(4096), dim3(256), 0, e->stream, (half_t*)q + (size_t)B * Lq * C, (long)B * Lq * C, 13u, 0.0003f);
+    SDM_LAUNCH(fill_random_f16_kernel, dim3(4096), dim3(256), 0, e->stream, (half_t*)k + (size_t)B * Lk * C, (long)B * Lk * C, 17u, 0.0003f);
+    SDM_LAUNCH(fill_random_f16_kernel, dim3(4096), dim3(256), 0, e->stream, (half_t*)vt + (size_t)B * heads * 64 * ldvt, (long)B * heads * 64 * ldvt, 19u, 0.0003f);
+  }
   SDM_LAUNCH(fill_random_f16_kernel, dim3(4096), dim3(256), 0, e->stream, (half_t*)q, (long)B * Lq * C, 3u, 1.0f);
   SDM_LAUNCH(fill_random_f16_kernel, dim3(4096), dim3(256), 0, e->stream, (half_t*)k, (long)B * Lk * C, 7u, 1.0f);
   SDM_LAUNCH(fill_random_f16_kernel, dim3(4096), dim3(256), 0, e->stream, (half_t*)vt, (long)B * heads * 64 * ldvt, 11u, 1.0f);
@@ -2173,14 +2185,17 @@ float sdm_bench_attn(sdm_ctx* e, int B, int heads, int Lq, int Lk, int qt, int a
   p.q = (const half_t*)q; p.q_bs = (long)Lq * C; p.ldq = C; p.k = (const half_t*)k; p.k_bs = (long)Lk * C; p.ldk = C;
   p.vt = (const half_t*)vt; p.vt_hs = (long)64 * ldvt; p.vt_bs = heads * p.vt_hs; p.ldvt = ldvt; p.o = (half_t*)o; p.o_bs = (long)Lq * C; p.ldo = C;
   p.Lq = Lq; p.Lk = Lk; p.scale_log2e = 0.125f * SDM_LOG2E; p.ablate = ablate;
-  (void)qt;
-  p.batch = B; p.heads = heads; p.nq_blocks = sdm_cdiv(Lq, 128); p.q_chunks = 8;
+  if (prec) { p.q_lo = (long)B * Lq * C; p.k_lo = (long)B * Lk * C; p.vt_lo = (long)B * p.vt_bs; p.o_f32 = 1; }
+  p.batch = B; p.heads = heads; p.nq_blocks = sdm_cdiv(Lq, nw8 ? 256 : 128); p.q_chunks = 8;
   const unsigned nblk = (unsigned)(B * heads * p.q_chunks * sdm_cdiv(p.nq_blocks, p.q_chunks));
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   for (int i = 0; i <= iters; ++i) {
     if (i == 1) (void)hipEventRecord(e0, (hipStream_t)e->stream);
-    SDM_LAUNCH(attn_d64_kernel<1>, dim3(nblk), dim3(256), ATTN64_SMEM, e->stream, p);
+    if (prec && nw8) { auto kp = attn_d64_kernel<1, 1, 8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk), dim3(512), ATTN64P_SMEM, e->stream, p); }
+    else if (prec) { auto kp = attn_d64_kernel<1, 1, 4>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk), dim3(256), ATTN64P_SMEM, e->stream, p); }
+    else if (nw8) { auto kf = attn_d64_kernel<1, 0, 8>; SDM_SET_SMEM(kf, 160 * 1024); SDM_LAUNCH(kf, dim3(nblk), dim3(512), ATTN64P_SMEM, e->stream, p); }
+    else { SDM_LAUNCH((attn_d64_kernel<1, 0, 4>), dim3(nblk), dim3(256), ATTN64_SMEM, e->stream, p); }
   }
   (void)hipEventRecord(e1, (hipStream_t)e->stream);
   (void)hipStreamSynchronize((hipStream_t)e->stream);
