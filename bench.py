@@ -67,11 +67,15 @@ def main():
     ap.add_argument("--precision", type=str, default=None, help="fp16x3 (default: meets the 1e-3 parity bar) or fp16 (fast)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-mode", action="store_true", help="skip timing the non-default precision")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="only warmup + timed steps + the one profiled step (all identical): the run rocprofv3 summaries are taken from")
     ap.add_argument("--cpu-sample-size", type=int, default=512)
     ap.add_argument("--dump-profile", type=str, default=None, help="write the per-launch profile CSV here")
     ap.add_argument("--dense-attention", action="store_true",
                     help="walk every key tile in the trimap-biased self-attention instead of skipping the tiles whose bias underflows the softmax")
     args = ap.parse_args()
+    if args.timed_only:
+        args.no_other_mode = args.no_cpu_baseline = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU, RCCL rendezvous on 127.0.0.1)
@@ -145,7 +149,7 @@ def main():
     if rank == 0:
         # ---- B = 1 latency (BASELINE configs[1] is quoted one image per call) ----
         b1 = None
-        if world == 1:
+        if world == 1 and not args.timed_only:
             a1 = torch.empty(1, S, S, dtype=torch.float32, device=dev)
             i1, t1 = img_d[:1].contiguous(), tri_d[:1].contiguous()
             eng.apply_matte(i1, t1, S, False, out=a1, sync=True)
@@ -159,7 +163,7 @@ def main():
             b1 = {"batch": 1, "ms_per_image": round(ms1, 3), "images_per_s": round(1e3 / ms1, 3)}
         # ---- host-buffer hand-over (PCIe-inclusive; never `value`): pageable host tensors in, host alpha out ----
         incl = None
-        if world == 1:
+        if world == 1 and not args.timed_only:
             ah = torch.empty(B, S, S, dtype=torch.float32)
             eng.apply_matte(img, tri, S, False, out=ah)
             t0 = time.perf_counter()

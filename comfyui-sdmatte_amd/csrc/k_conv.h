@@ -202,6 +202,10 @@ conv_mfma_kernel(ConvParams p) {
   //      32-bit byte offset per load, hardware zero-fill for anything out of range (halo, ragged rows, padded channels). ----
   static_assert(NT % KV == 0 && NT % (2 * BN) == 0, "staging decomposition: one thread keeps one (co, half) for every i");
   const unsigned int es = IN_F32 ? 4u : 2u;
+  // 3x3: the descriptors below start at the first input row this tile's halo can touch and span only the rows it needs, so
+  // the 32-bit byte offsets stay small whatever the size of the image (one fp32 256-channel image at 2048^2 is 4.3 GB)
+  const int band0 = (NTAPS == 9) ? ((oy0 * STRIDE - p.pad_t) > 0 ? ((oy0 * STRIDE - p.pad_t) >> p.up) : 0) : 0;
+  const int band_rows = (NTAPS == 9) ? ((p.Hin - band0) < (C::HPH + 1) ? (p.Hin - band0) : (C::HPH + 1)) : 0;
   const int a_part = (tid % KV) * 8;                 // channel offset inside the chunk (same for every i)
   const int a_hp0 = tid / KV;                        // halo pixel of vector i: a_hp0 + i*(NT/KV)
   int a_pix[A_PER];                                  // pixel index inside the image / row inside the tile; -1: zero fill
@@ -213,7 +217,7 @@ conv_mfma_kernel(ConvParams p) {
       if (NTAPS == 9) {
         const int hy = hp / HPW, hx = hp % HPW;
         const int iy = oy0 * STRIDE + hy - p.pad_t, ix = ox0 * STRIDE + hx - p.pad_l;
-        if (iy >= 0 && iy < Hl && ix >= 0 && ix < Wl) a_pix[i] = (iy >> p.up) * p.Win + (ix >> p.up);
+        if (iy >= 0 && iy < Hl && ix >= 0 && ix < Wl) a_pix[i] = ((iy >> p.up) - band0) * p.Win + (ix >> p.up);
       } else {
         a_pix[i] = hp;                                // rows beyond M fall outside the descriptor -> 0
       }
@@ -222,7 +226,7 @@ conv_mfma_kernel(ConvParams p) {
   sdm_rsrc rs0, rs1, rsw;
   {
     size_t base_px, npx;
-    if (NTAPS == 9) { base_px = (size_t)img * p.Hin * p.Win; npx = (size_t)p.Hin * p.Win; }
+    if (NTAPS == 9) { base_px = ((size_t)img * p.Hin + band0) * p.Win; npx = (size_t)band_rows * p.Win; }
     else { base_px = (size_t)m0; npx = (size_t)((m_end - m0) < (long)C::BM ? (m_end - m0) : (long)C::BM); }
     rs0 = sdm_make_rsrc((const unsigned char*)p.in0 + base_px * p.C0 * es, (unsigned int)(npx * p.C0 * es));
     rs1 = sdm_make_rsrc(p.in1 ? (const unsigned char*)p.in1 + base_px * p.C1 * es : (const unsigned char*)p.in0, p.in1 ? (unsigned int)(npx * p.C1 * es) : 0u);
@@ -253,10 +257,10 @@ conv_mfma_kernel(ConvParams p) {
     }
   };
   // DMAB: the same loads, invisible to the compiler's vmcnt bookkeeping (it would drain the weight DMAs at every use)
-  const sdm_rsrc_raw rq0 = sdm_make_rsrc_raw((const unsigned char*)p.in0 + ((NTAPS == 9) ? (size_t)img * p.Hin * p.Win : (size_t)m0) * p.C0 * es,
-                                             (unsigned int)((size_t)p.Hin * p.Win * p.C0 * es));
-  const sdm_rsrc_raw rq1 = sdm_make_rsrc_raw(p.in1 ? (const unsigned char*)p.in1 + (size_t)img * p.Hin * p.Win * p.C1 * es : (const unsigned char*)p.in0,
-                                             p.in1 ? (unsigned int)((size_t)p.Hin * p.Win * p.C1 * es) : 0u);
+  const sdm_rsrc_raw rq0 = sdm_make_rsrc_raw((const unsigned char*)p.in0 + ((NTAPS == 9) ? ((size_t)img * p.Hin + band0) * p.Win : (size_t)m0) * p.C0 * es,
+                                             (unsigned int)((size_t)band_rows * p.Win * p.C0 * es));
+  const sdm_rsrc_raw rq1 = sdm_make_rsrc_raw(p.in1 ? (const unsigned char*)p.in1 + ((size_t)img * p.Hin + band0) * p.Win * p.C1 * es : (const unsigned char*)p.in0,
+                                             p.in1 ? (unsigned int)((size_t)band_rows * p.Win * p.C1 * es) : 0u);
   auto issue_loads_a_asm = [&](int c0) {
     const bool second = c0 >= p.C0;
     const sdm_rsrc_raw rq = second ? rq1 : rq0;
@@ -658,8 +662,10 @@ conv_mfma_kernel(ConvParams p) {
     // residual through a per-block buffer descriptor: all loads of a 32-row tile are issued up front, unconditionally
     // (invalid rows/columns get an out-of-range offset -> 0), instead of one dependent global round trip per row pass
     const unsigned int res_es = p.res_f32 ? 4u : 2u;
-    const size_t res_span = (NTAPS == 9) ? (size_t)p.Hout * p.Wout : (size_t)(((m_end - m0) < (long)C::BM) ? (m_end - m0) : (long)C::BM);
-    const sdm_rsrc rsr = sdm_make_rsrc(p.res ? (const unsigned char*)p.res + opix_base * p.res_C * res_es : (const unsigned char*)p.out,
+    const long res_row0 = (NTAPS == 9) ? (long)oy0 * p.Wout : 0L;          // 3x3: descriptor from the tile's first output row (small offsets)
+    const size_t res_span = (NTAPS == 9) ? (size_t)((p.Hout - oy0) < TH ? (p.Hout - oy0) : TH) * p.Wout
+                                         : (size_t)(((m_end - m0) < (long)C::BM) ? (m_end - m0) : (long)C::BM);
+    const sdm_rsrc rsr = sdm_make_rsrc(p.res ? (const unsigned char*)p.res + (opix_base + (size_t)res_row0) * p.res_C * res_es : (const unsigned char*)p.out,
                                        p.res ? (unsigned int)(res_span * p.res_C * res_es) : 0u);
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -669,7 +675,7 @@ conv_mfma_kernel(ConvParams p) {
         for (int pass = 0; pass < NPASS; ++pass) {
           long lp;
           const bool valid = pix_of(i, pass * RPP + lane / LPR, lp);
-          const unsigned int off = (valid && oc < p.Cout_valid) ? (unsigned int)(((size_t)lp * p.res_C + oc) * res_es) : SDM_BUF_INVALID;
+          const unsigned int off = (valid && oc < p.Cout_valid) ? (unsigned int)(((size_t)(lp - res_row0) * p.res_C + oc) * res_es) : SDM_BUF_INVALID;
           if (p.res_f32) {
             rr[pass] = sdm_buffer_load16(rsr, off, 0);
           } else {                                              // fp16 residual: 4 channels = 8 bytes

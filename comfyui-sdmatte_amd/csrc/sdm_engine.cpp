@@ -751,13 +751,11 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
   p.epi = L.geglu; p.out_scale = a.out_scale;
   p.gn_scale = a.gn_scale; p.gn_shift = a.gn_shift; p.gn_silu = a.gn_silu;
   if ((long)a.in0->rows() >= (1L << 31) || p.M >= (1L << 31)) SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: tensor too large for 32-bit pixel indices", L.name.c_str());
-  {   // the kernel addresses one image (3x3) through a buffer descriptor with 32-bit byte offsets: fail loudly beyond 4 GB
-    const size_t es_in = p.in_f32 ? 4 : 2, es_res = p.res_f32 ? 4 : 2;
-    const size_t img_in = (size_t)p.Hin * p.Win * (size_t)std::max(p.C0, p.C1) * es_in;
-    const size_t img_res = a.res ? (size_t)p.Hout * p.Wout * (size_t)p.res_C * es_res : 0;
-    if (L.ntaps == 9 && (img_in >= 0xFFFF0000ull || img_res >= 0xFFFF0000ull))
-      SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: one image of the operand is %zu MB - beyond the 4 GB a buffer descriptor addresses "
-               "(inference sizes above ~1536 need tiling, which is not built)", L.name.c_str(), std::max(img_in, img_res) >> 20);
+  {   // 3x3: per-tile descriptors span only the rows of the tile's halo (k_conv.h band0), so an image may exceed 4 GB; what
+      // stays 32-bit is the byte offset inside that band
+    const size_t es_in = p.in_f32 ? 4 : 2;
+    if (L.ntaps == 9 && (size_t)40 * p.Win * (size_t)std::max(p.C0, p.C1) * es_in >= 0xFFFF0000ull)
+      SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: a %d-pixel-wide row band of the operand exceeds a buffer descriptor", L.name.c_str(), p.Win);
   }
   if (p.C0 + p.C1 != L.Cin_pad) SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: input channels %d+%d != %d", L.name.c_str(), p.C0, p.C1, L.Cin_pad);
   if (a.in1 && a.in1->f32 != a.in0->f32) SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: concat sources differ in dtype", L.name.c_str());
