@@ -350,6 +350,37 @@ def test_e2e_full_model_1024_properties(pkg, monkeypatch):
     eng.close()
 
 
+@pytest.mark.slow
+def test_e2e_full_model_2048_images_beyond_4gb(pkg):
+    """one 2048x2048 image of the fp32 256-channel VAE decoder level is 4.3 GB, beyond what a single buffer
+    descriptor addresses; the 3x3 kernels build their descriptors per tile row band instead.  The fp32 oracle cannot run this size
+    (its attention materialises 65536^2 scores per head), so the default precision is checked against the fp16 engine path, whose
+    fp16 activations stay below 4 GB per image (independent addressing), at the fp16 operand floor - plus range / determinism."""
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    from comfyui_sdmatte_amd.engine import Engine
+    from comfyui_sdmatte_amd.synth import synthetic_inputs
+    from comfyui_sdmatte_amd.weights import synthetic_state_dict
+    cfg = SDMatteConfig.full()
+    w = synthetic_state_dict(cfg, 0)
+    S = 2048
+    img, tri = synthetic_inputs(1, S, S, seed=99)
+    img, tri = img.cuda(), tri.cuda()
+    eng = Engine(cfg, 0)
+    assert not eng.load_state_dict(w)[0]
+    a = eng.apply_matte(img, tri, S, False).cpu()
+    ms = eng.last_forward_ms()
+    assert a.shape == (1, S, S) and torch.isfinite(a).all() and a.min() >= 0.0 and a.max() <= 1.0 and a.std() > 1e-3
+    assert torch.equal(eng.apply_matte(img, tri, S, False).cpu(), a)
+    eng.close()
+    fast = Engine(cfg, 0, precision="fp16")
+    assert not fast.load_state_dict(w)[0]
+    f = fast.apply_matte(img, tri, S, False).cpu()
+    fast.close()
+    d = (a - f).abs()
+    print(f"\n[full 2048 fp16x3 vs fp16] max|d|={d.max():.3e} mean|d|={d.mean():.3e}  fp16x3 forward {ms:.0f} ms")
+    assert d.max().item() <= 1.5e-2 and d.mean().item() <= 1.5e-3          # fp16 operand floor (3.6e-3 max at 1024^2), not the parity bar
+
+
 def test_e2e_config5_mixed_resolution_stream_matted_rgba(pkg):
     """BASELINE config #5 on one GPU: a request stream cycling inference sizes 512 / 768 / 1024 through parallel.matte_stream
     (bucketing by size, equal-shape micro-batches) and the node's matted_rgba composition, vs the oracle (tiny architecture so

@@ -163,3 +163,27 @@ def test_attention_matches_reference_scores_fixture(eng, golden_dir):
         ref = tok(torch.from_numpy(g[key]))
         # fp16 operands vs the reference's fp32 q/k/v: 5e-3 on O(1) outputs
         assert (out.float().cpu() - ref).abs().max().item() < 5e-3
+
+
+@pytest.mark.slow
+def test_conv3x3_operand_image_beyond_4gb_matches_row_band_crops(eng):
+    """One NHWC fp32 image of 256 channels at 2048x2048 is 4.29 GB: more than a buffer descriptor spans.  The kernel's per-tile
+    row-band descriptors must give what the same conv gives on small crops (rows a-1 .. b+1) of the tensor, up to the fp32
+    summation order (the crop may select another tile shape): 2e-5 on O(10) outputs, where a mis-addressed row would be O(1).
+    The crops exercise the first rows, the 4 GB crossing and the last rows."""
+    torch.manual_seed(5)
+    H = W = 2048
+    x = torch.empty(1, H, W, 256, dtype=torch.float32, device="cuda").normal_()
+    assert x.numel() * 4 >= (1 << 32)
+    w = (torch.randn(128, 256, 3, 3) / 48.0).cuda()
+    b = torch.randn(128).cuda()
+    res = torch.empty(1, H, W, 128, dtype=torch.float32, device="cuda").normal_()
+    for split in (True, False):
+        y = eng.op_conv(x, w, b, res=res, out_f32=True, split=split)
+        for (ra, rb) in ((0, 16), (2040, 2048), (1016, 1040), (2047 - 16, 2047)):
+            lo, hi = max(0, ra - 1), min(H, rb + 1)
+            yc = eng.op_conv(x[:, lo:hi].contiguous(), w, b, res=res[:, lo:hi].contiguous(), out_f32=True, split=split)
+            got, want = y[:, ra:rb], yc[:, ra - lo:rb - lo]
+            tol = 2e-5
+            assert (got - want).abs().max().item() <= tol, f"split={split} rows {ra}..{rb}: max|d|={(got - want).abs().max().item():.3e}"
+        del y
