@@ -198,6 +198,30 @@ def test_e2e_pre_post_match_reference_fixture(pkg, golden_dir):
     eng.close()
 
 
+def test_gpu_node_tail_bit_exact_all_fixture_cases(pkg, golden_dir):
+    """sdm_apply_matte_node (forward + mask_refine + composition in one C-ABI call, all on the device) for EVERY (output mode,
+    refine, constraint) case of fixture G1: same bits as `refine_and_compose` (pinned bit-exactly to the reference node's output in
+    tests/test_node_cpu.py) applied on the CPU to the engine's own alpha."""
+    import numpy as np
+    from comfyui_sdmatte_amd.engine import Engine
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    from comfyui_sdmatte_amd.weights import synthetic_state_dict
+    from comfyui_sdmatte_amd.sdmatte_nodes import refine_and_compose
+    g = np.load(os.path.join(golden_dir, "g1_node_prepost.npz"))
+    image, tri = torch.from_numpy(g["image"]), torch.from_numpy(g["trimap"])
+    cfg = SDMatteConfig.tiny()
+    eng = Engine(cfg, 0)
+    eng.load_state_dict(synthetic_state_dict(cfg, 0))
+    raw = eng.apply_matte(image, tri, 64)
+    for tag in g["cases"]:
+        mode, refine, c = str(tag).split("__")
+        for (im, tr) in ((image, tri), (image.cuda(), tri.cuda())):          # host buffers and device buffers
+            a, m = eng.apply_matte_node(im, tr, 64, False, mode, refine == "refine1", int(c[1:]) / 10.0)
+            wa, wm = refine_and_compose(raw.clone(), image, tri, mode, refine == "refine1", int(c[1:]) / 10.0)
+            assert torch.equal(a.cpu(), wa) and torch.equal(m.cpu(), wm), str(tag)
+    eng.close()
+
+
 def test_weight_blob_roundtrip_and_rccl_path(pkg):
     """Multi-GPU plumbing on ONE device: (1) export the packed weight blob from one engine and import it into a second one ->
     bit-identical alphas (what every non-zero rank does after the RCCL broadcast); (2) the torch.distributed 'nccl' (= RCCL)
