@@ -58,6 +58,9 @@ struct ConvParams {
   const float* gn_scale;                // GN template arg: fused GroupNorm apply on load: x*scale[n][c] + shift[n][c] (+SiLU),
   const float* gn_shift;                // [N][C0+C1] fp32 each (from gn_finalize_*); the table of this image sits in LDS
   int gn_silu;
+  int pc;                               // DMAB + SPLIT: 1 = producer / consumer form (8 waves, one block per CU), set by the launcher
+  int f8;                               // 1: w_dma holds the fp8-residual layout (pack_conv_weight_f8_kernel) -> F8 kernel
+  int f8_sa, f8_sb;                     // E8M0 exponents (byte 0) of the fp8 MFMA operand scales: 2^(sa-127) * 2^(sb-127) maps the residual sums to accumulator units
   int ablate;                           // debug/bench only (sdm_bench_conv): 1 skip global loads, 2 skip LDS writes, 4 skip MFMA,
                                         // 8 skip the epilogue stores -- after the first K-chunk; always 0 in the engine
   int tiles_m, tiles_n, xcd_chunk;      // 1-D XCD-aware grid (set by launch_conv_t): M tiles per image (9 taps) or in total (1 tap), N tiles, M tiles per XCD
@@ -66,9 +69,10 @@ struct ConvParams {
                                         // layer (reduced by gn_partials_scale_shift_kernel); NTAPS==9 or one image per launch
 };
 
-template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN, int DB = 0, int SPLIT = 0, int DMAB = 0>
+template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN, int DB = 0, int SPLIT = 0, int DMAB = 0, int PC = 0, int F8 = 0>
 struct ConvCfg {
-  static constexpr int NTHREADS = 64 * WM * WN;
+  static constexpr int NTHREADS = 64 * WM * WN;                 // threads of one role (PC: consumers = producers = NTHREADS)
+  static constexpr int LAUNCH_THREADS = NTHREADS * (PC ? 2 : 1);
   static constexpr int BM = TH * TW;
   static constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 32, NTL = WTN / 32;
   static constexpr int HPH = (NTAPS == 9) ? (TH - 1) * STRIDE + 3 : TH;
@@ -91,15 +95,17 @@ struct ConvCfg {
   static constexpr int STG_BYTES = WM * WN * 32 * WTN * 4;
   // DMAB (weights by LDS-DMA): two A tiles (fp16: double buffer; SPLIT: hi | lo) + a ring of 4 weight stages, one stage = the 3 taps
   // of one kernel column dx for BN output channels in half-plane layout (2 x 3 x BN rows of 16 B)
-  static constexpr int DMA_SLOT = 96 * BN, DMA_SLOTS = 4;
-  static constexpr int TILE_BYTES = DMAB ? 2 * A_BYTES + DMA_SLOTS * DMA_SLOT
+  static constexpr int DMA_SLOT = 96 * BN, DMA_SLOTS = F8 ? 6 : (PC ? 5 : 4);      // PC: weights land TWO stages ahead of their use (fragment prefetch across the barrier)
+  static constexpr int TILE_BYTES = DMAB ? (PC ? 4 : 2) * A_BYTES + DMA_SLOTS * DMA_SLOT
                                          : (SPLIT ? 2 : 1) * A_BYTES + B_BYTES;   // one K-chunk of A halo (SPLIT: high and low parts) + B taps
   static constexpr int SMEM = ((DB ? 2 : 1) * TILE_BYTES) > STG_BYTES ? ((DB ? 2 : 1) * TILE_BYTES) : STG_BYTES;
   static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of 32x32");
   static_assert(KC % 16 == 0, "KC multiple of the MFMA K (16)");
   static_assert(!DB || KC == 16, "swizzled double-buffered tiles assume 2 halves per row");
   static_assert(!(DB && SPLIT), "the split-operand kernels use the single-buffered tile");
-  static_assert(!DMAB || (NTAPS == 9 && STRIDE == 1 && TW == 32 && KC == 16 && BN == 128 && WM * WN == 4 && !DB), "DMA-weight pipeline: 256 x 128 tile only");
+  static_assert(!DMAB || (NTAPS == 9 && STRIDE == 1 && TW == 32 && (KC == 16 || (F8 && KC == 32)) && BN == 128 && WM * WN == 4 && !DB), "DMA-weight pipeline: 256 x 128 tile only");
+  static_assert(!F8 || (PC && KC == 32), "fp8-residual form: producer / consumer kernel on 32-channel chunks");
+  static_assert(!PC || (DMAB && SPLIT), "producer/consumer form: split-precision DMA-weight kernel only");
 };
 
 // SPLIT = 1 ("precise" mode): every operand enters the MFMAs as a pair of fp16 values hi + lo (22 significant
@@ -115,12 +121,27 @@ struct ConvCfg {
 // (24 MFMAs per wave, vertical A-fragment reuse as before), ONE raw s_barrier per stage with a counted vmcnt, so DMAs stay in
 // flight across barriers.  fp16-operand kernels double-buffer the activation halo tile in LDS as well (written while the previous
 // chunk is still being multiplied); SPLIT kernels keep A_hi | A_lo single-buffered and re-stage them between two barriers per chunk.
-template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN, int IN_F32, int DB, int GN, int SPLIT = 0, int DMAB = 0>
+//
+// PC = 1 (producer / consumer waves; split-precision DMA-weight kernel): the block has 8 waves.  Waves 0-3 ("consumers", one per
+// SIMD) execute nothing but LDS fragment reads and MFMAs - one such wave per SIMD keeps the matrix pipe as busy as two do
+// (tools/probe/mfma_mix_probe.hip: 666 vs 688 TFLOP/s algorithmic) - and the epilogue; waves 4-7 ("producers") issue the weight
+// DMAs and do the whole activation staging (global loads, GroupNorm / SiLU, hi | lo split, LDS writes) into a DOUBLE-buffered
+// A_hi | A_lo tile, one chunk ahead.  Staging instructions therefore never sit in an MFMA wave's in-order instruction stream;
+// the two roles meet at the one raw barrier per stage.  One block per CU (8 waves at <= 256 registers, 135 KB of LDS).
+//
+// F8 = 1 (PC kernel on 32-channel chunks): the two RESIDUAL terms of the split product, x_lo.w and x.w_lo, are evaluated on OCP
+// fp8 (e4m3) operands by ONE v_mfma_scale_f32_32x32x64_f8f6f4 per tap and 32 channels (K = 64 = [x_lo8 | x8] . [w8 | w_lo8]; twice
+// the fp16 rate and less energy per MAC - the kernel is power-limited, tools/probe/mfma_mix_probe.hip), x_hi.w_hi stays on fp16.
+// A residual term is 2^-11 of the product, so the 2^-4 relative rounding of e4m3 leaves ~2^-15: the alpha error stays ~1e-4
+// (tests/tools/exp_lowprec_residual_terms.py).  The producers write, per halo pixel and 32 channels, 4 x 16 B of fp16 high parts
+// and 2 x 32 B of fp8 (x_lo * 2^13, x * 2^2; clamped to +-448); the weights were packed to match (pack_conv_weight_f8_kernel).
+// The E8M0 operand scales of the MFMA bring both residual terms back to the unit of the fp16 accumulation.
+template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN, int IN_F32, int DB, int GN, int SPLIT = 0, int DMAB = 0, int PC = 0, int F8 = 0>
 // second argument = minimum waves per SIMD: the big 4-wave tiles keep 2 blocks/CU resident (2 waves/SIMD, <= 256 registers)
-__global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BN == 128) ? 2 : (WM * WN == 4 && BN == 64 && KC == 16 && TW == 32) ? 3 : 1)
+__global__ void __launch_bounds__(64 * WM * WN * (PC ? 2 : 1), (WM * WN == 4 && BN == 128) ? 2 : (WM * WN == 4 && BN == 64 && KC == 16 && TW == 32) ? 3 : 1)
 conv_mfma_kernel(ConvParams p) {
   static_assert(!SPLIT || IN_F32, "split operands are produced from fp32 activations");
-  using C = ConvCfg<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN, DB, SPLIT, DMAB>;
+  using C = ConvCfg<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN, DB, SPLIT, DMAB, PC, F8>;
   constexpr int NT = C::NTHREADS, MT = C::MT, NTL = C::NTL, PITCH = C::PITCH, KV = C::KV;
   constexpr int HPW = C::HPW, HP = C::HP, WTM = C::WTM, WTN = C::WTN;
   constexpr int SWZ = C::SWZ, PL = C::PL, ROWB = C::ROWB;
@@ -131,7 +152,9 @@ conv_mfma_kernel(ConvParams p) {
   unsigned char* As = smem;                 // current K-chunk tile (switches between the two halves when DB)
   unsigned char* Bs = smem + (SPLIT ? 2 : 1) * C::A_BYTES;      // SPLIT: A_hi | A_lo | B
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // PC: `tid` / `wave` are the index inside the role (consumers: MFMA tile position; producers: staging decomposition)
+  const int role = PC ? SDM_UNIFORM_I((int)threadIdx.x / NT) : 0;                  // 0: consumer (or everything), 1: producer
+  const int tid = PC ? ((int)threadIdx.x & (NT - 1)) : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   // XCD-aware 1-D grid.  The dispatcher places block id on XCD id % 8 (speed only, never needed for correctness).  XCD x owns
   // the contiguous M-tile range [x*chunk, (x+1)*chunk) and walks it in order, running the tiles_n output-channel tiles of
@@ -173,7 +196,7 @@ conv_mfma_kernel(ConvParams p) {
 
   // fused GroupNorm apply: scale[Cin] | shift[Cin] of this image, behind the A/B tile region
   float* gn_tab = (float*)(smem + (DB ? 2 : 1) * C::TILE_BYTES);
-  if (GN) {
+  if (GN && !F8) {               // F8: no room in LDS - the producers read the 8 scale / shift values of their channels per chunk
     for (int c = tid; c < Cin; c += NT) {
       gn_tab[c] = p.gn_scale[(size_t)img * Cin + c];
       gn_tab[Cin + c] = p.gn_shift[(size_t)img * Cin + c];
@@ -278,7 +301,7 @@ conv_mfma_kernel(ConvParams p) {
   // weight DMAs.  The (free) counted wait names every destination register so that no consumer is scheduled above it.
   auto a_loads_landed = [&]() {
 #ifndef SDM_EMU
-    static_assert(!DMAB || A_PER <= 3, "register list of the wait statement");
+    static_assert(!DMAB || F8 || A_PER <= 3, "register list of the wait statement");
     if (IN_F32) {
       if (A_PER == 3) asm volatile("s_waitcnt vmcnt(9)" : "+v"(a_raw[0][0]), "+v"(a_raw[0][IN_F32 ? 1 : 0]), "+v"(a_raw[A_PER > 1 ? 1 : 0][0]),
                                    "+v"(a_raw[A_PER > 1 ? 1 : 0][IN_F32 ? 1 : 0]), "+v"(a_raw[A_PER > 2 ? 2 : 0][0]), "+v"(a_raw[A_PER > 2 ? 2 : 0][IN_F32 ? 1 : 0]) :: "memory");
@@ -466,15 +489,15 @@ conv_mfma_kernel(ConvParams p) {
   if (DMAB) {
     constexpr int SLOT = C::DMA_SLOT, NPR = SPLIT ? 2 : 1, PLANE = 3 * BN * 16;      // PLANE: one k-half plane of a stage (3 dy x BN rows)
     unsigned char* Aring = smem;
-    unsigned char* Bring = smem + 2 * C::A_BYTES;
+    unsigned char* Bring = smem + (PC ? 4 : 2) * C::A_BYTES;
     const int nchunks = Cin / 16, nst = nchunks * 3 * NPR;
     const sdm_rsrc rsd = sdm_make_rsrc(p.w_dma, (unsigned int)((size_t)Cin * 9 * NPR * p.Cout_pad * 2));
     const int wv = SDM_UNIFORM_I(wave);
     const unsigned int dma_voff = (unsigned int)((n0 + lane) * 16);
     const unsigned int stage_rows = (unsigned int)p.Cout_pad * 16u;                  // bytes of one (k-half, dy) row group
     // 12 pieces of 1 KB per stage: piece q = (k-half, dy, 64-channel half); this wave issues pieces 3*wave .. 3*wave+2
-    auto dma_stage = [&](int s) {
-      unsigned char* dst = Bring + (s & 3) * SLOT;
+    auto dma_stage_sl = [&](int s, int sl) {
+      unsigned char* dst = Bring + sl * SLOT;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const int q = wv * 3 + k, half = q / 6, dy = (q >> 1) % 3, ch = q & 1;
@@ -482,6 +505,7 @@ conv_mfma_kernel(ConvParams p) {
         sdm_glds16_buf(rsd, dma_voff + (unsigned int)(ch * 1024), row * stage_rows, dst + half * PLANE + dy * (BN * 16) + ch * 1024);
       }
     };
+    auto dma_stage = [&](int s) { dma_stage_sl(s, s & 3); };
     int bq[NTL];
 #pragma unroll
     for (int j = 0; j < NTL; ++j) bq[j] = (lane >> 5) * PLANE + (wn * WTN + j * 32 + (lane & 31)) * 16;
@@ -526,6 +550,316 @@ conv_mfma_kernel(ConvParams p) {
       SDM_WAIT_LGKMCNT0();
       SDM_RAW_BARRIER();
     };
+    if (F8) {
+      // ---- fp8-residual producer / consumer form.  One STEP = two 12 KB weight units: S1 = w_hi of channels 0-15 | 16-31 (two
+      // fp16 K16 sweeps, 48 MFMAs), S2 = w8 | w_lo8 (one K64 fp8 sweep, 24 MFMAs of twice the duration): equal step lengths, two
+      // barriers per kernel column.  Ring of 3 steps; the DMAs of step t+2 are issued at the start of step t and have landed when
+      // the barrier of step t releases, so the B fragments of step t+1 are read while step t is multiplied. ----
+      constexpr int NR = MT + 2, STEP = 2 * SLOT;
+      constexpr float F8_XS = 4.0f, F8_LS = 4.0f * 2048.0f;           // x8 = e4m3(x * 2^2), x_lo8 = e4m3(x_lo * 2^13)
+      const int nch = Cin / 32, nsteps = nch * 6;
+      auto mod3 = [](int x) { return x >= 6 ? x - 6 : (x >= 3 ? x - 3 : x); };
+      const sdm_rsrc rs8 = sdm_make_rsrc(p.w_dma, (unsigned int)((size_t)Cin * 9 * p.Cout_pad * 4));
+      // 24 pieces of 1 KB per step: piece q = (unit, plane, dy, 64-channel half); this wave issues pieces 6*wave .. 6*wave+5
+      auto dma_step = [&](int t, int sl) {
+        unsigned char* dst = Bring + sl * STEP;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          const int q = wv * 6 + k, ul = q / 12, qq = q % 12, pl = qq / 6, dy = (qq >> 1) % 3, ch = qq & 1;
+          const unsigned int row = (unsigned int)(((t * 2 + ul) * 2 + pl) * 3 + dy);
+          sdm_glds16_buf(rs8, dma_voff + (unsigned int)(ch * 1024), row * stage_rows, dst + ul * SLOT + pl * PLANE + dy * (BN * 16) + ch * 1024);
+        }
+      };
+      f32x4 gq[4];                  // producers, GN: scale[0:4], scale[4:8], shift[0:4], shift[4:8] of this thread's channels in the next chunk
+      auto issue_gn = [&](int c0w) {
+        if (GN) {
+          const float* ts = p.gn_scale + (size_t)img * Cin + c0w + a_part;
+          const float* th = p.gn_shift + (size_t)img * Cin + c0w + a_part;
+          gq[0] = *(const f32x4*)ts; gq[1] = *(const f32x4*)(ts + 4); gq[2] = *(const f32x4*)th; gq[3] = *(const f32x4*)(th + 4);
+        }
+      };
+      // fp32 (after the fused GroupNorm / SiLU) -> fp16 high parts (4 planes of 16-B rows: channel group g of the chunk) and the
+      // fp8 images of x_lo and x (region behind: sub-planes [x_lo8 ch 0-15 | x_lo8 ch 16-31 | x8 ch 0-15 | x8 ch 16-31] of 16-B rows)
+      auto write_lds_a_f8 = [&](unsigned char* Ad, int i0, int i1) {        // vectors i0 .. i1-1 of this thread
+        const int g = a_part >> 3;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+          if (i >= i0 && i < i1 && tid + i * NT < A_VEC) {
+            const f32x4 v0 = __builtin_bit_cast(f32x4, a_raw[i][0]), v1 = __builtin_bit_cast(f32x4, a_raw[i][IN_F32 ? 1 : 0]);
+            const bool inside = a_pix[i] >= 0;
+            f16x8 vh;
+            float xl[8], xx[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float y = e < 4 ? v0[e & 3] : v1[e & 3];
+              if (GN) {
+                y = y * (e < 4 ? gq[0][e & 3] : gq[1][e & 3]) + (e < 4 ? gq[2][e & 3] : gq[3][e & 3]);
+                if (p.gn_silu) y = y * sdm_rcp(1.0f + sdm_exp2(-y * SDM_LOG2E));
+                if (!inside) y = 0.0f;                     // zero padding stays zero AFTER the normalisation
+              }
+              const half_t h = (half_t)y;
+              vh[e] = h;
+              xl[e] = fminf(fmaxf((y - (float)h) * F8_LS, -448.0f), 448.0f);
+              xx[e] = fminf(fmaxf(y * F8_XS, -448.0f), 448.0f);
+            }
+            const int hp = a_hp0 + i * (NT / KV);
+            *(f16x8*)(Ad + g * A_HALF + hp * 16) = vh;
+            int l0 = SDM_CVT_PK_FP8(xl[0], xl[1], 0, false), l1 = SDM_CVT_PK_FP8(xl[4], xl[5], 0, false);
+            l0 = SDM_CVT_PK_FP8(xl[2], xl[3], l0, true); l1 = SDM_CVT_PK_FP8(xl[6], xl[7], l1, true);
+            int x0 = SDM_CVT_PK_FP8(xx[0], xx[1], 0, false), x1 = SDM_CVT_PK_FP8(xx[4], xx[5], 0, false);
+            x0 = SDM_CVT_PK_FP8(xx[2], xx[3], x0, true); x1 = SDM_CVT_PK_FP8(xx[6], xx[7], x1, true);
+            unsigned char* a8 = Ad + C::A_BYTES + (g >> 1) * A_HALF + hp * 16 + (g & 1) * 8;
+            u32x2 wl, wx;
+            wl[0] = (unsigned int)l0; wl[1] = (unsigned int)l1; wx[0] = (unsigned int)x0; wx[1] = (unsigned int)x1;
+            *(u32x2*)a8 = wl;
+            *(u32x2*)(a8 + 2 * A_HALF) = wx;
+          }
+        }
+      };
+      constexpr int AFLY = A_PER * (IN_F32 ? 2 : 1) + (GN ? 4 : 0);      // register loads that may stay in flight behind a step's DMAs
+      static_assert(!F8 || AFLY == 12 || AFLY == 16, "counted wait below");
+      if (role) {
+        dma_step(0, 0);
+        if (1 < nsteps) dma_step(1, 1);
+        issue_loads_a(0);
+        issue_gn(0);
+        write_lds_a_f8(Aring, 0, A_PER);
+        SDM_WAIT_VMCNT0();
+      }
+      SDM_WAIT_LGKMCNT0();
+      SDM_RAW_BARRIER();
+      int cm = 0;                   // (6 * c) % 3 = 0 always: the chunk's first step sits in ring slot 0 (kept for clarity)
+      if (role) {
+        for (int c = 0; c < nch; ++c) {
+          const bool more = c + 1 < nch;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) {                  // step t = 6c + k: (dx = k / 2, S1 | S2)
+            const int t = c * 6 + k;
+            if (t + 2 < nsteps) dma_step(t + 2, mod3(cm + k + 2));
+            SDM_SCHED_FENCE();
+            if (k == 0 && more) {                        // next chunk's activations (and its GroupNorm coefficients): in flight for two steps
+              issue_loads_a((c + 1) * 32);
+              issue_gn((c + 1) * 32);
+              SDM_SCHED_FENCE();
+              if (AFLY == 12) SDM_WAIT_VMCNT(12); else SDM_WAIT_VMCNT(16);
+            } else {
+              // the other A buffer was last read in chunk c-1; the transform (GroupNorm, SiLU, hi / fp8 split) of the next chunk is
+              // spread over the remaining four steps so that no step's barrier waits for it
+              if (k >= 2 && more) {
+                unsigned char* An = Aring + ((c + 1) & 1) * 2 * C::A_BYTES;
+                if (k == 2) write_lds_a_f8(An, 0, 2);
+                else if (k == 3) write_lds_a_f8(An, 2, 4);
+                else if (k == 4) write_lds_a_f8(An, 4, 5);
+                else write_lds_a_f8(An, 5, A_PER);
+              }
+              SDM_WAIT_VMCNT0();
+            }
+            SDM_WAIT_LGKMCNT0();
+            SDM_RAW_BARRIER();
+          }
+        }
+      } else {
+        const int sa8 = p.f8_sa, sb8 = p.f8_sb;
+        f16x8 fbh[2][3][NTL];         // w_hi fragments of the two 16-channel halves
+        i32x8 fb8[3][NTL];            // [w8 | w_lo8] fragments
+        const int a8base = abase[0] - (lane >> 5) * A_HALF + (lane >> 5) * 2 * A_HALF;      // fp8 region: lanes 0-31 read x_lo8, lanes 32-63 x8
+        int bq8[NTL];
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) bq8[j] = (lane >> 5) * SLOT + (wn * WTN + j * 32 + (lane & 31)) * 16;
+        auto ld_bh = [&](int ks, int dy, const unsigned char* Bp) {
+#pragma unroll
+          for (int j = 0; j < NTL; ++j) fbh[ks][dy][j] = *(const f16x8*)(Bp + ks * SLOT + bq[j] + dy * (BN * 16));
+        };
+        auto ld_b8 = [&](int dy, const unsigned char* Bp) {
+#pragma unroll
+          for (int j = 0; j < NTL; ++j) {
+            const i32x4 q0 = *(const i32x4*)(Bp + bq8[j] + dy * (BN * 16)), q1 = *(const i32x4*)(Bp + bq8[j] + PLANE + dy * (BN * 16));
+            fb8[dy][j] = i32x8{q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+          }
+        };
+        auto ld_ah = [&](const unsigned char* Ap, int ks, int r, int dx) { return *(const f16x8*)(Ap + abase[0] + ks * 2 * A_HALF + (r * HPW + dx) * 16); };
+        auto ld_a8 = [&](const unsigned char* Ap, int r, int dx) {
+          const unsigned char* q = Ap + C::A_BYTES + a8base + (r * HPW + dx) * 16;
+          const i32x4 q0 = *(const i32x4*)q, q1 = *(const i32x4*)(q + A_HALF);
+          return i32x8{q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+        };
+        {   // operands of the first step
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy) ld_bh(0, dy, Bring);
+        }
+        for (int c = 0; c < nch; ++c) {
+          const bool more = c + 1 < nch;
+          const unsigned char* Ab = Aring + (c & 1) * 2 * C::A_BYTES;
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            const unsigned char* B1 = Bring + mod3(cm + dx * 2) * STEP;           // S1 of this column
+            const unsigned char* B2 = Bring + mod3(cm + dx * 2 + 1) * STEP;       // S2 of this column
+            // ---- S1: A_hi . w_hi, channels 0-15 then 16-31; the second half's and the fp8 step's B fragments are read underneath ----
+            f16x8 fa[2];
+            fa[0] = ld_ah(Ab, 0, 0, dx);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+              fa[(r + 1) & 1] = (r + 1 < NR) ? ld_ah(Ab, 0, r + 1, dx) : ld_ah(Ab, 1, 0, dx);
+              if (r < 3) ld_bh(1, r, B1);
+              SDM_SCHED_FENCE();
+#pragma unroll
+              for (int dy = 0; dy < 3; ++dy) {
+                const int i = r - dy;
+                if (i >= 0 && i < MT) {
+#pragma unroll
+                  for (int j = 0; j < NTL; ++j) acc[i][j] = SDM_MFMA_32x32x16_F16(fa[r & 1], fbh[0][dy][j], acc[i][j]);
+                }
+              }
+              SDM_SCHED_FENCE();
+            }
+            i32x8 f8a[2];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+              if (r + 1 < NR) fa[(NR + r + 1) & 1] = ld_ah(Ab, 1, r + 1, dx);
+              else f8a[0] = ld_a8(Ab, 0, dx);
+              if (r < 3) ld_b8(r, B2);
+              SDM_SCHED_FENCE();
+#pragma unroll
+              for (int dy = 0; dy < 3; ++dy) {
+                const int i = r - dy;
+                if (i >= 0 && i < MT) {
+#pragma unroll
+                  for (int j = 0; j < NTL; ++j) acc[i][j] = SDM_MFMA_32x32x16_F16(fa[(NR + r) & 1], fbh[1][dy][j], acc[i][j]);
+                }
+              }
+              SDM_SCHED_FENCE();
+            }
+            SDM_RAW_BARRIER();
+            // ---- S2: [x_lo8 | x8] . [w8 | w_lo8]; the w_hi fragments of the next column (or chunk) are read underneath ----
+            const bool last = (dx == 2) && !more;
+            const unsigned char* Bn = Bring + mod3(cm + dx * 2 + 2) * STEP;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+              if (r + 1 < NR) f8a[(r + 1) & 1] = ld_a8(Ab, r + 1, dx);
+              if (r < 3 && !last) ld_bh(0, r, Bn);
+              SDM_SCHED_FENCE();
+#pragma unroll
+              for (int dy = 0; dy < 3; ++dy) {
+                const int i = r - dy;
+                if (i >= 0 && i < MT) {
+#pragma unroll
+                  for (int j = 0; j < NTL; ++j) acc[i][j] = SDM_MFMA_32x32x64_F8(f8a[r & 1], fb8[dy][j], acc[i][j], sa8, sb8);
+                }
+              }
+              SDM_SCHED_FENCE();
+            }
+            SDM_RAW_BARRIER();
+          }
+        }
+      }
+    } else if (PC) {
+      // ---- producer / consumer form: same stages and barriers for both roles, disjoint instruction streams.
+      // Invariant: when the barrier that ends stage t releases, the weights of stage t+2 have landed (ring of 5, DMAs 4 stages
+      // ahead), so a consumer reads the B fragments of stage t+1 WHILE it multiplies stage t and enters every stage with its
+      // operands in registers; stage t's ring slot is overwritten only after barrier t (its fragments were consumed before). ----
+      constexpr int NR = MT + 2;
+      auto mod5 = [](int x) { return x >= 10 ? x - 10 : (x >= 5 ? x - 5 : x); };
+      if (role) {
+        issue_loads_a(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          if (s < nst) dma_stage_sl(s, s);
+      }
+      if (GN) __syncthreads();      // gn_tab filled
+      if (role) {
+        write_lds_a(Aring, 0);
+        SDM_WAIT_VMCNT0();
+      }
+      SDM_WAIT_LGKMCNT0();
+      SDM_RAW_BARRIER();
+      int cm = 0;                   // (6 * c) % 5: ring slot of the chunk's first stage
+      if (role) {
+        auto stage_end_pc = [&](int t, bool a_fly) {
+          if (t + 4 < nst) { if (a_fly) SDM_WAIT_VMCNT(12); else SDM_WAIT_VMCNT(6); }      // everything issued after DMA(t+2) may stay in flight
+          else if (t + 3 < nst) SDM_WAIT_VMCNT(3);
+          else SDM_WAIT_VMCNT0();
+          SDM_WAIT_LGKMCNT0();
+          SDM_RAW_BARRIER();
+        };
+        for (int c = 0; c < nchunks; ++c) {
+          const bool more = c + 1 < nchunks;
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            const int t = c * 6 + dx * 2;
+            if (dx == 0 && more) issue_loads_a_asm((c + 1) * 16);
+            if (t + 4 < nst) dma_stage_sl(t + 4, mod5(cm + dx * 2 + 4));
+            // the other A buffer was last read in chunk c-1: chunk c+1 is transformed, split and written during stage (c, dx=1)
+            if (dx == 1 && more) { a_loads_landed(); write_lds_a(Aring + ((c + 1) & 1) * 2 * C::A_BYTES, (c + 1) * 16); }
+            stage_end_pc(t, dx == 0 && more);
+            if (t + 5 < nst) dma_stage_sl(t + 5, mod5(cm + dx * 2 + 5));
+            stage_end_pc(t + 1, dx == 0 && more);
+          }
+          cm = mod5(cm + 6);
+        }
+      } else {
+        f16x8 fb[2][3][NTL];          // B fragments: [0] the w_hi stage being multiplied / prefetched, [1] the w_lo stage
+        f16x8 ah[NR], al[2];          // A_hi rows of the current kernel column (kept for the w_lo stage); A_lo rows rotate
+        auto ld_b = [&](int set, int dy, const unsigned char* Bp) {
+#pragma unroll
+          for (int j = 0; j < NTL; ++j) fb[set][dy][j] = *(const f16x8*)(Bp + bq[j] + dy * (BN * 16));
+        };
+        auto ld_a = [&](const unsigned char* Ap, int r, int dx) { return *(const f16x8*)(Ap + abase[0] + (r * HPW + dx) * 16); };
+        auto rowmm = [&](const f16x8 a, int set, int r) {
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy) {
+            const int i = r - dy;
+            if (i >= 0 && i < MT) {
+#pragma unroll
+              for (int j = 0; j < NTL; ++j) acc[i][j] = SDM_MFMA_32x32x16_F16(a, fb[set][dy][j], acc[i][j]);
+            }
+          }
+        };
+        {   // operands of the first stage
+          const unsigned char* B0 = Bring;
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy) ld_b(0, dy, B0);
+          ah[0] = ld_a(Aring, 0, 0);
+          al[0] = ld_a(Aring + C::A_BYTES, 0, 0);
+        }
+        for (int c = 0; c < nchunks; ++c) {
+          const bool more = c + 1 < nchunks;
+          const unsigned char* Ahi = Aring + (c & 1) * 2 * C::A_BYTES;
+          const unsigned char* Alo = Ahi + C::A_BYTES;
+          const unsigned char* AhiN = Aring + ((c + 1) & 1) * 2 * C::A_BYTES;
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            // ---- stage (c, dx, w_hi): A_hi . w_hi and A_lo . w_hi, row by row; the next row's fragments and the w_lo
+            //      fragments of this column are read underneath ----
+            const unsigned char* Blo = Bring + mod5(cm + dx * 2 + 1) * SLOT;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+              if (r + 1 < NR) { ah[r + 1] = ld_a(Ahi, r + 1, dx); al[(r + 1) & 1] = ld_a(Alo, r + 1, dx); }
+              if (r < 3) ld_b(1, r, Blo);
+              SDM_SCHED_FENCE();
+              rowmm(ah[r], 0, r);
+              rowmm(al[r & 1], 0, r);
+              SDM_SCHED_FENCE();
+            }
+            SDM_RAW_BARRIER();
+            // ---- stage (c, dx, w_lo): A_hi (registers) . w_lo; the operands of the next w_hi stage are read underneath ----
+            const bool last = (dx == 2) && !more;
+            const unsigned char* Bn = Bring + mod5(cm + dx * 2 + 2) * SLOT;
+            const unsigned char* An = (dx == 2) ? AhiN : Ahi;
+            const int dxn = (dx == 2) ? 0 : dx + 1;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+              if (r < 3 && !last) ld_b(0, r, Bn);
+              SDM_SCHED_FENCE();
+              rowmm(ah[r], 1, r);
+              SDM_SCHED_FENCE();
+              if (r == 2 && !last) { ah[0] = ld_a(An, 0, dxn); al[0] = ld_a(An + C::A_BYTES, 0, dxn); }      // rows 0..2 of ah are free again
+            }
+            SDM_RAW_BARRIER();
+          }
+          cm = mod5(cm + 6);
+        }
+      }
+    } else {
     issue_loads_a(0);
 #pragma unroll
     for (int s = 0; s < 3; ++s)
@@ -575,6 +909,7 @@ conv_mfma_kernel(ConvParams p) {
         }
       }
     }
+    }   // !PC
   } else {
   issue_loads(0);
   if (DB) {                      // double-buffered tiles: chunk 0 is staged up front, ONE barrier per K-chunk afterwards
@@ -631,6 +966,7 @@ conv_mfma_kernel(ConvParams p) {
 
   // ---- epilogue: per-wave PRIVATE fp32 staging tile (32 x WTN) in LDS -> coalesced row stores ----
   if (!DB) __syncthreads();      // all waves are done with the A/B tiles (DB: the loop ended with a barrier)
+  if (PC && role) return;        // the accumulators live in the consumer waves; no block-wide barrier below this line
   float* stg = (float*)smem + wave * (32 * WTN);
   const bool geglu = (p.epi == 1);
   constexpr int LPR = WTN / 4;                    // lanes per output row (linear epilogue: 4 channels per lane)
@@ -867,6 +1203,51 @@ __global__ void pack_conv_weight_dma_kernel(const float* __restrict__ w, half_t*
     const float vs = v * scale;
     const half_t hi = (half_t)vs;
     wd[idx] = part == 0 ? hi : (half_t)(vs - (float)hi);
+  }
+}
+
+// fp8-residual layout of a 3x3 weight (F8 kernels), per 32-channel chunk and kernel column dx four 12 KB-per-128-channels units of
+// [plane][dy][Cout_pad][16 B]:  unit 0 / 1 = fp16 high parts of channels 0-15 / 16-31 (plane = 8-channel half, 8 halfs per row),
+// unit 2 = e4m3(v) (plane = channels 0-15 | 16-31, one byte per channel), unit 3 = e4m3((v - hi) * 2^11), with v = w * scale.
+// Same number of bytes as the hi | lo fp16 pair (4 per weight).  Values beyond +-448 are clamped (v = w * 2^8: |w| > 1.75).
+__global__ void pack_conv_weight_f8_kernel(const float* __restrict__ w, unsigned char* __restrict__ wd, int O, int I, int Cin_pad, int Cout_pad,
+                                           int ci_off, float scale) {
+  const size_t total = (size_t)(Cin_pad / 32) * 3 * 4 * 2 * 3 * Cout_pad;         // 16-byte rows
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    size_t t = idx;
+    const int co = t % Cout_pad; t /= Cout_pad;
+    const int dy = t % 3; t /= 3;
+    const int pl = t % 2; t /= 2;
+    const int u = t % 4; t /= 4;
+    const int dx = t % 3;
+    const int chunk = (int)(t / 3);
+    auto wv = [&](int c) {
+      const int ci = c - ci_off;
+      return (co < O && ci >= 0 && ci < I) ? w[((size_t)co * I + ci) * 9 + dy * 3 + dx] * scale : 0.0f;
+    };
+    unsigned char* dst = wd + idx * 16;
+    if (u < 2) {
+      f16x8 h;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) h[e] = (half_t)wv(chunk * 32 + u * 16 + pl * 8 + e);
+      *(f16x8*)dst = h;
+    } else {
+      float v[16];
+#pragma unroll
+      for (int b = 0; b < 16; ++b) {
+        const float x = wv(chunk * 32 + pl * 16 + b);
+        const float r = (u == 2) ? x : (x - (float)(half_t)x) * 2048.0f;
+        v[b] = fminf(fmaxf(r, -448.0f), 448.0f);
+      }
+      u32x4 o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int pk = SDM_CVT_PK_FP8(v[q * 4], v[q * 4 + 1], 0, false);
+        pk = SDM_CVT_PK_FP8(v[q * 4 + 2], v[q * 4 + 3], pk, true);
+        o[q] = (unsigned int)pk;
+      }
+      *(u32x4*)dst = o;
+    }
   }
 }
 

@@ -19,11 +19,15 @@ typedef half_t f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 #ifdef SDM_EMU
 #define SDM_DYN_SMEM(name) unsigned char* name = emu::g_dyn_smem
 #define SDM_SHARED static thread_local
 #define SDM_MFMA_32x32x16_F16(a, b, c) emu_mfma_f32_32x32x16_f16((a), (b), (c))
+#define SDM_MFMA_32x32x64_F8(a, b, c, sa, sb) emu_mfma_scale_f32_32x32x64_fp8((a), (b), (c), (sa), (sb))
+#define SDM_CVT_PK_FP8(a, b, old, hi_word) emu_cvt_pk_fp8_f32((a), (b), (old), (hi_word))
 #define SDM_LAUNCH(kernel, grid, block, smem, stream, ...) \
   emu::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); })
 #define SDM_DEV_INLINE static inline
@@ -36,6 +40,13 @@ static inline float sdm_rcp(float x) { return 1.0f / x; }
 #define SDM_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #define SDM_SHARED __shared__
 #define SDM_MFMA_32x32x16_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+// v_mfma_scale_f32_32x32x64_f8f6f4 on OCP e4m3 operands: lane l holds row / column (l & 31) and the 32 K values 32*(l>>5) .. +31
+// as 32 consecutive bytes; the product is multiplied by 2^(sa-127) * 2^(sb-127) (E8M0 exponents in byte 0 of two VGPRs; a
+// run-time 0 means 2^-127, NOT "unscaled").  Verified on hardware by tools/probe/f8_semantics_probe.hip.
+#define SDM_MFMA_32x32x64_F8(a, b, c, sa, sb) __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4((a), (b), (c), 0, 0, 0, (sa), 0, (sb))
+// v_cvt_pk_fp8_f32: two fp32 -> two e4m3 bytes (round to nearest even; |x| > 448 gives NaN, so callers clamp) into the low or
+// high 16 bits of `old`
+#define SDM_CVT_PK_FP8(a, b, old, hi_word) __builtin_amdgcn_cvt_pk_fp8_f32((a), (b), (old), (hi_word))
 #define SDM_LAUNCH(kernel, grid, block, smem, stream, ...) \
   hipLaunchKernelGGL(kernel, (grid), (block), (smem), (hipStream_t)(stream), __VA_ARGS__)
 #define SDM_DEV_INLINE __device__ __forceinline__

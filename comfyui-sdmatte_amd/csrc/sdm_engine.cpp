@@ -209,16 +209,28 @@ static void launch_conv_dma(const ConvParams& p_in, void* stream) {
   const dim3 grid((unsigned)(8L * p.xcd_chunk * p.tiles_n), 1, 1);
   const bool gn = p.gn_scale != nullptr, split = p.w_lo != nullptr;
   const size_t gn_extra = gn ? (size_t)(p.C0 + p.C1) * 8 : 0;
-#define SDM_DMA_CASE(F32, GNF, SPL)                                                                          \
+#define SDM_DMA_CASE(F32, GNF, SPL, PCF)                                                                     \
   do {                                                                                                       \
-    using CD = ConvCfg<9, 1, 8, 32, 128, 16, 2, 2, 0, SPL, 1>;                                               \
-    auto k = conv_mfma_kernel<9, 1, 8, 32, 128, 16, 2, 2, F32, 0, GNF, SPL, 1>;                              \
+    using CD = ConvCfg<9, 1, 8, 32, 128, 16, 2, 2, 0, SPL, 1, PCF>;                                          \
+    auto k = conv_mfma_kernel<9, 1, 8, 32, 128, 16, 2, 2, F32, 0, GNF, SPL, 1, PCF>;                         \
     SDM_SET_SMEM(k, 160 * 1024);                                                                             \
-    SDM_LAUNCH(k, grid, dim3(CD::NTHREADS), (size_t)CD::SMEM + gn_extra, stream, p);                         \
+    SDM_LAUNCH(k, grid, dim3(CD::LAUNCH_THREADS), (size_t)CD::SMEM + gn_extra, stream, p);                   \
   } while (0)
-  if (split) { if (gn) SDM_DMA_CASE(1, 1, 1); else SDM_DMA_CASE(1, 0, 1); }
-  else if (p.in_f32) { if (gn) SDM_DMA_CASE(1, 1, 0); else SDM_DMA_CASE(1, 0, 0); }
-  else { if (gn) SDM_DMA_CASE(0, 1, 0); else SDM_DMA_CASE(0, 0, 0); }
+  if (split && p.f8) {          // fp8-residual producer / consumer kernel (32-channel chunks; no GroupNorm table in LDS)
+#define SDM_F8_CASE(GNF)                                                                                     \
+  do {                                                                                                       \
+    using CD = ConvCfg<9, 1, 8, 32, 128, 32, 2, 2, 0, 1, 1, 1, 1>;                                           \
+    auto k = conv_mfma_kernel<9, 1, 8, 32, 128, 32, 2, 2, 1, 0, GNF, 1, 1, 1, 1>;                            \
+    SDM_SET_SMEM(k, 160 * 1024);                                                                             \
+    SDM_LAUNCH(k, grid, dim3(CD::LAUNCH_THREADS), (size_t)CD::SMEM, stream, p);                              \
+  } while (0)
+    if (gn) SDM_F8_CASE(1); else SDM_F8_CASE(0);
+#undef SDM_F8_CASE
+  }
+  else if (split && p.pc) { if (gn) SDM_DMA_CASE(1, 1, 1, 1); else SDM_DMA_CASE(1, 0, 1, 1); }
+  else if (split) { if (gn) SDM_DMA_CASE(1, 1, 1, 0); else SDM_DMA_CASE(1, 0, 1, 0); }
+  else if (p.in_f32) { if (gn) SDM_DMA_CASE(1, 1, 0, 0); else SDM_DMA_CASE(1, 0, 0, 0); }
+  else { if (gn) SDM_DMA_CASE(0, 1, 0, 0); else SDM_DMA_CASE(0, 0, 0, 0); }
 #undef SDM_DMA_CASE
 }
 
@@ -256,6 +268,13 @@ static int launch_conv(int ntaps, int stride, int cfg, const ConvParams& p, void
 // ------------------------------------------------------------------------------------------------
 // engine data structures
 // ------------------------------------------------------------------------------------------------
+// Residual terms of the split-precision 3x3 convs on fp8 operands (k_conv.h, F8): default on; SDM_CONV_F8=0 keeps them on fp16
+// (the round-2 "fp16x3" arithmetic everywhere).  Read when a model is built: the weight copy is packed for one of the two.
+static bool conv_f8_enabled() {
+  const char* v = getenv("SDM_CONV_F8");
+  return !(v && v[0] == '0');
+}
+
 struct ConvL {
   std::string name;
   int ntaps = 1, I = 0, O = 0, Cin_pad = 0, Cout_pad = 0, geglu = 0;
@@ -269,6 +288,7 @@ struct ConvL {
   // 3x3 layers wide enough for the 256x128 tile also keep their weights in the stage order of the DMA-weight kernels
   size_t wdma_off = 0, wdma_bytes = 0;
   half_t* w_dma = nullptr;
+  int f8 = 0;                 // w_dma holds the fp8-residual layout (F8 conv kernel) instead of the stage-ordered hi | lo pair
 };
 static const int kSplitWeightExp = 8;      // pre-scale 2^8: typical |w| ~ 1e-2 .. 1 -> low parts ~ 1e-3 .. 1e-1 * 2^-4: fp16-normal
 struct NormL {
@@ -434,6 +454,7 @@ struct Builder {
     if (ntaps == 9 && L.Cout_pad >= 128 && !geglu && (L.split || dma_all)) {
       L.wdma_bytes = (size_t)L.Cin_pad * 9 * L.Cout_pad * 2 * (L.split ? 2 : 1);
       L.wdma_off = woff; woff += rupz(L.wdma_bytes, 256);
+      L.f8 = (L.split && L.Cin_pad % 32 == 0 && conv_f8_enabled()) ? 1 : 0;      // same bytes, fp8-residual layout
     }
     e->convs.push_back(L);
     return (int)e->convs.size() - 1;
@@ -777,6 +798,12 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
   // weights by LDS-DMA (256x128 tile, 3x3 stride 1): the layer keeps a stage-ordered copy of its weights for that kernel
   static const bool dma_off = getenv("SDM_CONV_DMA") && getenv("SDM_CONV_DMA")[0] == '0';      // A/B hook
   if (!dma_off && L.ntaps == 9 && a.stride == 1 && cfg == 0 && L.w_dma && (!L.split || p.in_f32)) p.w_dma = L.w_dma;
+  {   // producer / consumer form of the split-precision DMA kernel (k_conv.h, PC): SDM_CONV_PC=0 / 1 forces it off / on
+    const char* pc_env = getenv("SDM_CONV_PC");                  // read per launch: tests toggle it
+    const int pc_min_cin = getenv("SDM_CONV_PC_MIN_CIN") ? atoi(getenv("SDM_CONV_PC_MIN_CIN")) : 256;
+    if (p.w_dma && L.split) p.pc = pc_env ? (pc_env[0] == '1') : (L.Cin_pad >= pc_min_cin);
+    if (p.w_dma && L.f8) { p.f8 = 1; p.f8_sa = 127 - 13; p.f8_sb = 127; }      // x_lo8 = x_lo * 2^13, x8 * w_lo8 = (x * 2^2)(w_lo * 2^11): both 2^13 too large
+  }
   if (e->dry) return 0;
   const double flops = 2.0 * (double)p.M * L.O * L.I * L.ntaps;
   const double bytes = (double)a.in0->rows() * L.Cin_pad * (p.in_f32 ? 4 : 2) + (double)p.M * p.Cout_valid * (p.out_f32 ? 4 : 2) +
@@ -1726,7 +1753,11 @@ int sdm_load_tensor(sdm_ctx* e, const char* name, int dtype, int ndim, const int
       SDM_LAUNCH(pack_conv_weight_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 65535)), dim3(256), 0, e->stream,
                  (const float*)dsrc, L.w, O, I, L.ntaps, L.Cin_pad, L.Cout_pad, s.ci_off, s.co_off, L.geglu,
                  s.w_scale * ldexpf(1.0f, L.w_exp), L.w_lo);
-      if (L.w_dma) {
+      if (L.w_dma && L.f8) {
+        const size_t rows = total / 4;       // 16-byte rows: 4 bytes per weight
+        SDM_LAUNCH(pack_conv_weight_f8_kernel, dim3((unsigned)std::min<size_t>((rows + 255) / 256, 65535)), dim3(256), 0, e->stream,
+                   (const float*)dsrc, (unsigned char*)L.w_dma, O, I, L.Cin_pad, L.Cout_pad, s.ci_off, s.w_scale * ldexpf(1.0f, L.w_exp));
+      } else if (L.w_dma) {
         const size_t tot2 = total * (L.split ? 2 : 1);
         SDM_LAUNCH(pack_conv_weight_dma_kernel, dim3((unsigned)std::min<size_t>((tot2 + 255) / 256, 65535)), dim3(256), 0, e->stream,
                    (const float*)dsrc, L.w_dma, O, I, L.Cin_pad, L.Cout_pad, s.ci_off, s.w_scale * ldexpf(1.0f, L.w_exp), L.split ? 2 : 1);
@@ -1790,7 +1821,10 @@ static int fold_cross_kv(sdm_ctx* e) {
     const size_t total = (size_t)L.Cin_pad * 9 * L.Cout_pad;
     SDM_LAUNCH(pack_conv_weight_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 65535)), dim3(256), 0, e->stream, (const float*)e->stage,
                L.w, 2 * C, 4, 9, L.Cin_pad, L.Cout_pad, 4, 0, 0, ldexpf(1.0f, L.w_exp), L.w_lo);
-    if (L.w_dma)
+    if (L.w_dma && L.f8)
+      SDM_LAUNCH(pack_conv_weight_f8_kernel, dim3((unsigned)std::min<size_t>((total / 4 + 255) / 256, 65535)), dim3(256), 0, e->stream,
+                 (const float*)e->stage, (unsigned char*)L.w_dma, 2 * C, 4, L.Cin_pad, L.Cout_pad, 4, ldexpf(1.0f, L.w_exp));
+    else if (L.w_dma)
       SDM_LAUNCH(pack_conv_weight_dma_kernel, dim3((unsigned)std::min<size_t>((total * (L.split ? 2 : 1) + 255) / 256, 65535)), dim3(256), 0, e->stream,
                  (const float*)e->stage, L.w_dma, 2 * C, 4, L.Cin_pad, L.Cout_pad, 4, ldexpf(1.0f, L.w_exp), L.split ? 2 : 1);
     SDM_CHECK_DEV(e, dev_sync(e->stream));
@@ -2003,6 +2037,11 @@ int sdm_op_conv_ex(sdm_ctx* e, const void* in0, const void* in1, int C0, int C1,
     const size_t tot2 = total * (split ? 2 : 1);
     SDM_CHECK_DEV(e, dev_malloc(&wd, tot2 * 2));
     L.w_dma = (half_t*)wd;
+    L.f8 = (split && L.Cin_pad % 32 == 0 && conv_f8_enabled()) ? 1 : 0;
+    if (L.f8)
+      SDM_LAUNCH(pack_conv_weight_f8_kernel, dim3((unsigned)std::min<size_t>((total / 4 + 255) / 256, 65535)), dim3(256), 0, e->stream, w,
+                 (unsigned char*)L.w_dma, O, L.I, L.Cin_pad, L.Cout_pad, 0, ldexpf(1.0f, L.w_exp));
+    else
     SDM_LAUNCH(pack_conv_weight_dma_kernel, dim3((unsigned)std::min<size_t>((tot2 + 255) / 256, 65535)), dim3(256), 0, e->stream, w, L.w_dma, O, L.I,
                L.Cin_pad, L.Cout_pad, 0, ldexpf(1.0f, L.w_exp), split ? 2 : 1);
   }
@@ -2096,8 +2135,9 @@ int sdm_debug_temb_row(sdm_ctx* e, int temb_index, int is_trans, const float* co
 /* Bench/ablation helper (not used by the engine): times `iters` launches of one conv with HIP events; returns ms per launch
  * (negative on error).  ablate bits: see ConvParams::ablate. */
 float sdm_bench_conv(sdm_ctx* e, int N, int H, int W, int Cin, int Cout, int ntaps, int stride, int in_f32, int tile_cfg, int ablate, int iters) {
-  // in_f32: bit 0 = fp32 activations, bit 1 = split-precision kernel (implies fp32), bit 2 = fused GroupNorm+SiLU staging
-  const int split = (in_f32 >> 1) & 1, gnf = (in_f32 >> 2) & 1;
+  // in_f32: bit 0 = fp32 activations, bit 1 = split-precision kernel (implies fp32), bit 2 = fused GroupNorm+SiLU staging,
+  // bit 3 = producer / consumer form of the split-precision DMA kernel
+  const int split = (in_f32 >> 1) & 1, gnf = (in_f32 >> 2) & 1, pcf = (in_f32 >> 3) & 1, f8f = (in_f32 >> 4) & 1;      // bit 4: fp8-residual kernel
   in_f32 = (in_f32 & 1) | split;
   if (e) dev_use(e->device);
   if (!e) return -1.f;
@@ -2138,6 +2178,8 @@ float sdm_bench_conv(sdm_ctx* e, int N, int H, int W, int Cin, int Cout, int nta
     p.w_dma = (const half_t*)wdm;
   }
   if (split) p.w_lo = (const half_t*)wl;
+  p.pc = (split && p.w_dma && pcf) ? 1 : 0;
+  if (split && p.w_dma && f8f && L.Cin_pad % 32 == 0) { p.f8 = 1; p.f8_sa = 127 - 13; p.f8_sb = 127; }
   if (gnf) { p.gn_scale = (const float*)gnt; p.gn_shift = (const float*)gnt + (size_t)N * L.Cin_pad; p.gn_silu = 1; }
   int cfg = tile_cfg >= 0 ? tile_cfg : conv_pick_cfg(ntaps, stride, p);
   hipEvent_t e0, e1;

@@ -114,6 +114,59 @@ static inline emu_f16v emu_mfma_f32_32x32x16_f16(emu_h8 a, emu_h8 b, emu_f16v c)
   return c;
 }
 
+// ---- OCP fp8 e4m3 (gfx950): conversion (round to nearest even, NaN beyond +-448 like v_cvt_pk_fp8_f32) and the K = 64 scaled
+//      MFMA (lane l: row / column l & 31, K values 32*(l>>5) .. +31 as 32 consecutive bytes; product scaled by
+//      2^(sa-127) * 2^(sb-127)); semantics pinned on hardware by tools/probe/f8_semantics_probe.hip ----
+static inline float emu_e4m3_to_f32(unsigned char v) {
+  const int s = v >> 7, e = (v >> 3) & 15, m = v & 7;
+  float r;
+  if (e == 0) r = ldexpf((float)m, -9);
+  else if (e == 15 && m == 7) r = NAN;
+  else r = ldexpf(1.0f + m / 8.0f, e - 7);
+  return s ? -r : r;
+}
+static inline unsigned char emu_f32_to_e4m3(float x) {
+  const unsigned char sign = std::signbit(x) ? 0x80 : 0;
+  float a = fabsf(x);
+  if (!(a == a)) return sign | 0x7f;
+  if (a > 464.0f) return sign | 0x7f;                      // beyond the rounding range of 448: NaN (callers clamp)
+  if (a >= 448.0f) return sign | 0x7e;
+  if (a < ldexpf(1.0f, -10)) return sign;                  // below half of the smallest subnormal (ties to even -> 0)
+  int e; frexpf(a, &e); e -= 1;                            // a = 1.xxx * 2^e
+  if (e < -6) e = -6;                                      // subnormal range: fixed step 2^-9
+  const float step = ldexpf(1.0f, e - 3);
+  float q = nearbyintf(a / step);                          // default rounding mode: nearest even
+  float v = q * step;
+  int ee; frexpf(v, &ee); ee -= 1;
+  if (v < ldexpf(1.0f, -6)) return sign | (unsigned char)q;                       // subnormal: mantissa = q
+  const int m = (int)nearbyintf((v / ldexpf(1.0f, ee) - 1.0f) * 8.0f);
+  return sign | (unsigned char)(((ee + 7) << 3) | m);
+}
+static inline int emu_cvt_pk_fp8_f32(float a, float b, int old, bool hi_word) {
+  const unsigned int pk = (unsigned int)emu_f32_to_e4m3(a) | ((unsigned int)emu_f32_to_e4m3(b) << 8);
+  const unsigned int o = (unsigned int)old;
+  return (int)(hi_word ? ((o & 0x0000ffffu) | (pk << 16)) : ((o & 0xffff0000u) | pk));
+}
+typedef int emu_i8v __attribute__((ext_vector_type(8)));
+static inline emu_f16v emu_mfma_scale_f32_32x32x64_fp8(emu_i8v a, emu_i8v b, emu_f16v c, int sa, int sb) {
+  auto& w = emu::wave(); int l = emu::lane_id();
+  memcpy(&w.slot[l][0], &a, 32); memcpy(&w.slot[l][8], &b, 32); emu::wave_barrier();
+  const float scale = ldexpf(1.0f, (sa & 255) - 127 + (sb & 255) - 127);
+  int col = l & 31, hi = l >> 5;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    double acc = 0.0;
+    for (int kh = 0; kh < 2; ++kh) {
+      const unsigned char* av = (const unsigned char*)&w.slot[row + 32 * kh][0];
+      const unsigned char* bv = (const unsigned char*)&w.slot[col + 32 * kh][8];
+      for (int j = 0; j < 32; ++j) acc += (double)emu_e4m3_to_f32(av[j]) * (double)emu_e4m3_to_f32(bv[j]);
+    }
+    c[r] = c[r] + (float)acc * scale;
+  }
+  emu::wave_barrier();
+  return c;
+}
+
 // ---- host runtime stand-ins used by the engine ----
 typedef void* hipStream_t;
 typedef int hipError_t;

@@ -2,6 +2,7 @@
 kernels): every HIP kernel vs a plain torch fp32 reference of the same op on the same seeded inputs.
 Tolerances are stated per check: operands are fp16 (MFMA inputs), accumulation fp32."""
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -25,9 +26,11 @@ def h16(x):
 
 
 def check_conv(eng, dev, N, H, W, Cin, Cout, ntaps=9, stride=1, pad_mode=0, up=0, C1=0, in_f32=False, res=None, out_f32=False,
-               geglu=False, out_scale=1.0, tile_cfg=-1, seed=0, atol=4e-3, split=False, gn=None):
+               geglu=False, out_scale=1.0, tile_cfg=-1, seed=0, atol=4e-3, split=False, gn=None, f8=False):
     """gn = (eps, silu): GroupNorm(32)(+SiLU) of the input fused into the conv's operand staging (the ResBlock path).
-    split = True: split-fp16 operands (precise mode) - the reference then sees the un-rounded fp32 operands."""
+    split = True: split-fp16 operands (precise mode) - the reference then sees the un-rounded fp32 operands.
+    f8 = True: the residual terms of the split product on fp8 operands (F8 kernel: 3x3 stride 1, Cin % 32 == 0, tile cfg 0);
+    False pins them to fp16 (SDM_CONV_F8=0) so that the 2e-5 checks of the fp16x3 arithmetic keep their meaning."""
     g = _g(seed)
     rnd = (lambda t: t) if split else h16
     x = torch.randn(N, Cin + C1, H, W, generator=g)
@@ -75,8 +78,16 @@ def check_conv(eng, dev, N, H, W, Cin, Cout, ntaps=9, stride=1, pad_mode=0, up=0
     if r is not None:
         rr = nhwc(r)
         rr = (rr if res == "f32" else rr.half()).to(dev)
-    out = eng.op_conv(x0, w.to(dev), b.to(dev), x1=x1, stride=stride, pad_mode=pad_mode, up=up, res=rr, geglu=geglu, out_f32=out_f32,
-                      out_scale=out_scale, tile_cfg=tile_cfg, split=split, gn=gn_arg)
+    prev = os.environ.get("SDM_CONV_F8")
+    os.environ["SDM_CONV_F8"] = "1" if f8 else "0"
+    try:
+        out = eng.op_conv(x0, w.to(dev), b.to(dev), x1=x1, stride=stride, pad_mode=pad_mode, up=up, res=rr, geglu=geglu, out_f32=out_f32,
+                          out_scale=out_scale, tile_cfg=tile_cfg, split=split, gn=gn_arg)
+    finally:
+        if prev is None:
+            os.environ.pop("SDM_CONV_F8", None)
+        else:
+            os.environ["SDM_CONV_F8"] = prev
     got = nchw(out.float().cpu())
     err = (got - ref).abs().max().item()
     assert err < atol, f"conv mismatch max|d|={err:.4g} (ntaps={ntaps} s={stride} pad={pad_mode} up={up} cfg={tile_cfg} " \

@@ -60,6 +60,33 @@ def test_conv3x3_dma_weight_pipeline(emu_engine):
     S.check_conv(emu_engine, DEV, 1, 6, 20, 32, 128, C1=32, up=1, tile_cfg=0, in_f32=True, out_f32=True, split=True, seed=8, atol=2e-5)
 
 
+def test_conv3x3_producer_consumer_form(emu_engine, monkeypatch):
+    """PC form of the split-precision DMA-weight kernel (8 waves: 4 MFMA-only consumer waves + 4 staging producer waves, A tile
+    double-buffered, weights two stages ahead in a ring of 5): 1 / odd / even numbers of K-chunks, ragged output-channel tile, fused
+    GroupNorm, upsample + concat, residual; and agreement with the 4-wave form up to the fp32 summation order."""
+    monkeypatch.setenv("SDM_CONV_PC", "1")
+    S.check_conv(emu_engine, DEV, 1, 9, 35, 16, 128, tile_cfg=0, in_f32=True, out_f32=True, split=True, seed=6, atol=2e-5)
+    S.check_conv(emu_engine, DEV, 2, 9, 35, 96, 160, tile_cfg=0, in_f32=True, out_f32=True, split=True, gn=(1e-6, True), res="f32", seed=7, atol=2e-5)
+    S.check_conv(emu_engine, DEV, 1, 6, 20, 32, 128, C1=32, up=1, tile_cfg=0, in_f32=True, out_f32=True, split=True, seed=8, atol=2e-5)
+    torch.manual_seed(3)
+    x = torch.randn(1, 10, 33, 80)
+    w = torch.randn(128, 80, 3, 3) / 27.0
+    a = emu_engine.op_conv(x, w, None, out_f32=True, split=True, tile_cfg=0)
+    monkeypatch.setenv("SDM_CONV_PC", "0")
+    b = emu_engine.op_conv(x, w, None, out_f32=True, split=True, tile_cfg=0)
+    assert (a - b).abs().max().item() <= 2e-5
+
+
+def test_conv3x3_fp8_residual_terms(emu_engine):
+    """F8 kernel: x_hi.w_hi on fp16, the residual terms x_lo.w and x.w_lo on e4m3 operands (one K=64 MFMA per tap and 32 channels),
+    32-channel chunks, producer / consumer waves.  1 / 2 / 3 chunks, ragged output-channel tile, fused GroupNorm + SiLU, residual,
+    upsample + concat.  Error bound: a residual term is 2^-11 of the product and e4m3 rounds at 2^-4: ~2^-15 per operand."""
+    e0 = S.check_conv(emu_engine, DEV, 1, 9, 35, 32, 128, tile_cfg=0, in_f32=True, out_f32=True, split=True, f8=True, seed=6, atol=3e-4)
+    S.check_conv(emu_engine, DEV, 2, 9, 35, 96, 160, tile_cfg=0, in_f32=True, out_f32=True, split=True, f8=True, gn=(1e-6, True), res="f32", seed=7, atol=3e-4)
+    S.check_conv(emu_engine, DEV, 1, 6, 20, 32, 128, C1=32, up=1, tile_cfg=0, in_f32=True, out_f32=True, split=True, f8=True, seed=8, atol=3e-4)
+    assert e0 < 1e-4, e0          # plain fp16 operands sit at ~1.5e-3 against the un-rounded reference on these inputs
+
+
 def test_conv3x3_thin_output_tile(emu_engine):
     S.check_conv(emu_engine, DEV, 2, 10, 33, 32, 3, in_f32=True, tile_cfg=4, seed=9)          # conv_out shape: Cout 3 -> one 32-wide tile
 

@@ -187,3 +187,14 @@ def test_conv3x3_operand_image_beyond_4gb_matches_row_band_crops(eng):
             tol = 2e-5
             assert (got - want).abs().max().item() <= tol, f"split={split} rows {ra}..{rb}: max|d|={(got - want).abs().max().item():.3e}"
         del y
+
+
+@pytest.mark.parametrize("cin,cout,H,W,gn,res,up", [(32, 128, 9, 35, None, None, 0), (128, 128, 40, 96, (1e-6, True), "f32", 0), (512, 200, 24, 40, (1e-5, True), None, 0),
+                                                   (256, 128, 20, 48, None, "f32", 1), (320, 320, 32, 64, (1e-5, True), "f32", 0)])
+def test_conv3x3_fp8_residual_terms(eng, cin, cout, H, W, gn, res, up):
+    """F8 kernel (k_conv.h): x_hi.w_hi on fp16 MFMAs, the residual terms x_lo.w and x.w_lo on e4m3 operands through
+    v_mfma_scale_f32_32x32x64_f8f6f4, producer / consumer waves, against the un-rounded fp32 reference: far inside the 4e-3 of fp16
+    operands, at the ~2^-15 relative level a 2^-4 rounding of a 2^-11 term leaves."""
+    err = S.check_conv(eng, DEV, 2, H, W, cin, cout, tile_cfg=0, in_f32=True, out_f32=True, split=True, f8=True, gn=gn, res=res if cout % 4 == 0 else None,
+                       up=up, seed=cin + cout, atol=3e-4)
+    print(f"[F8 conv {cin}->{cout}] max|d|={err:.2e}")
