@@ -60,6 +60,7 @@ struct ConvParams {
   int gn_silu;
   int pc;                               // DMAB + SPLIT: 1 = producer / consumer form (8 waves, one block per CU), set by the launcher
   int f8;                               // 1: w_dma holds the fp8-residual layout (pack_conv_weight_f8_kernel) -> F8 kernel
+  int f8_hint;                          // tile selection only: the layer has the fp8-residual weights (cfg 0 then beats the 256x64 tile)
   int f8_sa, f8_sb;                     // E8M0 exponents (byte 0) of the fp8 MFMA operand scales: 2^(sa-127) * 2^(sb-127) maps the residual sums to accumulator units
   int ablate;                           // debug/bench only (sdm_bench_conv): 1 skip global loads, 2 skip LDS writes, 4 skip MFMA,
                                         // 8 skip the epilogue stores -- after the first K-chunk; always 0 in the engine

@@ -183,7 +183,9 @@ static int conv_pick_cfg(int ntaps, int stride, const ConvParams& p) {
       if (ntaps == 9 && stride == 1 && i == 0 && p.Cout_pad <= 32 && conv_cfg_ok(t[4], p)) return 4;
       // fewer than two rounds of the 256x128 tile (2 blocks per CU): the 256x64 tile (3 blocks per CU, twice the blocks) fills the
       // chip better - measured +5..17 % on the U-Net layers (320 ch @128^2, 640 @64^2, 1280 @32^2), -3..10 % on the large VAE layers
-      if (ntaps == 9 && stride == 1 && i == 0 && blocks < 1024 && p.Cout_pad > 64 && conv_cfg_ok(t[5], p)) return 5;
+      // (not for layers with the fp8-residual weights: their 8-wave one-block-per-CU kernel on the 256x128 tile measured
+      // 1.35-1.5x the 256x64 tile on exactly these shapes)
+      if (ntaps == 9 && stride == 1 && i == 0 && blocks < 1024 && p.Cout_pad > 64 && !p.f8_hint && conv_cfg_ok(t[5], p)) return 5;
       // stride 2: 256 pixels x 128 channels on 8 waves halves the input re-reads per output channel (+25 % on the VAE
       // down-samplers) once there is a block for every CU
       if (ntaps == 9 && stride == 2 && i == 0 && conv_cfg_ok(t[3], p) &&
@@ -780,6 +782,7 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
   }
   if (p.C0 + p.C1 != L.Cin_pad) SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: input channels %d+%d != %d", L.name.c_str(), p.C0, p.C1, L.Cin_pad);
   if (a.in1 && a.in1->f32 != a.in0->f32) SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: concat sources differ in dtype", L.name.c_str());
+  p.f8_hint = (L.f8 && L.w_dma && p.in_f32 && L.ntaps == 9 && a.stride == 1) ? 1 : 0;
   int cfg = a.force_cfg >= 0 ? a.force_cfg : conv_pick_cfg(L.ntaps, a.stride, p);
   if (cfg < 0 || cfg >= conv_num_cfgs(L.ntaps, a.stride) || !conv_cfg_ok(conv_cfg_table(L.ntaps, a.stride)[cfg], p))
     SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: no tile configuration for Cin=%d+%d (cfg %d)", L.name.c_str(), p.C0, p.C1, cfg);
@@ -1030,6 +1033,7 @@ static bool conv_can_fuse_gn(sdm_ctx* e, const ConvL& L, const T& x, const T* x2
   memset(&p, 0, sizeof(p));
   p.C0 = x.C; p.C1 = x2 ? x2->C : 0; p.in_f32 = x.f32; p.N = x.N; p.Hin = x.H; p.Win = x.W; p.Hout = x.H; p.Wout = x.W; p.Cout_pad = L.Cout_pad;
   p.M = x.rows();
+  p.f8_hint = (L.f8 && L.wdma_bytes && x.f32) ? 1 : 0;
   const int cfg = conv_pick_cfg(9, 1, p);
   return cfg == 0 || cfg == 4 || cfg == 5;        // the 256-pixel tiles that carry the fused-GroupNorm variant
   (void)e;
