@@ -192,7 +192,10 @@ def main():
                 traffic = pt.get("conv3x3_bytes_per_launch")
         except Exception:
             pass
-        mfma_per_product = 3 if precision == "fp16x3" else 1
+        f8_res = precision == "fp16x3" and os.environ.get("SDM_CONV_F8", "1") != "0"      # residual terms of the 3x3 convs on fp8 (engine default)
+        # matrix-pipe time per algorithmic product in units of one fp16 MFMA: fp16x3 = 3; fp16 + two fp8 residual terms at twice
+        # the rate = 2 (a handful of thin / strided launches of the family stay on 3 and are counted as 2: lower bound)
+        mfma_per_product = (2 if f8_res else 3) if precision == "fp16x3" else 1
         if "conv3x3_mfma" in prof:
             c = prof["conv3x3_mfma"]
             ach = c["flops"] / (c["ms"] * 1e-3) / 1e12 if c["ms"] > 0 else 0.0
@@ -200,8 +203,9 @@ def main():
                     "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_PEAK_TFLOPS, 4), "traffic": traffic,
                     "launches_per_step": c["launches"], "avg_launch_us": round(c["ms"] * 1e3 / max(c["launches"], 1), 2),
                     "flops_per_launch": c["flops"] / max(c["launches"], 1),
-                    "note": f"achieved = ALGORITHMIC flops (2*MAC of the convolution) / time; this precision issues {mfma_per_product} "
-                            f"fp16 MFMA(s) per algorithmic product, i.e. the matrix pipe executes {mfma_per_product}x that rate",
+                    "note": f"achieved = ALGORITHMIC flops (2*MAC of the convolution) / time; this precision keeps the matrix pipe busy for "
+                            f"{mfma_per_product} fp16-MFMA time(s) per algorithmic product"
+                            + (" (x_hi*w_hi on fp16 + the two residual terms on fp8 K=64 MFMAs at twice the rate)" if f8_res else ""),
                     "mfma_executed_frac": round(mfma_per_product * ach / MFMA_F16_PEAK_TFLOPS, 4)}
         breakdown = {k: {"ms": round(v["ms"], 3), "launches": v["launches"],
                          "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1) if v["flops"] else None,
@@ -257,7 +261,11 @@ def main():
                                    f"synthetic weights, {B} images per GPU per step",
                        "inference_size": S, "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
                        "precision": precision,
-                       "arithmetic": ("split-fp16 MFMA operands (hi+lo, 3 MFMAs per product), fp32 accumulate, fp32 activations"
+                       "arithmetic": (("split MFMA operands x = hi + lo, fp32 accumulate, fp32 activations: x_hi*w_hi on fp16; the residual "
+                                       "terms x_lo*w + x*w_lo on fp8 e4m3 (one K=64 MFMA) in the 3x3 convs with >= 128 output channels, on "
+                                       "fp16 (2 more MFMAs) in every other conv / GEMM / attention product"
+                                       if os.environ.get("SDM_CONV_F8", "1") != "0" else
+                                       "split-fp16 MFMA operands (hi+lo, 3 MFMAs per product), fp32 accumulate, fp32 activations")
                                       if precision == "fp16x3" else "fp16 MFMA operands, fp32 accumulate, fp32 residual stream"),
                        "trimap": "synthetic disc/annulus (28 % foreground / 22 % unknown / 50 % background, SURVEY.md 8d)",
                        "self_attention_keys": "all key tiles" if args.dense_attention else
