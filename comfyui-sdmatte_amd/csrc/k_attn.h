@@ -77,9 +77,13 @@ SDM_DEV_INLINE bool attn_block_coords(const AttnParams& p, int bid, int& b, int&
 // L2 / Infinity-Cache traffic and half the LDS staging work per MFMA of the 4-wave block (K | V of one head in hi | lo planes is
 // 8.4 MB at 16384 keys: it does not fit the 4 MB L2 of an XCD, and 128-query blocks streamed it at ~5 TB/s) - at the same 2
 // waves per SIMD; used when it still yields at least one block per CU.
+// PREC = 2: only Q.K^T is split; P and V^T enter P.V as plain fp16 (V^T_lo is neither loaded nor staged).  The logits feed an
+// exponential, the probabilities are averaged: on the full architecture the residual terms of P.V move alpha by 9e-6 (1.055e-4 ->
+// 1.143e-4 at 512^2) and cost 16 % of the kernel (tests/tools/attn_pv_experiment.py) - PREC = 2 is what the engine uses.
 template <int QT, int PREC = 0, int NW = 4>
 __global__ void __launch_bounds__(64 * NW, 2) attn_d64_kernel(AttnParams p) {
   static_assert(!PREC || QT == 1, "the split-precision variant keeps one 32-query tile per wave");
+  constexpr int PVS = (PREC == 1) ? 1 : 0;                       // P.V on split operands too
   constexpr int NTH = 64 * NW, VPT = 512 / NTH;                  // threads, 16-byte vectors per thread and tile (K and V^T: 512 each)
   SDM_DYN_SMEM(smem);
   constexpr int PK = ATTN64_PK, PV = ATTN64_PV;
@@ -87,7 +91,7 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_kernel(AttnParams p) {
   constexpr int KLO = 64 * PK;                                   // PREC: byte offset of the K_lo tile behind K_hi
   constexpr int VOFF = (PREC ? 2 : 1) * 64 * PK;                 // V^T_hi tile
   constexpr int VLO = 64 * PV;                                   // PREC: V^T_lo behind V^T_hi
-  constexpr int BOFF = VOFF + (PREC ? 2 : 1) * 64 * PV;          // bias row
+  constexpr int BOFF = VOFF + (PVS ? 2 : 1) * 64 * PV;           // bias row
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, l31 = lane & 31;
   int b, head, qblk;
@@ -147,7 +151,7 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_kernel(AttnParams p) {
   const float* bbase = p.bias ? p.bias + (size_t)b * p.bias_bs : nullptr;
   const int ntiles = (p.Lk + 63) / 64;
 
-  f16x8 kreg[VPT], vreg[VPT], kregl[PREC ? VPT : 1], vregl[PREC ? VPT : 1];
+  f16x8 kreg[VPT], vreg[VPT], kregl[PREC ? VPT : 1], vregl[PVS ? VPT : 1];
   float breg = 0.0f;
   bool binr = true;
   // without a bias the load still happens (from the K tensor: >= Lk readable floats) and its value is discarded by a select
@@ -164,10 +168,8 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_kernel(AttnParams p) {
       if (kr > p.Lk - 1) kr = p.Lk - 1;
       kreg[i] = *(const f16x8*)(kbase + (size_t)kr * p.ldk + part * 8);
       vreg[i] = *(const f16x8*)(vbase + (size_t)row * p.ldvt + k0 + part * 8);
-      if (PREC) {
-        kregl[PREC ? i : 0] = *(const f16x8*)(kbase + p.k_lo + (size_t)kr * p.ldk + part * 8);
-        vregl[PREC ? i : 0] = *(const f16x8*)(vbase + p.vt_lo + (size_t)row * p.ldvt + k0 + part * 8);
-      }
+      if (PREC) kregl[PREC ? i : 0] = *(const f16x8*)(kbase + p.k_lo + (size_t)kr * p.ldk + part * 8);
+      if (PVS) vregl[PVS ? i : 0] = *(const f16x8*)(vbase + p.vt_lo + (size_t)row * p.ldvt + k0 + part * 8);
     }
     // bias: UNCONDITIONAL raw load, consumed only in stage() after the MFMAs.  (`bbase ? bbase[kb] : 0` followed by a select
     // made hipcc branch around the load and wait vmcnt(0) right here - which also drains the four K / V^T prefetch loads
@@ -190,10 +192,10 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_kernel(AttnParams p) {
       for (int e = 0; e < 4; ++e) { lo[e] = vreg[i][e]; hi4[e] = vreg[i][4 + e]; }
       *(f16x4*)(base + VOFF + row * PV + part * 16) = lo;
       *(f16x4*)(base + VOFF + row * PV + part * 16 + 8) = hi4;
-      if (PREC) {
-        *(f16x8*)(base + KLO + row * PK + part * 16) = kregl[PREC ? i : 0];
+      if (PREC) *(f16x8*)(base + KLO + row * PK + part * 16) = kregl[PREC ? i : 0];
+      if (PVS) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { lo[e] = vregl[PREC ? i : 0][e]; hi4[e] = vregl[PREC ? i : 0][4 + e]; }
+        for (int e = 0; e < 4; ++e) { lo[e] = vregl[PVS ? i : 0][e]; hi4[e] = vregl[PVS ? i : 0][4 + e]; }
         *(f16x4*)(base + VOFF + VLO + row * PV + part * 16) = lo;
         *(f16x4*)(base + VOFF + VLO + row * PV + part * 16 + 8) = hi4;
       }
@@ -292,7 +294,7 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_kernel(AttnParams p) {
         for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
           for (int j = 0; j < 8; ++j) pf[qt][j] = (half_t)s[qt][kt][8 * u + j];
-        if (PREC) {
+        if (PVS) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) pfl[j] = (half_t)(s[0][kt][8 * u + j] - (float)pf[0][j]);
         }
@@ -310,7 +312,7 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_kernel(AttnParams p) {
           for (int e = 0; e < 4; ++e) { vf[e] = v0[e]; vf[4 + e] = v1[e]; }
 #pragma unroll
           for (int qt = 0; qt < QT; ++qt) o[qt][dt] = SDM_MFMA_32x32x16_F16(vf, pf[qt], o[qt][dt]);
-          if (PREC) {
+          if (PVS) {
             const f16x4 w0 = *(const f16x4*)(vp + VLO);
             const f16x4 w1 = *(const f16x4*)(vp + VLO + 16);
             f16x8 vfl;

@@ -944,7 +944,11 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
     prof_begin(e, "transpose_v", 0, (double)B * Lk * heads * D * 4);
     SDM_LAUNCH(transpose_v_kernel, dim3(ldvt / 64, heads * (D / 64), B), dim3(256), 0, e->stream, v, (long)Lk * ldv, ldv, (half_t*)vt.p, vt_bs,
                vt_hs, ldvt, Lk, D);
-    if (ap.prec)
+    // split-precision variant: Q.K^T on split operands, P.V on plain fp16 (k_attn.h, PREC = 2) unless SDM_ATTN_PV_SPLIT=1 asks for
+    // the residual terms of P.V too (PREC = 1: then V^T_lo is needed as well)
+    const char* pvs_env = getenv("SDM_ATTN_PV_SPLIT");
+    const bool pv_split = ap.prec && pvs_env && pvs_env[0] == '1';
+    if (pv_split)
       SDM_LAUNCH(transpose_v_kernel, dim3(ldvt / 64, heads * (D / 64), B), dim3(256), 0, e->stream, v + ap.v_lo, (long)Lk * ldv, ldv,
                  (half_t*)vt.p + (size_t)B * vt_bs, vt_bs, vt_hs, ldvt, Lk, D);
     prof_end(e);
@@ -986,9 +990,12 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
       p.batch = B; p.heads = heads; p.nq_blocks = sdm_cdiv(Lq, qrows); p.q_chunks = 8;     // B*heads*8 units: always a multiple of 8
       const int qb = sdm_cdiv(p.nq_blocks, p.q_chunks);
       const unsigned nblk = (unsigned)(B * heads * p.q_chunks * qb);                         // 1-D grid, XCD-aware mapping in the kernel
-      if (ap.prec) {
+      if (ap.prec && pv_split) {
         if (nw8) { auto kp = attn_d64_kernel<1, 1, 8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(512), ATTN64P_SMEM, e->stream, p); }
         else { auto kp = attn_d64_kernel<1, 1, 4>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(256), ATTN64P_SMEM, e->stream, p); }
+      } else if (ap.prec) {
+        if (nw8) { auto kp = attn_d64_kernel<1, 2, 8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(512), ATTN64P_SMEM, e->stream, p); }
+        else { auto kp = attn_d64_kernel<1, 2, 4>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(256), ATTN64P_SMEM, e->stream, p); }
       } else {
         if (nw8) { auto kf = attn_d64_kernel<1, 0, 8>; SDM_SET_SMEM(kf, 160 * 1024); SDM_LAUNCH(kf, dim3(nblk, 1, 1), dim3(512), ATTN64P_SMEM, e->stream, p); }
         else { SDM_LAUNCH((attn_d64_kernel<1, 0, 4>), dim3(nblk, 1, 1), dim3(256), ATTN64_SMEM, e->stream, p); }
@@ -2236,7 +2243,9 @@ float sdm_bench_attn(sdm_ctx* e, int B, int heads, int Lq, int Lk, int qt, int a
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   for (int i = 0; i <= iters; ++i) {
     if (i == 1) (void)hipEventRecord(e0, (hipStream_t)e->stream);
-    if (prec && nw8) { auto kp = attn_d64_kernel<1, 1, 8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk), dim3(512), ATTN64P_SMEM, e->stream, p); }
+    if (prec && (qt & 8) && nw8) { auto kp = attn_d64_kernel<1, 2, 8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk), dim3(512), ATTN64P_SMEM, e->stream, p); }      // bit 8: P.V on plain fp16
+    else if (prec && (qt & 8)) { auto kp = attn_d64_kernel<1, 2, 4>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk), dim3(256), ATTN64P_SMEM, e->stream, p); }
+    else if (prec && nw8) { auto kp = attn_d64_kernel<1, 1, 8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk), dim3(512), ATTN64P_SMEM, e->stream, p); }
     else if (prec) { auto kp = attn_d64_kernel<1, 1, 4>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk), dim3(256), ATTN64P_SMEM, e->stream, p); }
     else if (nw8) { auto kf = attn_d64_kernel<1, 0, 8>; SDM_SET_SMEM(kf, 160 * 1024); SDM_LAUNCH(kf, dim3(nblk), dim3(512), ATTN64P_SMEM, e->stream, p); }
     else { SDM_LAUNCH((attn_d64_kernel<1, 0, 4>), dim3(nblk), dim3(256), ATTN64_SMEM, e->stream, p); }
