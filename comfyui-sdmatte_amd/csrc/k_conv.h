@@ -64,6 +64,7 @@ struct ConvParams {
   int f8_sa, f8_sb;                     // E8M0 exponents (byte 0) of the fp8 MFMA operand scales: 2^(sa-127) * 2^(sb-127) maps the residual sums to accumulator units
   int ablate;                           // debug/bench only (sdm_bench_conv): 1 skip global loads, 2 skip LDS writes, 4 skip MFMA,
                                         // 8 skip the epilogue stores -- after the first K-chunk; always 0 in the engine
+  int vgrid, tpb;                       // F8 (tpb tiles per block): number of virtual block ids = the grid of the one-tile-per-block forms
   int tiles_m, tiles_n, xcd_chunk;      // 1-D XCD-aware grid (set by launch_conv_t): M tiles per image (9 taps) or in total (1 tap), N tiles, M tiles per XCD
   float* stats;                         // optional [N][tiles_m*WM][Cout_store][2]: per-(image, wave row-tile, channel) partial
                                         // sum / sum of squares of the stored values = fused GroupNorm statistics of the NEXT
@@ -153,9 +154,16 @@ conv_mfma_kernel(ConvParams p) {
   unsigned char* As = smem;                 // current K-chunk tile (switches between the two halves when DB)
   unsigned char* Bs = smem + (SPLIT ? 2 : 1) * C::A_BYTES;      // SPLIT: A_hi | A_lo | B
 
+  // One tile = one call of run_tile.  F8 blocks run p.tpb tiles back to back: while the consumer waves
+  // are in the epilogue of tile k, the producer waves already stage the first chunk and the first weight steps of tile k+1 (the
+  // epilogue's LDS staging lives in the second A buffer, which that prologue does not touch); the ~16 us of fixed cost per tile
+  // (launch, first loads, epilogue) is what separated the 4-chunk 128-channel layers from the 16-chunk ones.
+  auto run_tile = [&](const int vbid) {
   // PC: `tid` / `wave` are the index inside the role (consumers: MFMA tile position; producers: staging decomposition)
-  const int role = PC ? SDM_UNIFORM_I((int)threadIdx.x / NT) : 0;                  // 0: consumer (or everything), 1: producer
-  const int tid = PC ? ((int)threadIdx.x & (NT - 1)) : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int tx = (int)threadIdx.x;
+  if (F8) SDM_OPAQUE_I(tx);          // per tile: nothing derived from the lane index is shared between the inlined tiles and kept live across an epilogue
+  const int role = PC ? SDM_UNIFORM_I(tx / NT) : 0;                  // 0: consumer (or everything), 1: producer
+  const int tid = PC ? (tx & (NT - 1)) : tx, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   // XCD-aware 1-D grid.  The dispatcher places block id on XCD id % 8 (speed only, never needed for correctness).  XCD x owns
   // the contiguous M-tile range [x*chunk, (x+1)*chunk) and walks it in order, running the tiles_n output-channel tiles of
@@ -165,7 +173,7 @@ conv_mfma_kernel(ConvParams p) {
   int mt, n0, img = 0, oy0 = 0, ox0 = 0;
   long m0 = 0;
   {
-    const int bid = blockIdx.x;
+    const int bid = vbid;
     const int j = bid >> 3;
     const int ml = j / p.tiles_n;
     const int mlin = (bid & 7) * p.xcd_chunk + ml;
@@ -968,7 +976,7 @@ conv_mfma_kernel(ConvParams p) {
   // ---- epilogue: per-wave PRIVATE fp32 staging tile (32 x WTN) in LDS -> coalesced row stores ----
   if (!DB) __syncthreads();      // all waves are done with the A/B tiles (DB: the loop ended with a barrier)
   if (PC && role) return;        // the accumulators live in the consumer waves; no block-wide barrier below this line
-  float* stg = (float*)smem + wave * (32 * WTN);
+  float* stg = (float*)(smem + (F8 ? 2 * C::A_BYTES : 0)) + wave * (32 * WTN);      // F8: second A buffer (the next tile's prologue fills the first)
   const bool geglu = (p.epi == 1);
   constexpr int LPR = WTN / 4;                    // lanes per output row (linear epilogue: 4 channels per lane)
   const float* bias = p.bias;
@@ -1140,6 +1148,15 @@ conv_mfma_kernel(ConvParams p) {
       *(f32x4*)st = o0;
       *(f32x4*)(st + 4) = o1;
     }
+  }
+  };   // run_tile
+  if (F8) {
+    for (int k = 0; k < p.tpb; ++k) {
+      const int v = (int)blockIdx.x + k * (int)gridDim.x;
+      if (v < p.vgrid) run_tile(v);
+    }
+  } else {
+    run_tile((int)blockIdx.x);
   }
 }
 

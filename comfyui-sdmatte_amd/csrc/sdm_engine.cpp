@@ -200,6 +200,27 @@ static int conv_pick_cfg(int ntaps, int stride, const ConvParams& p) {
   return best;
 }
 
+// F8 conv kernel: tiles a block runs back to back (the producer waves stage tile k+1 under the epilogue of tile k).  Only when
+// every CU still gets a block: 160 tiles as 80 two-tile blocks measured 0.43 vs 0.26 ms.  SDM_CONV_F8_TPB overrides (A/B).
+static int conv_f8_tiles_per_block(long tiles) {
+#ifdef SDM_EMU
+  return tiles >= 6 ? 3 : (tiles >= 2 ? 2 : 1);
+#else
+  const char* o = getenv("SDM_CONV_F8_TPB");
+  if (o && o[0] >= '1' && o[0] <= '8') return o[0] - '0';
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+  }
+  // measured (profiles/r02_conv_f8_tiles_per_block.txt): 128->128 @1024^2 (64 tiles per CU) 490 / 504 / 516 TFLOP/s at 1 / 2 / 4 tiles per
+  // block; 320->320 @128^2 (3 per CU) 542 / 455; 1280->1280 @32^2 (0.6 per CU) 575 / 299: only deep queues gain
+  const long per_cu = tiles / cus;
+  return per_cu >= 32 ? 4 : (per_cu >= 8 ? 2 : 1);
+#endif
+}
+
 // 256 px x 128 co, 3x3 stride 1, weights through the LDS-DMA stage ring (k_conv.h, DMAB): fp16 / fp32 activations, optional fused
 // GroupNorm, optional split precision
 static void launch_conv_dma(const ConvParams& p_in, void* stream) {
@@ -224,7 +245,11 @@ static void launch_conv_dma(const ConvParams& p_in, void* stream) {
     using CD = ConvCfg<9, 1, 8, 32, 128, 32, 2, 2, 0, 1, 1, 1, 1>;                                           \
     auto k = conv_mfma_kernel<9, 1, 8, 32, 128, 32, 2, 2, 1, 0, GNF, 1, 1, 1, 1>;                            \
     SDM_SET_SMEM(k, 160 * 1024);                                                                             \
-    SDM_LAUNCH(k, grid, dim3(CD::LAUNCH_THREADS), (size_t)CD::SMEM, stream, p);                              \
+    p.vgrid = (int)grid.x;                                                                                   \
+    p.tpb = conv_f8_tiles_per_block((long)grid.x);                                                           \
+    unsigned pg = (grid.x + p.tpb - 1) / p.tpb;                                                              \
+    pg = (pg + 7) & ~7u;              /* block id % 8 = XCD: the stride between a block's tiles stays a multiple of 8 */ \
+    SDM_LAUNCH(k, dim3(pg, 1, 1), dim3(CD::LAUNCH_THREADS), (size_t)CD::SMEM, stream, p);                    \
   } while (0)
     if (gn) SDM_F8_CASE(1); else SDM_F8_CASE(0);
 #undef SDM_F8_CASE
