@@ -627,13 +627,44 @@ conv_mfma_kernel(ConvParams p) {
       };
       constexpr int AFLY = A_PER * (IN_F32 ? 2 : 1) + (GN ? 4 : 0);      // register loads that may stay in flight behind a step's DMAs
       static_assert(!F8 || AFLY == 12 || AFLY == 16, "counted wait below");
+      // activations (and GroupNorm coefficients) of the chunk AFTER the next one: loaded a whole chunk before they are transformed, so
+      // that the transform of the next chunk can be spread evenly over the six steps of the current one (one vector per step)
+      u32x4 a_nx[A_PER][IN_F32 ? 2 : 1];
+      f32x4 gqn[4];
+      auto issue_loads_nx = [&](int c0) {
+        const bool second = c0 >= p.C0;
+        const sdm_rsrc rs = second ? rs1 : rs0;
+        const unsigned int Cs = (unsigned int)(second ? p.C1 : p.C0) * es;
+        const unsigned int cc = (unsigned int)((second ? c0 - p.C0 : c0) + a_part) * es;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+          const unsigned int off = a_pix[i] >= 0 ? (unsigned int)a_pix[i] * Cs + cc : SDM_BUF_INVALID;
+          a_nx[i][0] = sdm_buffer_load16(rs, off, 0);
+          if (IN_F32) a_nx[i][IN_F32 ? 1 : 0] = sdm_buffer_load16(rs, off, 16);
+        }
+        if (GN) {
+          const float* ts = p.gn_scale + (size_t)img * Cin + c0 + a_part;
+          const float* th = p.gn_shift + (size_t)img * Cin + c0 + a_part;
+          gqn[0] = *(const f32x4*)ts; gqn[1] = *(const f32x4*)(ts + 4); gqn[2] = *(const f32x4*)th; gqn[3] = *(const f32x4*)(th + 4);
+        }
+      };
+      auto take_nx = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) { a_raw[i][0] = a_nx[i][0]; if (IN_F32) a_raw[i][IN_F32 ? 1 : 0] = a_nx[i][IN_F32 ? 1 : 0]; }
+        if (GN) { gq[0] = gqn[0]; gq[1] = gqn[1]; gq[2] = gqn[2]; gq[3] = gqn[3]; }
+      };
       if (role) {
         dma_step(0, 0);
         if (1 < nsteps) dma_step(1, 1);
+        SDM_SCHED_FENCE();
         issue_loads_a(0);
         issue_gn(0);
         write_lds_a_f8(Aring, 0, A_PER);
         SDM_WAIT_VMCNT0();
+        if (nch > 1) {                  // chunk 1: in flight across the first barrier
+          issue_loads_nx(32);
+          SDM_SCHED_FENCE();
+        }
       }
       SDM_WAIT_LGKMCNT0();
       SDM_RAW_BARRIER();
@@ -644,25 +675,21 @@ conv_mfma_kernel(ConvParams p) {
 #pragma unroll
           for (int k = 0; k < 6; ++k) {                  // step t = 6c + k: (dx = k / 2, S1 | S2)
             const int t = c * 6 + k;
+            // chunk c+1's raw values arrived during chunk c-1 (every earlier step ended with vmcnt(0) or left only them in flight)
+            if (k == 0 && more) take_nx();
+            SDM_SCHED_FENCE();
             if (t + 2 < nsteps) dma_step(t + 2, mod3(cm + k + 2));
             SDM_SCHED_FENCE();
-            if (k == 0 && more) {                        // next chunk's activations (and its GroupNorm coefficients): in flight for two steps
-              issue_loads_a((c + 1) * 32);
-              issue_gn((c + 1) * 32);
+            const bool fly = (k == 0) && (c + 2 < nch);
+            if (fly) {                                   // chunk c+2: loaded now, transformed during chunk c+1
+              issue_loads_nx((c + 2) * 32);
               SDM_SCHED_FENCE();
-              if (AFLY == 12) SDM_WAIT_VMCNT(12); else SDM_WAIT_VMCNT(16);
-            } else {
-              // the other A buffer was last read in chunk c-1; the transform (GroupNorm, SiLU, hi / fp8 split) of the next chunk is
-              // spread over the remaining four steps so that no step's barrier waits for it
-              if (k >= 2 && more) {
-                unsigned char* An = Aring + ((c + 1) & 1) * 2 * C::A_BYTES;
-                if (k == 2) write_lds_a_f8(An, 0, 2);
-                else if (k == 3) write_lds_a_f8(An, 2, 4);
-                else if (k == 4) write_lds_a_f8(An, 4, 5);
-                else write_lds_a_f8(An, 5, A_PER);
-              }
-              SDM_WAIT_VMCNT0();
             }
+            // the other A buffer was last read in chunk c-1: one vector of the next chunk's transform (GroupNorm, SiLU, hi / fp8
+            // split) per step, so that no step's barrier waits for the producers
+            if (more) write_lds_a_f8(Aring + ((c + 1) & 1) * 2 * C::A_BYTES, k, k + 1);
+            if (fly) { if (AFLY == 12) SDM_WAIT_VMCNT(12); else SDM_WAIT_VMCNT(16); }
+            else SDM_WAIT_VMCNT0();
             SDM_WAIT_LGKMCNT0();
             SDM_RAW_BARRIER();
           }
