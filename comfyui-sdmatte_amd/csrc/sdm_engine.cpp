@@ -1009,7 +1009,7 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
       // 8-wave blocks (256 queries share every K / V^T tile: half the L2 / Infinity-Cache traffic and LDS staging per MFMA) only
       // where they measured faster: the split-precision variant with >= 4 such blocks per CU (B=4 h=5 L=16384: 4.01 vs 4.25 ms;
       // h=10 Lq=4096: 2.39 vs 2.24 ms, i.e. slower; the fp16 variant is neutral to -10 %) - profiles/r02_ablate_attn_nw8.txt
-      static const char* force_nw = getenv("SDM_ATTN_NW");          // A/B hook: "4" or "8"
+      const char* force_nw = getenv("SDM_ATTN_NW");                 // A/B / test hook: "4" or "8" (read per launch)
       const bool nw8 = force_nw ? (force_nw[0] == '8') : (ap.prec && (long)B * heads * sdm_cdiv(Lq, 256) >= 1024);
       const int qrows = nw8 ? 256 : 128;
       p.batch = B; p.heads = heads; p.nq_blocks = sdm_cdiv(Lq, qrows); p.q_chunks = 8;     // B*heads*8 units: always a multiple of 8
@@ -2317,6 +2317,27 @@ int sdm_op_attention(sdm_ctx* e, const void* q, int ldq, const void* k, int ldk,
     }
     int rc = op_attention_raw(e, (const half_t*)q, ldq, (const half_t*)k, ldk, (const half_t*)v, ldv, bias ? bl2 : nullptr,
                               B, heads, Lq, Lk, D, (half_t*)out, ldo);
+    tfree(e, b2);
+    return rc;
+  });
+}
+
+/* Split-precision d = 64 attention (the default precision's attention cores): q / k / v arrive as two fp16 planes hi | lo (the lo plane
+ * `*_lo_off` ELEMENTS behind the hi plane, same strides), the output is fp32.  Test hook for the kernel the engine runs. */
+int sdm_op_attention_split(sdm_ctx* e, const void* q, int ldq, long q_lo_off, const void* k, int ldk, long k_lo_off, const void* v, int ldv,
+                           long v_lo_off, const float* bias, int B, int heads, int Lq, int Lk, float* out, int ldo) {
+  if (e) dev_use(e->device);
+  if (!e || !q || !k || !v || !out) return SDM_ERR_INVALID;
+  return run_two_pass(e, [&]() {
+    T b2 = talloc(e, B, 1, 1, Lk, 1);
+    const float* bl2 = nullptr;
+    if (bias) {
+      bl2 = (const float*)b2.p;
+      if (!e->dry) SDM_LAUNCH(scale_copy_kernel, dim3(sdm_cdiv(B * Lk, 256)), dim3(256), 0, e->stream, bias, (float*)b2.p, (long)B * Lk, SDM_LOG2E);
+    }
+    AttnPrec ap; ap.prec = 1; ap.q_lo = q_lo_off; ap.k_lo = k_lo_off; ap.v_lo = v_lo_off; ap.out_f32 = 1;
+    int rc = op_attention_raw(e, (const half_t*)q, ldq, (const half_t*)k, ldk, (const half_t*)v, ldv, bias ? bl2 : nullptr, B, heads, Lq, Lk, 64,
+                              out, ldo, false, nullptr, ap);
     tfree(e, b2);
     return rc;
   });

@@ -83,7 +83,7 @@ EXPORTS = [
     "sdm_weight_stats", "sdm_missing_key", "sdm_weight_blob_bytes", "sdm_export_weight_blob", "sdm_import_weight_blob",
     "sdm_host_blob_bytes", "sdm_export_host_blob", "sdm_import_host_blob", "sdm_forward", "sdm_forward_ex", "sdm_forward_rect", "sdm_apply_matte", "sdm_apply_matte_node",
     "sdm_synchronize", "sdm_release_memory", "sdm_resident_bytes", "sdm_last_forward_ms", "sdm_profile_enable", "sdm_profile_count", "sdm_profile_get", "sdm_profile_dump",
-    "sdm_op_conv", "sdm_op_conv_ex", "sdm_debug_run_layer", "sdm_debug_temb_row", "sdm_conv_num_cfgs", "sdm_bench_conv", "sdm_bench_attn", "sdm_op_groupnorm", "sdm_op_layernorm", "sdm_op_attention", "sdm_op_resize_aa",
+    "sdm_op_conv", "sdm_op_conv_ex", "sdm_debug_run_layer", "sdm_debug_temb_row", "sdm_conv_num_cfgs", "sdm_bench_conv", "sdm_bench_attn", "sdm_op_groupnorm", "sdm_op_layernorm", "sdm_op_attention", "sdm_op_attention_split", "sdm_op_resize_aa",
     "sdm_op_mask_bias",
 ]
 
@@ -135,6 +135,7 @@ class Bindings:
             "sdm_op_groupnorm": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, f32, i32, vp]),
             "sdm_op_layernorm": (i32, [vp, vp, i32, C.c_long, i32, vp, vp, f32, vp]),
             "sdm_op_attention": (i32, [vp, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32]),
+            "sdm_op_attention_split": (i32, [vp, vp, i32, C.c_long, vp, i32, C.c_long, vp, i32, C.c_long, vp, i32, i32, i32, i32, vp, i32]),
             "sdm_op_resize_aa": (i32, [vp, vp, i32, i32, i32, vp, i32, i32]),
             "sdm_op_mask_bias": (i32, [vp, vp, i32, i32, i32, vp]),
         }
@@ -420,6 +421,20 @@ class Engine:
         out = torch.empty(B, Lq, HD, dtype=torch.float16, device=q.device)
         self._check(self.lib.sdm_op_attention(self.h, _ptr(q), q.stride(1), _ptr(k), k.stride(1), _ptr(v), v.stride(1), _ptr(bias), B,
                                               heads, Lq, Lk, D, _ptr(out), HD), "sdm_op_attention")
+        return out
+
+    def op_attention_split(self, q, k, v, heads, bias=None):
+        """Split-precision attention cores (head dim 64): q [B,Lq,h*64], k / v [B,Lk,h*64] fp32; they are split into fp16 planes
+        hi | lo here, as the producing GEMM's epilogue does in the engine; fp32 output."""
+        def planes(x):
+            hi = x.half()
+            return torch.stack([hi, (x - hi.float()).half()]).contiguous()
+        B, Lq, HD = q.shape
+        Lk = k.shape[1]
+        qp, kp, vp_ = planes(q.float()), planes(k.float()), planes(v.float())
+        out = torch.empty(B, Lq, HD, dtype=torch.float32, device=q.device)
+        self._check(self.lib.sdm_op_attention_split(self.h, _ptr(qp), HD, qp[0].numel(), _ptr(kp), HD, kp[0].numel(), _ptr(vp_), HD, vp_[0].numel(),
+                                                    _ptr(bias), B, heads, Lq, Lk, _ptr(out), HD), "sdm_op_attention_split")
         return out
 
     def op_resize_aa(self, planes, Hout, Wout):

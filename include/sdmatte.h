@@ -214,6 +214,9 @@ int sdm_op_layernorm(sdm_ctx* ctx, const void* x, int in_f32, long rows, int C, 
  * every tile; setting the environment variable SDM_ATTN_DENSE disables the skip. */
 int sdm_op_attention(sdm_ctx* ctx, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* bias,
                      int B, int heads, int Lq, int Lk, int D, void* out, int ldo);
+/* Split-precision attention cores (head dim 64): q / k / v as fp16 planes hi | lo (lo plane `*_lo_off` elements behind), fp32 output. */
+int sdm_op_attention_split(sdm_ctx* ctx, const void* q, int ldq, long q_lo_off, const void* k, int ldk, long k_lo_off, const void* v, int ldv,
+                           long v_lo_off, const float* bias, int B, int heads, int Lq, int Lk, float* out, int ldo);
 /* Antialiased bilinear resize of fp32 planes [P, Hin, Win] -> [P, Hout, Wout] (torchvision Resize). */
 int sdm_op_resize_aa(sdm_ctx* ctx, const float* in, int P, int Hin, int Win, float* out, int Hout, int Wout);
 /* Level-k additive key bias (natural-log domain) from the [-1,1] trimap plane [B,S,S] -> [B,(S/8>>k)^2]. */

@@ -131,7 +131,7 @@ def check_layernorm(eng, dev, rows, C, in_f32=True, seed=0, atol=4e-3):
     return err
 
 
-def check_attention(eng, dev, B, heads, Lq, Lk, D, use_bias, seed=0, atol=3e-3, fused_stride=False, spike=False, blocks=False):
+def check_attention(eng, dev, B, heads, Lq, Lk, D, use_bias, seed=0, atol=3e-3, fused_stride=False, spike=False, blocks=False, split=False):
     g = _g(seed)
     q = h16(torch.randn(B, Lq, heads * D, generator=g))
     k = h16(torch.randn(B, Lk, heads * D, generator=g))
@@ -172,7 +172,16 @@ def check_attention(eng, dev, B, heads, Lq, Lk, D, use_bias, seed=0, atol=3e-3, 
         qd, kd, vd = buf[:, :Lq, :heads * D], buf[:, :Lk, heads * D:2 * heads * D], buf[:, :Lk, 2 * heads * D:]
     else:
         qd, kd, vd = q.half().to(dev), k.half().to(dev), v.half().to(dev)
-    out = eng.op_attention(qd, kd, vd, heads, bias.to(dev) if bias is not None else None)
+    if split:
+        # the default precision's kernel: Q.K^T on hi | lo operand pairs, P.V on fp16; un-rounded fp32 q / k / v in, fp32 out
+        qs, ks, vs = torch.randn(B, Lq, heads * D, generator=g), torch.randn(B, Lk, heads * D, generator=g), torch.randn(B, Lk, heads * D, generator=g)
+        s2 = torch.matmul(qs.view(B, Lq, heads, D).permute(0, 2, 1, 3).double(), ks.view(B, Lk, heads, D).permute(0, 2, 1, 3).double().transpose(-1, -2)) * scale
+        if bias is not None:
+            s2 = s2 + bias[:, None, None, :].double()
+        ref = torch.matmul(s2.softmax(-1), vs.view(B, Lk, heads, D).permute(0, 2, 1, 3).double()).permute(0, 2, 1, 3).reshape(B, Lq, heads * D).float()
+        out = eng.op_attention_split(qs.to(dev), ks.to(dev), vs.to(dev), heads, bias.to(dev) if bias is not None else None)
+    else:
+        out = eng.op_attention(qd, kd, vd, heads, bias.to(dev) if bias is not None else None)
     err = (out.float().cpu() - ref).abs().max().item()
     assert err < atol, f"attention mismatch {err:.4g} (B={B} h={heads} Lq={Lq} Lk={Lk} D={D} bias={use_bias})"
     return err

@@ -135,6 +135,17 @@ def test_attention_d64(emu_engine):
     S.check_attention(emu_engine, DEV, 1, 1, 32, 192, 64, use_bias=False, spike=True, seed=3)
 
 
+def test_attention_d64_split_precision(emu_engine, monkeypatch):
+    """The default precision's attention cores: Q.K^T on split operands (the logits feed an exponential), P.V on plain fp16 operands
+    (PREC = 2), fp32 in / out; and the fully split form (PREC = 1, SDM_ATTN_PV_SPLIT=1).  Against un-rounded fp64 attention: the
+    fp16-operand kernel sits at ~2e-3 on these inputs."""
+    e2 = S.check_attention(emu_engine, DEV, 1, 2, 70, 100, 64, use_bias=True, split=True, atol=6e-4)
+    S.check_attention(emu_engine, DEV, 2, 1, 33, 200, 64, use_bias=False, split=True, seed=4, atol=6e-4)
+    monkeypatch.setenv("SDM_ATTN_PV_SPLIT", "1")
+    e1 = S.check_attention(emu_engine, DEV, 1, 2, 70, 100, 64, use_bias=True, split=True, atol=3e-5)
+    assert e1 < e2
+
+
 def test_attention_d64_skips_underflowing_key_tiles(emu_engine, monkeypatch):
     # trimap-like bias with whole key tiles at -5000 / -10000: those tiles are never loaded; the result must equal the fp32
     # reference (where their probabilities underflow to 0) AND be bit-identical to walking every tile
