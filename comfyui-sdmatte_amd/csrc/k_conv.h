@@ -97,7 +97,8 @@ struct ConvCfg {
   static constexpr int STG_BYTES = WM * WN * 32 * WTN * 4;
   // DMAB (weights by LDS-DMA): two A tiles (fp16: double buffer; SPLIT: hi | lo) + a ring of 4 weight stages, one stage = the 3 taps
   // of one kernel column dx for BN output channels in half-plane layout (2 x 3 x BN rows of 16 B)
-  static constexpr int DMA_SLOT = 96 * BN, DMA_SLOTS = F8 ? 6 : (PC ? 5 : 4);      // PC: weights land TWO stages ahead of their use (fragment prefetch across the barrier)
+  // one weight unit: 2 planes x (3 taps dy | 1) x BN rows of 16 B.  F8 rings: 3x3 = 3 steps x 2 units, 1x1 = 3 steps (chunks) x 4 units
+  static constexpr int DMA_SLOT = (NTAPS == 9 ? 96 : 32) * BN, DMA_SLOTS = F8 ? (NTAPS == 9 ? 6 : 12) : (PC ? 5 : 4);      // PC: weights land TWO stages ahead of their use (fragment prefetch across the barrier)
   static constexpr int TILE_BYTES = DMAB ? (PC ? 4 : 2) * A_BYTES + DMA_SLOTS * DMA_SLOT
                                          : (SPLIT ? 2 : 1) * A_BYTES + B_BYTES;   // one K-chunk of A halo (SPLIT: high and low parts) + B taps
   static constexpr int SMEM = ((DB ? 2 : 1) * TILE_BYTES) > STG_BYTES ? ((DB ? 2 : 1) * TILE_BYTES) : STG_BYTES;
@@ -105,7 +106,8 @@ struct ConvCfg {
   static_assert(KC % 16 == 0, "KC multiple of the MFMA K (16)");
   static_assert(!DB || KC == 16, "swizzled double-buffered tiles assume 2 halves per row");
   static_assert(!(DB && SPLIT), "the split-operand kernels use the single-buffered tile");
-  static_assert(!DMAB || (NTAPS == 9 && STRIDE == 1 && TW == 32 && (KC == 16 || (F8 && KC == 32)) && BN == 128 && WM * WN == 4 && !DB), "DMA-weight pipeline: 256 x 128 tile only");
+  static_assert(!DMAB || (((NTAPS == 9 && (KC == 16 || (F8 && KC == 32))) || (NTAPS == 1 && F8 && KC == 32)) && STRIDE == 1 && TW == 32 && BN == 128 && WM * WN == 4 && !DB),
+                "DMA-weight pipeline: 256 x 128 tile only");
   static_assert(!F8 || (PC && KC == 32), "fp8-residual form: producer / consumer kernel on 32-channel chunks");
   static_assert(!PC || (DMAB && SPLIT), "producer/consumer form: split-precision DMA-weight kernel only");
 };
@@ -568,7 +570,7 @@ conv_mfma_kernel(ConvParams p) {
       constexpr float F8_XS = 4.0f, F8_LS = 4.0f * 2048.0f;           // x8 = e4m3(x * 2^2), x_lo8 = e4m3(x_lo * 2^13)
       const int nch = Cin / 32, nsteps = nch * 6;
       auto mod3 = [](int x) { return x >= 6 ? x - 6 : (x >= 3 ? x - 3 : x); };
-      const sdm_rsrc rs8 = sdm_make_rsrc(p.w_dma, (unsigned int)((size_t)Cin * 9 * p.Cout_pad * 4));
+      const sdm_rsrc rs8 = sdm_make_rsrc(p.w_dma, (unsigned int)((size_t)Cin * NTAPS * p.Cout_pad * 4));
       // 24 pieces of 1 KB per step: piece q = (unit, plane, dy, 64-channel half); this wave issues pieces 6*wave .. 6*wave+5
       auto dma_step = [&](int t, int sl) {
         unsigned char* dst = Bring + sl * STEP;
@@ -626,7 +628,7 @@ conv_mfma_kernel(ConvParams p) {
         }
       };
       constexpr int AFLY = A_PER * (IN_F32 ? 2 : 1) + (GN ? 4 : 0);      // register loads that may stay in flight behind a step's DMAs
-      static_assert(!F8 || AFLY == 12 || AFLY == 16, "counted wait below");
+      static_assert(!F8 || NTAPS == 1 || AFLY == 12 || AFLY == 16, "counted wait below");
       // activations (and GroupNorm coefficients) of the chunk AFTER the next one: loaded a whole chunk before they are transformed, so
       // that the transform of the next chunk can be spread evenly over the six steps of the current one (one vector per step)
       u32x4 a_nx[A_PER][IN_F32 ? 2 : 1];
@@ -653,6 +655,107 @@ conv_mfma_kernel(ConvParams p) {
         for (int i = 0; i < A_PER; ++i) { a_raw[i][0] = a_nx[i][0]; if (IN_F32) a_raw[i][IN_F32 ? 1 : 0] = a_nx[i][IN_F32 ? 1 : 0]; }
         if (GN) { gq[0] = gqn[0]; gq[1] = gqn[1]; gq[2] = gqn[2]; gq[3] = gqn[3]; }
       };
+      if (NTAPS == 1) {
+        // ---- 1x1 / Linear GEMM in the same form.  One step = one 32-channel chunk = four 4 KB weight units (w_hi ch 0-15 | w_hi
+        // ch 16-31 | w8 | w_lo8): 16 fp16 MFMAs + 8 fp8 K64 MFMAs per wave, one barrier.  No operand reuse across taps here: the
+        // producers convert a 32 KB activation tile per 1024 MFMA cycles and set the pace (the 4-wave kernel did the same conversion
+        // inside its MFMA waves, between four barriers per chunk). ----
+        constexpr int PLANE1 = BN * 16, STEP1 = 4 * SLOT;
+        static_assert(NTAPS != 1 || !F8 || A_PER == 4, "1x1 F8: four vectors per producer thread and chunk");
+        auto dma_step1 = [&](int t, int sl) {      // 16 pieces of 1 KB: (unit, plane, 64-channel half); this wave issues 4
+          unsigned char* dst = Bring + sl * STEP1;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int q = wv * 4 + k, u = q >> 2, pl = (q >> 1) & 1, ch = q & 1;
+            const unsigned int row = (unsigned int)((t * 4 + u) * 2 + pl);
+            sdm_glds16_buf(rs8, dma_voff + (unsigned int)(ch * 1024), row * stage_rows, dst + u * SLOT + pl * PLANE1 + ch * 1024);
+          }
+        };
+        if (role) {
+          dma_step1(0, 0);
+          if (1 < nch) dma_step1(1, 1);
+          SDM_SCHED_FENCE();
+          issue_loads_a(0);
+          write_lds_a_f8(Aring, 0, A_PER);
+          SDM_WAIT_VMCNT0();
+          if (nch > 1) { issue_loads_nx(32); SDM_SCHED_FENCE(); }
+        }
+        SDM_WAIT_LGKMCNT0();
+        SDM_RAW_BARRIER();
+        if (role) {
+          int sl = 2;                   // ring slot of chunk c+2
+          for (int c = 0; c < nch; ++c) {
+            const bool more = c + 1 < nch, fly = c + 2 < nch;
+            if (more) take_nx();
+            SDM_SCHED_FENCE();
+            if (fly) { dma_step1(c + 2, sl); SDM_SCHED_FENCE(); issue_loads_nx((c + 2) * 32); SDM_SCHED_FENCE(); }
+            if (more) write_lds_a_f8(Aring + ((c + 1) & 1) * 2 * C::A_BYTES, 0, A_PER);
+            if (fly) SDM_WAIT_VMCNT(8); else SDM_WAIT_VMCNT0();
+            SDM_WAIT_LGKMCNT0();
+            SDM_RAW_BARRIER();
+            sl = sl == 2 ? 0 : sl + 1;
+          }
+        } else {
+          const int sa8 = p.f8_sa, sb8 = p.f8_sb;
+          f16x8 fbh[2][NTL];
+          i32x8 fb8[NTL];
+          int bq1[NTL], a8b[MT];
+#pragma unroll
+          for (int j = 0; j < NTL; ++j) bq1[j] = (wn * WTN + j * 32 + (lane & 31)) * 16;
+#pragma unroll
+          for (int i = 0; i < MT; ++i) a8b[i] = abase[i] - (lane >> 5) * A_HALF + (lane >> 5) * 2 * A_HALF;
+          auto ld_b = [&](const unsigned char* Bp) {
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+              fbh[0][j] = *(const f16x8*)(Bp + (lane >> 5) * PLANE1 + bq1[j]);
+              fbh[1][j] = *(const f16x8*)(Bp + SLOT + (lane >> 5) * PLANE1 + bq1[j]);
+              const unsigned char* q = Bp + (2 + (lane >> 5)) * SLOT + bq1[j];
+              const i32x4 q0 = *(const i32x4*)q, q1 = *(const i32x4*)(q + PLANE1);
+              fb8[j] = i32x8{q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+            }
+          };
+          ld_b(Bring);
+          int sl = 1;                   // ring slot of chunk c+1
+          for (int c = 0; c < nch; ++c) {
+            const unsigned char* Ab = Aring + (c & 1) * 2 * C::A_BYTES;
+            f16x8 ah[2][MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) ah[0][i] = *(const f16x8*)(Ab + abase[i]);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) ah[1][i] = *(const f16x8*)(Ab + abase[i] + 2 * A_HALF);
+            SDM_SCHED_FENCE();
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+              for (int j = 0; j < NTL; ++j) acc[i][j] = SDM_MFMA_32x32x16_F16(ah[0][i], fbh[0][j], acc[i][j]);
+            i32x8 a8[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+              const unsigned char* q = Ab + C::A_BYTES + a8b[i];
+              const i32x4 q0 = *(const i32x4*)q, q1 = *(const i32x4*)(q + A_HALF);
+              a8[i] = i32x8{q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+            }
+            SDM_SCHED_FENCE();
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+              for (int j = 0; j < NTL; ++j) acc[i][j] = SDM_MFMA_32x32x16_F16(ah[1][i], fbh[1][j], acc[i][j]);
+            SDM_SCHED_FENCE();
+            // the residual pair of this chunk; the fp16 fragments of the NEXT chunk's weights (landed one barrier ago) are read underneath
+            i32x8 fb8c[NTL];
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) fb8c[j] = fb8[j];
+            if (c + 1 < nch) ld_b(Bring + sl * STEP1);
+            SDM_SCHED_FENCE();
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+              for (int j = 0; j < NTL; ++j) acc[i][j] = SDM_MFMA_32x32x64_F8(a8[i], fb8c[j], acc[i][j], sa8, sb8);
+            SDM_RAW_BARRIER();
+            sl = sl == 2 ? 0 : sl + 1;
+          }
+        }
+      } else {
       if (role) {
         dma_step(0, 0);
         if (1 < nsteps) dma_step(1, 1);
@@ -788,6 +891,7 @@ conv_mfma_kernel(ConvParams p) {
           }
         }
       }
+      }   // NTAPS == 9
     } else if (PC) {
       // ---- producer / consumer form: same stages and barriers for both roles, disjoint instruction streams.
       // Invariant: when the barrier that ends stage t releases, the weights of stage t+2 have landed (ring of 5, DMAs 4 stages
@@ -1255,20 +1359,26 @@ __global__ void pack_conv_weight_dma_kernel(const float* __restrict__ w, half_t*
 // [plane][dy][Cout_pad][16 B]:  unit 0 / 1 = fp16 high parts of channels 0-15 / 16-31 (plane = 8-channel half, 8 halfs per row),
 // unit 2 = e4m3(v) (plane = channels 0-15 | 16-31, one byte per channel), unit 3 = e4m3((v - hi) * 2^11), with v = w * scale.
 // Same number of bytes as the hi | lo fp16 pair (4 per weight).  Values beyond +-448 are clamped (v = w * 2^8: |w| > 1.75).
+// ntaps == 1 (Linear / 1x1): the same without the dx / dy dimensions - [chunk32][unit][plane][Cout_pad][16 B]; as in
+// pack_conv_weight_kernel only the rows [co_off, co_off + O) of the packed layer (all rows for GEGLU) are written (fused q|k|v
+// layers are packed by three calls; the arena is zero-initialised).
 __global__ void pack_conv_weight_f8_kernel(const float* __restrict__ w, unsigned char* __restrict__ wd, int O, int I, int Cin_pad, int Cout_pad,
-                                           int ci_off, float scale) {
-  const size_t total = (size_t)(Cin_pad / 32) * 3 * 4 * 2 * 3 * Cout_pad;         // 16-byte rows
+                                           int ci_off, float scale, int ntaps, int co_off, int geglu) {
+  const int nd = ntaps == 9 ? 3 : 1;
+  const size_t total = (size_t)(Cin_pad / 32) * nd * 4 * 2 * nd * Cout_pad;         // 16-byte rows
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     size_t t = idx;
     const int co = t % Cout_pad; t /= Cout_pad;
-    const int dy = t % 3; t /= 3;
+    const int dy = t % nd; t /= nd;
     const int pl = t % 2; t /= 2;
     const int u = t % 4; t /= 4;
-    const int dx = t % 3;
-    const int chunk = (int)(t / 3);
+    const int dx = t % nd;
+    const int chunk = (int)(t / nd);
+    const int srow = (ntaps == 9) ? (co < O ? co : -1) : pack_src_row(co, O, co_off, geglu);
+    if (ntaps != 9 && srow < 0) continue;                                            // another slot's rows / padding: leave
     auto wv = [&](int c) {
       const int ci = c - ci_off;
-      return (co < O && ci >= 0 && ci < I) ? w[((size_t)co * I + ci) * 9 + dy * 3 + dx] * scale : 0.0f;
+      return (srow >= 0 && ci >= 0 && ci < I) ? w[((size_t)srow * I + ci) * ntaps + (ntaps == 9 ? dy * 3 + dx : 0)] * scale : 0.0f;
     };
     unsigned char* dst = wd + idx * 16;
     if (u < 2) {

@@ -261,6 +261,24 @@ static void launch_conv_dma(const ConvParams& p_in, void* stream) {
 #undef SDM_DMA_CASE
 }
 
+// Linear / 1x1 GEMM, 256 rows x 128 channels, fp8-residual producer / consumer kernel (k_conv.h, F8 with NTAPS = 1)
+static void launch_gemm_f8(const ConvParams& p_in, void* stream) {
+  using CD = ConvCfg<1, 1, 8, 32, 128, 32, 2, 2, 0, 1, 1, 1, 1>;
+  ConvParams p = p_in;
+  p.tiles_m = (int)(((p.rows_per_img ? (long)p.rows_per_img : p.M) + CD::BM - 1) / CD::BM);
+  p.tiles_n = sdm_cdiv(p.Cout_pad, 128);
+  const long total_m = (long)p.tiles_m * (p.rows_per_img ? p.N : 1);
+  p.xcd_chunk = (int)((total_m + 7) / 8);
+  const unsigned vg = (unsigned)(8L * p.xcd_chunk * p.tiles_n);
+  p.vgrid = (int)vg;
+  p.tpb = conv_f8_tiles_per_block((long)vg);
+  unsigned pg = (vg + p.tpb - 1) / p.tpb;
+  pg = (pg + 7) & ~7u;
+  auto k = conv_mfma_kernel<1, 1, 8, 32, 128, 32, 2, 2, 1, 0, 0, 1, 1, 1, 1>;
+  SDM_SET_SMEM(k, 160 * 1024);
+  SDM_LAUNCH(k, dim3(pg, 1, 1), dim3(CD::LAUNCH_THREADS), (size_t)CD::SMEM, stream, p);
+}
+
 static int launch_conv(int ntaps, int stride, int cfg, const ConvParams& p, void* stream) {
   if (ntaps == 9 && stride == 1) {
     switch (cfg) {
@@ -286,7 +304,9 @@ static int launch_conv(int ntaps, int stride, int cfg, const ConvParams& p, void
       case 1: launch_conv_t<1, 1, 4, 32, 64, 64, 4, 1>(p, stream); return 0;
       case 2: launch_conv_t<1, 1, 8, 8, 64, 64, 2, 1>(p, stream); return 0;
       case 3: launch_conv_t<1, 1, 8, 8, 64, 16, 2, 1>(p, stream); return 0;
-      case 4: launch_conv_t<1, 1, 8, 32, 128, 32, 2, 2>(p, stream); return 0;
+      case 4:
+        if (p.f8 && p.w_dma) { launch_gemm_f8(p, stream); return 0; }
+        launch_conv_t<1, 1, 8, 32, 128, 32, 2, 2>(p, stream); return 0;
     }
   }
   return -1;
@@ -300,6 +320,16 @@ static int launch_conv(int ntaps, int stride, int cfg, const ConvParams& p, void
 static bool conv_f8_enabled() {
   const char* v = getenv("SDM_CONV_F8");
   return !(v && v[0] == '0');
+}
+
+static bool gemm_f8_enabled() {
+  const char* v = getenv("SDM_GEMM_F8");
+  return !(v && v[0] == '0');
+}
+
+static int gemm_f8_min_k() {
+  const char* v = getenv("SDM_GEMM_F8_MIN_K");
+  return v ? atoi(v) : 1024;
 }
 
 struct ConvL {
@@ -482,6 +512,15 @@ struct Builder {
       L.wdma_bytes = (size_t)L.Cin_pad * 9 * L.Cout_pad * 2 * (L.split ? 2 : 1);
       L.wdma_off = woff; woff += rupz(L.wdma_bytes, 256);
       L.f8 = (L.split && L.Cin_pad % 32 == 0 && conv_f8_enabled()) ? 1 : 0;      // same bytes, fp8-residual layout
+    }
+    // Linear / 1x1 layers of the split-precision stages with K >= 1024: fp8-residual copy for the 8-wave GEMM kernel (k_conv.h, F8
+    // with NTAPS = 1), used when the launch takes the 256 x 128 tile; SDM_GEMM_F8=0 disables.  A GEMM has no operand reuse across
+    // taps, so the producer waves (one 32 KB activation tile converted per 1024 MFMA cycles) set the pace: measured against the
+    // 4-wave kernel x1.2-1.5 for K = 1280 ... 5120, x0.84-1.0 for K <= 640 (profiles/r02_gemm_f8_ab.txt) - hence the threshold
+    if (ntaps == 1 && L.split && L.Cout_pad >= 128 && L.Cin_pad % 32 == 0 && L.Cin_pad >= gemm_f8_min_k() && conv_f8_enabled() && gemm_f8_enabled()) {
+      L.wdma_bytes = (size_t)L.Cin_pad * L.Cout_pad * 4;
+      L.wdma_off = woff; woff += rupz(L.wdma_bytes, 256);
+      L.f8 = 1;
     }
     e->convs.push_back(L);
     return (int)e->convs.size() - 1;
@@ -831,6 +870,7 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
     const int pc_min_cin = getenv("SDM_CONV_PC_MIN_CIN") ? atoi(getenv("SDM_CONV_PC_MIN_CIN")) : 256;
     if (p.w_dma && L.split) p.pc = pc_env ? (pc_env[0] == '1') : (L.Cin_pad >= pc_min_cin);
     if (p.w_dma && L.f8) { p.f8 = 1; p.f8_sa = 127 - 13; p.f8_sb = 127; }      // x_lo8 = x_lo * 2^13, x8 * w_lo8 = (x * 2^2)(w_lo * 2^11): both 2^13 too large
+    if (L.ntaps == 1 && L.f8 && L.w_dma && cfg == 4 && p.in_f32 && gemm_f8_enabled()) { p.w_dma = L.w_dma; p.f8 = 1; p.f8_sa = 127 - 13; p.f8_sb = 127; }
   }
   if (e->dry) return 0;
   const double flops = 2.0 * (double)p.M * L.O * L.I * L.ntaps;
@@ -1792,7 +1832,8 @@ int sdm_load_tensor(sdm_ctx* e, const char* name, int dtype, int ndim, const int
       if (L.w_dma && L.f8) {
         const size_t rows = total / 4;       // 16-byte rows: 4 bytes per weight
         SDM_LAUNCH(pack_conv_weight_f8_kernel, dim3((unsigned)std::min<size_t>((rows + 255) / 256, 65535)), dim3(256), 0, e->stream,
-                   (const float*)dsrc, (unsigned char*)L.w_dma, O, I, L.Cin_pad, L.Cout_pad, s.ci_off, s.w_scale * ldexpf(1.0f, L.w_exp));
+                   (const float*)dsrc, (unsigned char*)L.w_dma, O, I, L.Cin_pad, L.Cout_pad, s.ci_off, s.w_scale * ldexpf(1.0f, L.w_exp), L.ntaps,
+                   s.co_off, L.geglu);
       } else if (L.w_dma) {
         const size_t tot2 = total * (L.split ? 2 : 1);
         SDM_LAUNCH(pack_conv_weight_dma_kernel, dim3((unsigned)std::min<size_t>((tot2 + 255) / 256, 65535)), dim3(256), 0, e->stream,
@@ -1859,7 +1900,7 @@ static int fold_cross_kv(sdm_ctx* e) {
                L.w, 2 * C, 4, 9, L.Cin_pad, L.Cout_pad, 4, 0, 0, ldexpf(1.0f, L.w_exp), L.w_lo);
     if (L.w_dma && L.f8)
       SDM_LAUNCH(pack_conv_weight_f8_kernel, dim3((unsigned)std::min<size_t>((total / 4 + 255) / 256, 65535)), dim3(256), 0, e->stream,
-                 (const float*)e->stage, (unsigned char*)L.w_dma, 2 * C, 4, L.Cin_pad, L.Cout_pad, 4, ldexpf(1.0f, L.w_exp));
+                 (const float*)e->stage, (unsigned char*)L.w_dma, 2 * C, 4, L.Cin_pad, L.Cout_pad, 4, ldexpf(1.0f, L.w_exp), 9, 0, 0);
     else if (L.w_dma)
       SDM_LAUNCH(pack_conv_weight_dma_kernel, dim3((unsigned)std::min<size_t>((total * (L.split ? 2 : 1) + 255) / 256, 65535)), dim3(256), 0, e->stream,
                  (const float*)e->stage, L.w_dma, 2 * C, 4, L.Cin_pad, L.Cout_pad, 4, ldexpf(1.0f, L.w_exp), L.split ? 2 : 1);
@@ -2076,10 +2117,17 @@ int sdm_op_conv_ex(sdm_ctx* e, const void* in0, const void* in1, int C0, int C1,
     L.f8 = (split && L.Cin_pad % 32 == 0 && conv_f8_enabled()) ? 1 : 0;
     if (L.f8)
       SDM_LAUNCH(pack_conv_weight_f8_kernel, dim3((unsigned)std::min<size_t>((total / 4 + 255) / 256, 65535)), dim3(256), 0, e->stream, w,
-                 (unsigned char*)L.w_dma, O, L.I, L.Cin_pad, L.Cout_pad, 0, ldexpf(1.0f, L.w_exp));
+                 (unsigned char*)L.w_dma, O, L.I, L.Cin_pad, L.Cout_pad, 0, ldexpf(1.0f, L.w_exp), ntaps, 0, geglu);
     else
     SDM_LAUNCH(pack_conv_weight_dma_kernel, dim3((unsigned)std::min<size_t>((tot2 + 255) / 256, 65535)), dim3(256), 0, e->stream, w, L.w_dma, O, L.I,
                L.Cin_pad, L.Cout_pad, 0, ldexpf(1.0f, L.w_exp), split ? 2 : 1);
+  }
+  if (ntaps == 1 && split && L.Cout_pad >= 128 && L.Cin_pad % 32 == 0 && conv_f8_enabled() && gemm_f8_enabled()) {      // fp8-residual copy for the 8-wave GEMM kernel
+    SDM_CHECK_DEV(e, dev_malloc(&wd, total * 4));
+    dev_memset(wd, 0, total * 4, e->stream);
+    L.w_dma = (half_t*)wd; L.f8 = 1;
+    SDM_LAUNCH(pack_conv_weight_f8_kernel, dim3((unsigned)std::min<size_t>((total / 4 + 255) / 256, 65535)), dim3(256), 0, e->stream, w,
+               (unsigned char*)L.w_dma, O, L.I, L.Cin_pad, L.Cout_pad, 0, ldexpf(1.0f, L.w_exp), 1, 0, geglu);
   }
   int Ho = Hin << up, Wo = Win << up;
   if (stride == 2) { Ho /= 2; Wo /= 2; }
@@ -2216,6 +2264,11 @@ float sdm_bench_conv(sdm_ctx* e, int N, int H, int W, int Cin, int Cout, int nta
   if (split) p.w_lo = (const half_t*)wl;
   p.pc = (split && p.w_dma && pcf) ? 1 : 0;
   if (split && p.w_dma && f8f && L.Cin_pad % 32 == 0) { p.f8 = 1; p.f8_sa = 127 - 13; p.f8_sb = 127; }
+  if (split && ntaps == 1 && f8f && L.Cin_pad % 32 == 0 && L.Cout_pad >= 128) {      // 1x1 GEMM on the fp8-residual kernel (tile cfg 4)
+    if (dev_malloc(&wdm, wbytes * 2)) return -2.f;
+    SDM_LAUNCH(fill_random_f16_kernel, dim3(2048), dim3(256), 0, e->stream, (half_t*)wdm, (long)wbytes, 29u, 0.05f);
+    p.w_dma = (const half_t*)wdm; p.f8 = 1; p.f8_sa = 127 - 13; p.f8_sb = 127;
+  }
   if (gnf) { p.gn_scale = (const float*)gnt; p.gn_shift = (const float*)gnt + (size_t)N * L.Cin_pad; p.gn_silu = 1; }
   int cfg = tile_cfg >= 0 ? tile_cfg : conv_pick_cfg(ntaps, stride, p);
   hipEvent_t e0, e1;

@@ -112,6 +112,14 @@ def test_gemm_all_tile_cfgs(emu_engine, cfg):
     S.check_conv(emu_engine, DEV, 1, 7, 11, cin, 72, ntaps=1, tile_cfg=cfg, res="f32", out_f32=True, seed=20 + cfg)
 
 
+def test_gemm_fp8_residual_terms(emu_engine):
+    """Linear / 1x1 GEMM on the 8-wave fp8-residual kernel (F8 with NTAPS = 1, tile cfg 4): 1 / 2 / 5 chunks of 32 channels, ragged
+    rows and output-channel tiles, residual, GEGLU epilogue, several tiles per block."""
+    S.check_conv(emu_engine, DEV, 1, 7, 11, 32, 128, ntaps=1, tile_cfg=4, in_f32=True, out_f32=True, split=True, f8=True, seed=80, atol=3e-4)
+    S.check_conv(emu_engine, DEV, 2, 19, 23, 64, 200, ntaps=1, tile_cfg=4, in_f32=True, out_f32=True, split=True, f8=True, res="f32", seed=81, atol=3e-4)
+    S.check_conv(emu_engine, DEV, 1, 9, 33, 160, 256, ntaps=1, geglu=True, tile_cfg=4, in_f32=True, out_f32=True, split=True, f8=True, seed=82, atol=3e-4)
+
+
 def test_gemm_geglu_and_scale(emu_engine):
     S.check_conv(emu_engine, DEV, 1, 5, 13, 64, 256, ntaps=1, geglu=True, tile_cfg=2, seed=30)
     S.check_conv(emu_engine, DEV, 1, 5, 13, 64, 128, ntaps=1, geglu=True, tile_cfg=0, seed=31)

@@ -210,3 +210,13 @@ def test_attention_d64_split_precision(eng, monkeypatch):
     monkeypatch.setenv("SDM_ATTN_PV_SPLIT", "1")
     e1 = S.check_attention(eng, DEV, 2, 5, 300, 1000, 64, use_bias=True, split=True, atol=3e-5)
     print(f"[split attention] P.V fp16: {e2:.2e}  fully split: {e1:.2e}")
+
+
+@pytest.mark.parametrize("M_hw,cin,cout,geglu,res", [((64, 64), 320, 320, False, "f32"), ((33, 70), 64, 200, False, None), ((64, 32), 640, 2560, True, None),
+                                                     ((128, 128), 256, 128, False, "f32")])
+def test_gemm_fp8_residual_terms(eng, M_hw, cin, cout, geglu, res):
+    """Linear / 1x1 GEMM on the 8-wave fp8-residual kernel (F8 with NTAPS = 1, the 256 x 128 tile) against the un-rounded fp32
+    reference."""
+    err = S.check_conv(eng, DEV, 2, M_hw[0], M_hw[1], cin, cout, ntaps=1, tile_cfg=4, in_f32=True, out_f32=True, split=True, f8=True, geglu=geglu,
+                       res=res, seed=cin + cout, atol=3e-4)
+    print(f"[F8 gemm {cin}->{cout}] max|d|={err:.2e}")
