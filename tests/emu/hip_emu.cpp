@@ -148,3 +148,8 @@ void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& bod
   for (auto& t : ts) t.join();
 }
 }  // namespace emu
+
+// test hooks (tests/test_emu_ops.py): the emulator's e4m3 conversion, to be pinned against an independent implementation (torch)
+// and against the hardware probe's outputs (profiles/r02_f8_semantics_probe.txt)
+extern "C" int sdm_emu_f32_to_e4m3(float x) { return (int)emu_f32_to_e4m3(x); }
+extern "C" float sdm_emu_e4m3_to_f32(int v) { return emu_e4m3_to_f32((unsigned char)v); }

@@ -180,3 +180,30 @@ def test_resize_aa(emu_engine):
     S.check_resize(emu_engine, DEV, 2, 37, 53, 64, 64)
     S.check_resize(emu_engine, DEV, 1, 64, 64, 37, 53)
     S.check_resize(emu_engine, DEV, 1, 100, 30, 16, 24)
+
+
+def test_emulated_e4m3_conversion_matches_torch_and_the_hardware_probe():
+    """The emulator's v_cvt_pk_fp8_f32 stand-in (round to nearest even, subnormals, saturation at 448, NaN beyond the rounding range)
+    against torch's float8_e4m3fn on a dense sweep, and against the bytes the MI355X produced for the probe's inputs
+    (tools/probe/f8_semantics_probe.hip -> profiles/r02_f8_semantics_probe.txt)."""
+    from emu.build_emu import build
+    lib = ctypes.CDLL(build())
+    lib.sdm_emu_f32_to_e4m3.argtypes = [ctypes.c_float]
+    lib.sdm_emu_f32_to_e4m3.restype = ctypes.c_int
+    lib.sdm_emu_e4m3_to_f32.argtypes = [ctypes.c_int]
+    lib.sdm_emu_e4m3_to_f32.restype = ctypes.c_float
+    g = torch.Generator().manual_seed(0)
+    x = torch.cat([torch.randn(4000, generator=g) * s for s in (1e-3, 0.05, 1.0, 30.0, 200.0)] + [torch.linspace(-448, 448, 3585)])
+    x = x.clamp(-448, 448)
+    want = x.to(torch.float8_e4m3fn).view(torch.uint8)
+    got = torch.tensor([lib.sdm_emu_f32_to_e4m3(float(v)) for v in x], dtype=torch.uint8)
+    same = (got == want) | ((x == 0) & ((got & 0x7f) == 0) & ((want & 0x7f) == 0))          # +-0
+    assert bool(same.all()), (x[~same][:5], got[~same][:5], want[~same][:5])
+    for v in range(256):                                                                    # decode round trip (0x7f / 0xff are NaN)
+        if (v & 0x7f) != 0x7f:
+            f = lib.sdm_emu_e4m3_to_f32(v)
+            assert lib.sdm_emu_f32_to_e4m3(f) == v or f == 0.0
+    hw = {1.0: 0x38, -1.0: 0xb8, 0.3: 0x2a, 448.0: 0x7e, 449.0: 0x7e, 1000.0: 0x7f, 0.0625: 0x18, 0.001: 0x01, 1.0625: 0x38, 1.1875: 0x3a, 17.0: 0x58,
+          0.0019: 0x01, 464.0: 0x7e, 3.3e-3: 0x02}
+    for f, b in hw.items():
+        assert lib.sdm_emu_f32_to_e4m3(f) == b, (f, hex(lib.sdm_emu_f32_to_e4m3(f)), hex(b))
