@@ -48,13 +48,8 @@ def test_emu_precise_mode_meets_parity_bar(pkg, monkeypatch):
     monkeypatch.setenv("SDM_FORCE_CFG0", "1")
     d0 = (eng.apply_matte(img, tri, 64) - ref).abs()
     assert d0.max().item() <= 1e-3, d0.max().item()
-    # a partial stage mask is accepted too (per-stage attribution) and lands between the two
     eng.close()
-    part = _emu_engine(cfg, E.PRECISE_VAE_ENC | E.PRECISE_UNET_RES)
-    part.load_state_dict(w)
-    dp = (part.apply_matte(img, tri, 64) - ref).abs()
-    part.close()
-    assert dp.mean().item() < dfast.mean().item()
+    # (partial stage masks - the per-stage attribution - run on the GPU: tests/test_gpu_e2e.py::test_e2e_per_stage_precision_attribution)
 
 
 def test_emu_gpu_node_tail_bit_exact_vs_reference_fixture(pkg, golden_dir):
