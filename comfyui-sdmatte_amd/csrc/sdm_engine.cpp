@@ -870,9 +870,10 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
     const int pc_min_cin = getenv("SDM_CONV_PC_MIN_CIN") ? atoi(getenv("SDM_CONV_PC_MIN_CIN")) : 256;
     if (p.w_dma && L.split) p.pc = pc_env ? (pc_env[0] == '1') : (L.Cin_pad >= pc_min_cin);
     if (p.w_dma && L.f8) {
-      // the fp8-residual kernel stages 32-channel chunks: a channel concat must split on a chunk boundary
-      if (p.C1 > 0 && (p.C0 % 32)) SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: concat boundary %d is not a multiple of 32 (fp8-residual kernel)", L.name.c_str(), p.C0);
-      p.f8 = 1; p.f8_sa = 127 - 13; p.f8_sb = 127;      // x_lo8 = x_lo * 2^13, x8 * w_lo8 = (x * 2^2)(w_lo * 2^11): both 2^13 too large
+      // the fp8-residual kernel stages 32-channel chunks: a channel concat that does not split on a chunk boundary takes the
+      // register-staged split kernel (K16 weights) instead
+      if (p.C1 > 0 && (p.C0 % 32)) { p.w_dma = nullptr; p.pc = 0; }
+      else { p.f8 = 1; p.f8_sa = 127 - 13; p.f8_sb = 127; }      // x_lo8 = x_lo * 2^13, x8 * w_lo8 = (x * 2^2)(w_lo * 2^11): both 2^13 too large
     }
     if (L.ntaps == 1 && L.f8 && L.w_dma && cfg == 4 && p.in_f32 && gemm_f8_enabled()) { p.w_dma = L.w_dma; p.f8 = 1; p.f8_sa = 127 - 13; p.f8_sb = 127; }
   }

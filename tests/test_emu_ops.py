@@ -85,6 +85,8 @@ def test_conv3x3_fp8_residual_terms(emu_engine):
     S.check_conv(emu_engine, DEV, 2, 9, 35, 96, 160, tile_cfg=0, in_f32=True, out_f32=True, split=True, f8=True, gn=(1e-6, True), res="f32", seed=7, atol=3e-4)
     S.check_conv(emu_engine, DEV, 1, 6, 20, 32, 128, C1=32, up=1, tile_cfg=0, in_f32=True, out_f32=True, split=True, f8=True, seed=8, atol=3e-4)
     assert e0 < 1e-4, e0          # plain fp16 operands sit at ~1.5e-3 against the un-rounded reference on these inputs
+    # a concat boundary inside a 32-channel chunk (C0 = 48): the layer falls back to the register-staged split kernel
+    S.check_conv(emu_engine, DEV, 1, 6, 20, 48, 128, C1=16, tile_cfg=0, in_f32=True, out_f32=True, split=True, f8=True, seed=9, atol=3e-5)
 
 
 def test_conv3x3_thin_output_tile(emu_engine):
