@@ -1,6 +1,6 @@
 """Experiment: error of the precise engine vs the fp32 oracle and vs an fp64 evaluation of the same oracle, tiny architecture, growing S."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from __graft_entry__ import load_package
 load_package()
