@@ -271,7 +271,11 @@ def main():
                        "self_attention_keys": "all key tiles" if args.dense_attention else
                        "key tiles whose (1-m)*-10000 bias underflows the fp32 softmax are not loaded (exact; --dense-attention disables)"},
             "parity": parity, "modes": modes, "single_image": b1, "including_host_transfers": incl,
+            # dense-equivalent algorithmic rate (28.89 TFLOP per 1024^2 image); the self-attention skips the key tiles
+            # whose bias underflows the softmax, so the executed attention work depends on the trimap (kernel_breakdown_ms has
+            # executed rates per kernel)
             "tflops_per_gpu": round(FLOPS_PER_IMAGE.get(S, 0) * B / (ms_per_step * 1e-3) / 1e12, 1),
+            "tflops_per_gpu_basis": "dense-equivalent algorithmic FLOPs of the reference graph (not executed FLOPs)",
             "weight_load_s": round(load_s, 1),
             "roofline": roof, "cpu_baseline": cpu, "kernel_breakdown_ms": breakdown,
         }
