@@ -57,9 +57,11 @@ typedef struct sdm_config {
   int32_t point_embeddings_input_dim;   /* 1680 (meta_arch.py:107-108); 0 = default */
   /* Arithmetic precision of the MFMA contractions, one bit per stage (enum sdm_precise_stage).  0 = fp16 operands everywhere
    * (fast: alpha within ~4e-3 of the fp32 reference path, the rounding floor of ANY fp16-operand evaluation).  A set bit evaluates
-   * that stage with split-fp16 operands (x = hi + lo, 22 significant bits, hi.hi + lo.hi + hi.lo in fp32 accumulators) and keeps
-   * every activation in fp32 between kernels: SDM_PRECISE_ALL reproduces the reference's fp32 CPU path to ~1e-4 (1e-3 is the
-   * parity bar, sdmatte_nodes.py:355-360) at roughly 2.5x the MFMA work. */
+   * that stage with split operands (x = hi + lo with hi = fp16(x): 22 significant bits; hi.hi + lo.w + x.lo_w in fp32 accumulators)
+   * and keeps every activation in fp32 between kernels: SDM_PRECISE_ALL reproduces the reference's fp32 CPU path to ~1.2e-4 (1e-3
+   * is the parity bar, sdmatte_nodes.py:355-360) at roughly 2x the matrix-pipe time.  The residual terms (2^-11 of a product) run
+   * on fp8 e4m3 operands in the wide 3x3 convs and the K >= 1024 GEMMs, on fp16 elsewhere; in the attention cores Q.K^T is split,
+   * P.V is plain fp16. */
   int32_t precise_mask;
   int32_t reserved[5];
 } sdm_config;
