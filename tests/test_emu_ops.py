@@ -209,3 +209,25 @@ def test_emulated_e4m3_conversion_matches_torch_and_the_hardware_probe():
           0.0019: 0x01, 464.0: 0x7e, 3.3e-3: 0x02}
     for f, b in hw.items():
         assert lib.sdm_emu_f32_to_e4m3(f) == b, (f, hex(lib.sdm_emu_f32_to_e4m3(f)), hex(b))
+
+
+def test_fp8_residual_kernels_random_shapes(emu_engine):
+    """Seeded random shapes through the 8-wave fp8-residual conv / GEMM kernels: ragged sizes, batches, concat on chunk boundaries,
+    fused GroupNorm (+SiLU), upsample, residual, ragged output-channel tiles, GEGLU (a 36-case sweep of the same generator ran
+    clean when the kernels were written; 8 cases here)."""
+    import random
+    rng = random.Random(7)
+    for it in range(6):
+        N = rng.choice([1, 2, 3]); H = rng.randint(3, 30); W = rng.randint(5, 45)
+        cin = rng.choice([32, 64, 96, 160]); cout = rng.choice([128, 136, 200, 256, 320])
+        up = rng.choice([0, 0, 0, 1]); c1 = rng.choice([0, 0, 32, 64])
+        gn = rng.choice([None, (1e-6, True), (1e-5, False)]) if up == 0 else None
+        res = rng.choice([None, "f32"])
+        if up:
+            H, W = max(3, H // 2), max(5, W // 2)
+        S.check_conv(emu_engine, DEV, N, H, W, cin, cout, C1=c1, up=up, tile_cfg=0, in_f32=True, out_f32=True, split=True, f8=True, gn=gn, res=res,
+                     seed=100 + it, atol=3e-4)
+    for it in range(2):
+        N = rng.choice([1, 2]); H = rng.randint(3, 40); W = rng.randint(5, 40)
+        cin = rng.choice([32, 64, 160, 320]); cout = rng.choice([128, 200, 256, 384])
+        S.check_conv(emu_engine, DEV, N, H, W, cin, cout, ntaps=1, tile_cfg=4, in_f32=True, out_f32=True, split=True, f8=True, res="f32", seed=200 + it, atol=3e-4)
