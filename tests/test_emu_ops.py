@@ -149,8 +149,8 @@ def test_attention_d64_split_precision(emu_engine, monkeypatch):
     """The default precision's attention cores: Q.K^T on split operands (the logits feed an exponential), P.V on plain fp16 operands
     (PREC = 2), fp32 in / out; and the fully split form (PREC = 1, SDM_ATTN_PV_SPLIT=1).  Against un-rounded fp64 attention: the
     fp16-operand kernel sits at ~2e-3 on these inputs."""
-    e2 = S.check_attention(emu_engine, DEV, 1, 2, 70, 100, 64, use_bias=True, split=True, atol=6e-4)
-    S.check_attention(emu_engine, DEV, 2, 1, 33, 200, 64, use_bias=False, split=True, seed=4, atol=6e-4)
+    e2 = S.check_attention(emu_engine, DEV, 1, 2, 70, 100, 64, use_bias=True, split=True, atol=1e-3)
+    S.check_attention(emu_engine, DEV, 2, 1, 33, 200, 64, use_bias=False, split=True, seed=4, atol=1e-3)
     monkeypatch.setenv("SDM_ATTN_PV_SPLIT", "1")
     e1 = S.check_attention(emu_engine, DEV, 1, 2, 70, 100, 64, use_bias=True, split=True, atol=3e-5)
     assert e1 < e2

@@ -203,9 +203,9 @@ def test_conv3x3_fp8_residual_terms(eng, cin, cout, H, W, gn, res, up):
 def test_attention_d64_split_precision(eng, monkeypatch):
     """Split-precision attention cores as the engine runs them (Q.K^T on hi | lo pairs, P.V on fp16; 4- and 8-wave blocks), and the
     fully split form, against un-rounded fp64 attention."""
-    e2 = S.check_attention(eng, DEV, 2, 5, 300, 1000, 64, use_bias=True, split=True, atol=6e-4)
+    e2 = S.check_attention(eng, DEV, 2, 5, 300, 1000, 64, use_bias=True, split=True, atol=1e-3)
     monkeypatch.setenv("SDM_ATTN_NW", "8")
-    S.check_attention(eng, DEV, 1, 2, 700, 333, 64, use_bias=False, split=True, seed=5, atol=6e-4)
+    S.check_attention(eng, DEV, 1, 2, 700, 333, 64, use_bias=False, split=True, seed=5, atol=1e-3)
     monkeypatch.delenv("SDM_ATTN_NW")
     monkeypatch.setenv("SDM_ATTN_PV_SPLIT", "1")
     e1 = S.check_attention(eng, DEV, 2, 5, 300, 1000, 64, use_bias=True, split=True, atol=3e-5)
