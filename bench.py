@@ -38,17 +38,18 @@ MFMA_F16_PEAK_TFLOPS = 2500.0                                       # MI355X den
 def timed_steps(step, steps, world, dev):
     """K steps bracketed by barrier + synchronize on both sides; returns max-over-ranks seconds."""
     import torch.distributed as dist
-    torch.cuda.synchronize()
+    sync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)      # (--emu test hook: host memory, nothing to wait for)
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -69,7 +70,11 @@ def main():
     ap.add_argument("--no-other-mode", action="store_true", help="skip timing the non-default precision")
     ap.add_argument("--timed-only", action="store_true",
                     help="only warmup + timed steps + the one profiled step (all identical): the run rocprofv3 summaries are taken from")
-    ap.add_argument("--cpu-sample-size", type=int, default=512)
+    ap.add_argument("--cpu-sample-size", type=int, default=1024,
+                    help="size of the ONE image the fp32 CPU oracle is timed on (default: the benchmark's own 1024 - about two minutes of host time)")
+    ap.add_argument("--emu", action="store_true",
+                    help="TEST HOOK (tests/test_emu_e2e.py): run the same script on the CPU kernel emulator with gloo and the tiny architecture, so "
+                         "that the N > 1 control flow of this file is exercised in the GPU-less build container; never a benchmark")
     ap.add_argument("--dump-profile", type=str, default=None, help="write the per-launch profile CSV here")
     ap.add_argument("--dense-attention", action="store_true",
                     help="walk every key tile in the trimap-biased self-attention instead of skipping the tiles whose bias underflows the softmax")
@@ -79,7 +84,7 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU, RCCL rendezvous on 127.0.0.1)
-        if torch.cuda.device_count() < args.gpus:
+        if not args.emu and torch.cuda.device_count() < args.gpus:
             sys.exit(f"[bench] --gpus {args.gpus} requested but only {torch.cuda.device_count()} GPU(s) are visible")
         import socket
         with socket.socket() as s:
@@ -93,11 +98,19 @@ def main():
     if world != args.gpus:
         sys.exit(f"[bench] WORLD_SIZE={world} does not match --gpus {args.gpus}")
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if args.emu:
+        dev = torch.device("cpu")
+        args.timed_only = args.no_other_mode = args.no_cpu_baseline = True
+        torch.set_num_threads(2)
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.emu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     if args.dense_attention:
         os.environ["SDM_ATTN_DENSE"] = "1"
@@ -107,11 +120,17 @@ def main():
     from comfyui_sdmatte_amd.synth import synthetic_inputs
     from comfyui_sdmatte_amd.weights import synthetic_state_dict
 
-    cfg = SDMatteConfig.full()
+    cfg = SDMatteConfig.tiny() if args.emu else SDMatteConfig.full()
     S, B = args.size, args.batch
     precision = args.precision or E.DEFAULT_PRECISION
     other = "fp16" if precision != "fp16" else "fp16x3"
-    eng = E.Engine(cfg, local_rank, precision=precision)
+    if args.emu:
+        import ctypes
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from emu.build_emu import build as _build_emu
+        eng = E.Engine(cfg, 0, precision=precision, _lib=E.Bindings(ctypes.CDLL(_build_emu())))
+    else:
+        eng = E.Engine(cfg, local_rank, precision=precision)
     sd = None
     if rank == 0:
         sd = synthetic_state_dict(cfg, 0)
@@ -123,7 +142,8 @@ def main():
         # RCCL broadcast of the packed weight blob (+ the small host-side embedding tensors at its tail)
         from comfyui_sdmatte_amd.parallel import broadcast_weights
         broadcast_weights(eng, 0, dev)
-        torch.cuda.empty_cache()
+        if dev.type == "cuda":
+            torch.cuda.empty_cache()
     load_s = time.time() - t_load0
 
     # synthetic inputs, resident in HBM (H = W = S so the node's resizes are identities)
@@ -134,7 +154,7 @@ def main():
 
     def make_step(engine):
         def step():
-            engine.apply_matte(img_d, tri_d, S, False, out=alpha, sync=False)    # stream-ordered with torch's current stream
+            engine.apply_matte(img_d, tri_d, S, False, out=alpha, sync=dev.type != "cuda")    # stream-ordered with torch's current stream
             if world > 1:
                 dist.gather(alpha, gathered, dst=0)                              # RCCL on the same stream order: no host sync in between
         return step
@@ -172,6 +192,19 @@ def main():
             dt = (time.perf_counter() - t0) / 2
             incl = {"images_per_s": round(B / dt, 3), "ms_per_step": round(dt * 1e3, 2),
                     "note": "inputs handed over as pageable host buffers: 16 MB H2D + 4 MB D2H per image inside the timed region"}
+        # ---- the same step with the self-attention walking EVERY key tile (the headline skips the tiles whose trimap bias underflows
+        #      the fp32 softmax - exact, but trimap-dependent): reported next to `value`, never instead of it ----
+        dense = None
+        if world == 1 and not args.timed_only and not args.dense_attention:
+            os.environ["SDM_ATTN_DENSE"] = "1"           # read per launch by the engine
+            try:
+                step()
+                el_d = timed_steps(step, max(2, args.steps // 2), 1, dev)
+                nd = max(2, args.steps // 2)
+                dense = {"images_per_s": round(B * nd / el_d, 3), "ms_per_step": round(el_d * 1e3 / nd, 3),
+                         "note": "SDM_ATTN_DENSE=1: every key tile of the trimap-biased self-attention is loaded and multiplied"}
+            finally:
+                os.environ.pop("SDM_ATTN_DENSE", None)
         # ---- roofline of the dominant kernel: per-launch HIP events on the engine stream (separate pass, 1 step) ----
         eng.profile(True)
         eng.apply_matte(img_d, tri_d, S, False, out=alpha, sync=True)
@@ -192,6 +225,16 @@ def main():
                 traffic = pt.get("conv3x3_bytes_per_launch")
         except Exception:
             pass
+        # matrix-pipe busy fraction of the same kernel from the committed SQ counter pass of `bench.py --timed-only`
+        # (profiles/pmc_sq.json, written by tools/pmc_sq.py: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES)); null when absent
+        mfma_busy = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_sq.json")) as fh:
+                ps = json.load(fh)
+            if ps.get("batch_per_gpu") == B and ps.get("inference_size") == S and ps.get("precision", "fp16") == precision:
+                mfma_busy = ps.get("conv3x3_mfma_busy_frac")
+        except Exception:
+            pass
         f8_res = precision == "fp16x3" and os.environ.get("SDM_CONV_F8", "1") != "0"      # residual terms of the 3x3 convs on fp8 (engine default)
         # matrix-pipe time per algorithmic product in units of one fp16 MFMA: fp16x3 = 3; fp16 + two fp8 residual terms at twice
         # the rate = 2 (a handful of thin / strided launches of the family stay on 3 and are counted as 2: lower bound)
@@ -206,7 +249,7 @@ def main():
                     "note": f"achieved = ALGORITHMIC flops (2*MAC of the convolution) / time; this precision keeps the matrix pipe busy for "
                             f"{mfma_per_product} fp16-MFMA time(s) per algorithmic product"
                             + (" (x_hi*w_hi on fp16 + the two residual terms on fp8 K=64 MFMAs at twice the rate)" if f8_res else ""),
-                    "mfma_executed_frac": round(mfma_per_product * ach / MFMA_F16_PEAK_TFLOPS, 4)}
+                    "mfma_executed_frac": round(mfma_per_product * ach / MFMA_F16_PEAK_TFLOPS, 4), "mfma_busy_frac_pmc": mfma_busy}
         breakdown = {k: {"ms": round(v["ms"], 3), "launches": v["launches"],
                          "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1) if v["flops"] else None,
                          "gbps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1) if v["bytes"] else None}
@@ -237,8 +280,8 @@ def main():
             cpu = {"value": round(1.0 / (tcpu * scale), 5), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
                    "extrapolated": Sc != S,
                    "sample": f"1 image at {Sc}x{Sc} through oracle/sdmatte_oracle.py (fp32 torch CPU restatement of the reference "
-                             f"force_cpu path) took {tcpu:.1f} s; EXTRAPOLATED to {S}x{S} by the dense-FLOP ratio {scale:.2f} "
-                             f"(not timed at {S}: ~2 min per image on this host)"}
+                             f"force_cpu path) took {tcpu:.1f} s on this host"
+                             + ("" if Sc == S else f"; EXTRAPOLATED to {S}x{S} by the dense-FLOP ratio {scale:.2f}")}
             parity = {"tolerance": 1e-3, "sample": f"{Sc}x{Sc}, full architecture, same synthetic weights, vs the fp32 oracle"}
             for name, en in ((precision, eng), (other, eng_o)):
                 if en is None:
@@ -262,15 +305,16 @@ def main():
                        "inference_size": S, "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
                        "precision": precision,
                        "arithmetic": (("split MFMA operands x = hi + lo, fp32 accumulate, fp32 activations: x_hi*w_hi on fp16; the residual "
-                                       "terms x_lo*w + x*w_lo on fp8 e4m3 (one K=64 MFMA) in the 3x3 convs with >= 128 output channels, on "
-                                       "fp16 (2 more MFMAs) in every other conv / GEMM / attention product"
+                                       "terms x_lo*w + x*w_lo on fp8 e4m3 (one K=64 MFMA) in the 3x3 convs with >= 128 output channels and the "
+                                       "GEMMs with K >= 1024, on fp16 (2 more MFMAs) in every other conv / GEMM and in Q.K^T; P.V on plain fp16 "
+                                       "operands with an fp32 VALU denominator; the d=512 VAE attention core on plain fp16"
                                        if os.environ.get("SDM_CONV_F8", "1") != "0" else
                                        "split-fp16 MFMA operands (hi+lo, 3 MFMAs per product), fp32 accumulate, fp32 activations")
                                       if precision == "fp16x3" else "fp16 MFMA operands, fp32 accumulate, fp32 residual stream"),
                        "trimap": "synthetic disc/annulus (28 % foreground / 22 % unknown / 50 % background, SURVEY.md 8d)",
                        "self_attention_keys": "all key tiles" if args.dense_attention else
                        "key tiles whose (1-m)*-10000 bias underflows the fp32 softmax are not loaded (exact; --dense-attention disables)"},
-            "parity": parity, "modes": modes, "single_image": b1, "including_host_transfers": incl,
+            "parity": parity, "modes": modes, "dense_attention": dense, "single_image": b1, "including_host_transfers": incl,
             # dense-equivalent algorithmic rate (28.89 TFLOP per 1024^2 image); the self-attention skips the key tiles
             # whose bias underflows the softmax, so the executed attention work depends on the trimap (kernel_breakdown_ms has
             # executed rates per kernel)

@@ -62,6 +62,9 @@ struct ConvParams {
   int f8;                               // 1: w_dma holds the fp8-residual layout (pack_conv_weight_f8_kernel) -> F8 kernel
   int f8_hint;                          // tile selection only: the layer has the fp8-residual weights (cfg 0 then beats the 256x64 tile)
   int f8_sa, f8_sb;                     // E8M0 exponents (byte 0) of the fp8 MFMA operand scales: 2^(sa-127) * 2^(sb-127) maps the residual sums to accumulator units
+  int epi_mode;                         // F8 kernels: 0 = LDS-transposed epilogue; 1 = accumulator-layout epilogue for full fp32 tiles (dword stores straight from
+                                        // the MFMA registers, no LDS, in-lane statistics); 2 = 1 + the residual enters as the accumulators' initial value;
+                                        // 3 = LDS-transposed epilogue + residual as the accumulators' initial value
   int ablate;                           // debug/bench only (sdm_bench_conv): 1 skip global loads, 2 skip LDS writes, 4 skip MFMA,
                                         // 8 skip the epilogue stores -- after the first K-chunk; always 0 in the engine
   int vgrid, tpb;                       // F8 (tpb tiles per block): number of virtual block ids = the grid of the one-tile-per-block forms
@@ -204,6 +207,49 @@ conv_mfma_kernel(ConvParams p) {
     for (int j = 0; j < NTL; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  // ---- accumulator-layout epilogue (F8 kernels; ConvParams::epi_mode).  After the MFMA chain register r of lane l holds output row
+  //      (r & 3) + 8 * (r >> 2) + 4 * (l >> 5) and column l & 31 of a 32 x 32 sub-tile: a 32-lane half-wave covers 128 contiguous bytes of
+  //      one fp32 output row, so ONE buffer_store_dword per register writes two full 128-byte lines - no LDS transpose, no wait in
+  //      the store stream (the accumulators are free again as soon as the stores have issued, and the next tile's MFMAs run while
+  //      they drain), per-channel statistics are in-lane sums.  With 32-pixel-wide tiles the 32 rows of sub-tile i are the 32
+  //      pixels of ONE image row, so every address is lane part (voffset, constant for the tile) + wave-uniform part (soffset).
+  //      Ragged tiles, fp16 / plane outputs and GEGLU keep the LDS-transposed epilogue below. ----
+  constexpr bool FASTEPI = (F8 != 0) && (NTAPS == 1 || (TW == 32 && WTM % TW == 0));
+  const int wmu = SDM_UNIFORM_I(wm), wnu = SDM_UNIFORM_I(wn);
+  bool fast_epi = false, res_init = false;
+  if (FASTEPI) {
+    const bool full = (NTAPS == 9) ? (oy0 + TH <= p.Hout && ox0 + TW <= p.Wout) : (m0 + (long)C::BM <= m_end);
+    const bool ok = p.out_f32 == 1 && p.epi == 0 && full && (!p.res || p.res_f32);
+    fast_epi = ok && (p.epi_mode == 1 || p.epi_mode == 2);
+    res_init = ok && p.epi_mode >= 2 && p.res != nullptr && p.out_scale == 1.0f;      // mode 3: residual as accumulator init + the LDS-transposed store epilogue
+  }
+  // first output pixel of this wave's sub-tile i, relative to the tile's first pixel (px_tile0)
+  const size_t px_tile0 = (NTAPS == 9) ? ((size_t)img * p.Hout + oy0) * p.Wout : (size_t)m0;
+  auto sub_px = [&](int i) { return (NTAPS == 9) ? (unsigned int)((wmu * (WTM / TW) + i) * p.Wout + ox0) : (unsigned int)(wmu * WTM + i * 32); };
+  auto acc_init_residual = [&]() {
+  if (FASTEPI && res_init) {
+    // the residual is the accumulators' initial value: out = (acc + bias) + res.  F8 layers carry acc_scale == 1 (their fp16 high parts
+    // are packed unscaled, the fp8 operand scales absorb the rest), so the loaded dwords ARE the accumulator registers: any arithmetic
+    // on them made hipcc stage all 128 values in a second register set (1.2 KB / lane of scratch).  Called by the CONSUMER branch only,
+    // in front of the barrier that ends the producers' prologue: the accumulators must not be live across the producers' code (the
+    // register allocation is the union of both roles), and the loads fly while the consumers wait for the first operands.
+    const unsigned int rs4 = (unsigned int)p.res_C * 4u;
+    const sdm_rsrc rsi = sdm_make_rsrc((const unsigned char*)p.res + px_tile0 * rs4, (unsigned int)(((NTAPS == 9) ? (size_t)TH * p.Wout : (size_t)C::BM) * rs4));
+    const unsigned int vr = (unsigned int)(4 * (lane >> 5)) * rs4 + (unsigned int)(n0 + wn * WTN + (lane & 31)) * 4u;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const unsigned int so = sub_px(i) * rs4;
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) {
+        const bool ok = (n0 + wn * WTN + j * 32 + (lane & 31)) < p.Cout_valid;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          acc[i][j][r] = sdm_buffer_load_f32(rsi, ok ? vr + (unsigned int)(j * 128) : SDM_BUF_INVALID, so + (unsigned int)((r & 3) + 8 * (r >> 2)) * rs4);
+      }
+    }
+  }
+  };
 
   // fused GroupNorm apply: scale[Cin] | shift[Cin] of this image, behind the A/B tile region
   float* gn_tab = (float*)(smem + (DB ? 2 : 1) * C::TILE_BYTES);
@@ -680,9 +726,9 @@ conv_mfma_kernel(ConvParams p) {
           SDM_WAIT_VMCNT0();
           if (nch > 1) { issue_loads_nx(32); SDM_SCHED_FENCE(); }
         }
-        SDM_WAIT_LGKMCNT0();
-        SDM_RAW_BARRIER();
         if (role) {
+          SDM_WAIT_LGKMCNT0();
+          SDM_RAW_BARRIER();
           int sl = 2;                   // ring slot of chunk c+2
           for (int c = 0; c < nch; ++c) {
             const bool more = c + 1 < nch, fly = c + 2 < nch;
@@ -696,6 +742,8 @@ conv_mfma_kernel(ConvParams p) {
             sl = sl == 2 ? 0 : sl + 1;
           }
         } else {
+          acc_init_residual();
+          SDM_RAW_BARRIER();            // the producers' prologue (same barrier as in their branch)
           const int sa8 = p.f8_sa, sb8 = p.f8_sb;
           f16x8 fbh[2][NTL];
           i32x8 fb8[NTL];
@@ -769,10 +817,10 @@ conv_mfma_kernel(ConvParams p) {
           SDM_SCHED_FENCE();
         }
       }
-      SDM_WAIT_LGKMCNT0();
-      SDM_RAW_BARRIER();
-      int cm = 0;                   // (6 * c) % 3 = 0 always: the chunk's first step sits in ring slot 0 (kept for clarity)
+      const int cm = 0;             // (6 * c) % 3 = 0 always: the chunk's first step sits in ring slot 0 (kept for clarity)
       if (role) {
+        SDM_WAIT_LGKMCNT0();
+        SDM_RAW_BARRIER();
         for (int c = 0; c < nch; ++c) {
           const bool more = c + 1 < nch;
 #pragma unroll
@@ -798,6 +846,8 @@ conv_mfma_kernel(ConvParams p) {
           }
         }
       } else {
+        acc_init_residual();
+        SDM_RAW_BARRIER();              // the producers' prologue (same barrier as in their branch)
         const int sa8 = p.f8_sa, sb8 = p.f8_sb;
         f16x8 fbh[2][3][NTL];         // w_hi fragments of the two 16-channel halves
         i32x8 fb8[3][NTL];            // [w8 | w_lo8] fragments
@@ -1107,6 +1157,66 @@ conv_mfma_kernel(ConvParams p) {
   // ---- epilogue: per-wave PRIVATE fp32 staging tile (32 x WTN) in LDS -> coalesced row stores ----
   if (!DB) __syncthreads();      // all waves are done with the A/B tiles (DB: the loop ended with a barrier)
   if (PC && role) return;        // the accumulators live in the consumer waves; no block-wide barrier below this line
+  if (FASTEPI && fast_epi) {
+    const unsigned int cs4 = (unsigned int)p.Cout_store * 4u, rs4 = (unsigned int)p.res_C * 4u;
+    const size_t span = (NTAPS == 9) ? (size_t)TH * p.Wout : (size_t)C::BM;
+    const sdm_rsrc rso = sdm_make_rsrc((unsigned char*)p.out + px_tile0 * cs4, (unsigned int)(span * cs4));
+    const bool res_epi = p.res != nullptr && !res_init;
+    const sdm_rsrc rsr2 = sdm_make_rsrc(res_epi ? (const unsigned char*)p.res + px_tile0 * rs4 : (const unsigned char*)p.out, res_epi ? (unsigned int)(span * rs4) : 0u);
+    const int cl = n0 + wn * WTN + (lane & 31);                      // output channel of j = 0
+    const unsigned int vo = (unsigned int)(4 * (lane >> 5)) * cs4 + (unsigned int)(p.out_ch_off + cl) * 4u;
+    const unsigned int vr = (unsigned int)(4 * (lane >> 5)) * rs4 + (unsigned int)cl * 4u;
+    const float* biasp = p.bias;
+    if (biasp && p.bias_sel) biasp += (size_t)p.bias_sel[img] * p.Cout_pad;
+    float bj[NTL], s1[NTL], s2[NTL];
+    bool okj[NTL];
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) {
+      const int occ = cl + j * 32;
+      okj[j] = occ < p.Cout_valid;
+      bj[j] = (biasp && occ < p.Cout_pad) ? biasp[occ] : 0.0f;
+      s1[j] = 0.0f; s2[j] = 0.0f;
+    }
+    const bool do_store = !(p.ablate & 8);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const unsigned int px = sub_px(i);
+      float rv[NTL][16];
+      if (res_epi) {
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            rv[j][r] = sdm_buffer_load_f32(rsr2, okj[j] ? vr + (unsigned int)(j * 128) : SDM_BUF_INVALID, (px + (unsigned int)((r & 3) + 8 * (r >> 2))) * rs4);
+      }
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = ((SPLIT ? acc[i][j][r] * p.acc_scale : acc[i][j][r]) + bj[j]) * p.out_scale;
+          if (res_epi) v += rv[j][r];
+          if (okj[j]) {
+            if (do_store) sdm_buffer_store_f32(v, rso, vo + (unsigned int)(j * 128), (px + (unsigned int)((r & 3) + 8 * (r >> 2))) * cs4);
+            s1[j] += v; s2[j] += v * v;
+          }
+        }
+      }
+    }
+    if (p.stats) {      // lanes l and l + 32 own the same channel (rows 4 apart): one partial row per (tile, wave-row), as below
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) { s1[j] += __shfl_xor(s1[j], 32); s2[j] += __shfl_xor(s2[j], 32); }
+      const size_t prow = (size_t)img * (p.tiles_m * WM) + (size_t)mt * WM + wm;
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) {
+        if (lane < 32 && okj[j]) {
+          f32x2 o2;
+          o2[0] = s1[j]; o2[1] = s2[j];
+          *(f32x2*)(p.stats + (prow * p.Cout_store + p.out_ch_off + cl + j * 32) * 2) = o2;
+        }
+      }
+    }
+    return;
+  }
   float* stg = (float*)(smem + (F8 ? 2 * C::A_BYTES : 0)) + wave * (32 * WTN);      // F8: second A buffer (the next tile's prologue fills the first)
   const bool geglu = (p.epi == 1);
   constexpr int LPR = WTN / 4;                    // lanes per output row (linear epilogue: 4 channels per lane)
@@ -1143,10 +1253,11 @@ conv_mfma_kernel(ConvParams p) {
                                          : (size_t)(((m_end - m0) < (long)C::BM) ? (m_end - m0) : (long)C::BM);
     const sdm_rsrc rsr = sdm_make_rsrc(p.res ? (const unsigned char*)p.res + (opix_base + (size_t)res_row0) * p.res_C * res_es : (const unsigned char*)p.out,
                                        p.res ? (unsigned int)(res_span * p.res_C * res_es) : 0u);
+    const bool res_late = p.res != nullptr && !(FASTEPI && res_init);      // not already in the accumulators
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       u32x4 rr[NPASS];
-      if (p.res) {
+      if (res_late) {
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
           long lp;
@@ -1177,7 +1288,7 @@ conv_mfma_kernel(ConvParams p) {
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = ((SPLIT ? t[e] * p.acc_scale : t[e]) + bu[e]) * p.out_scale;
-        if (p.res) {
+        if (res_late) {
           if (p.res_f32) {
             const f32x4 r4 = __builtin_bit_cast(f32x4, rr[pass]);
 #pragma unroll
@@ -1357,13 +1468,16 @@ __global__ void pack_conv_weight_dma_kernel(const float* __restrict__ w, half_t*
 
 // fp8-residual layout of a 3x3 weight (F8 kernels), per 32-channel chunk and kernel column dx four 12 KB-per-128-channels units of
 // [plane][dy][Cout_pad][16 B]:  unit 0 / 1 = fp16 high parts of channels 0-15 / 16-31 (plane = 8-channel half, 8 halfs per row),
-// unit 2 = e4m3(v) (plane = channels 0-15 | 16-31, one byte per channel), unit 3 = e4m3((v - hi) * 2^11), with v = w * scale.
-// Same number of bytes as the hi | lo fp16 pair (4 per weight).  Values beyond +-448 are clamped (v = w * 2^8: |w| > 1.75).
+// unit 2 = e4m3(w * s8) (plane = channels 0-15 | 16-31, one byte per channel), unit 3 = e4m3((w - hi) * s8 * 2^11), hi = fp16(w).
+// Same number of bytes as the hi | lo fp16 pair (4 per weight).  Values beyond +-448 are clamped (s8 = 2^8: |w| > 1.75).
 // ntaps == 1 (Linear / 1x1): the same without the dx / dy dimensions - [chunk32][unit][plane][Cout_pad][16 B]; as in
 // pack_conv_weight_kernel only the rows [co_off, co_off + O) of the packed layer (all rows for GEGLU) are written (fused q|k|v
 // layers are packed by three calls; the arena is zero-initialised).
+// `wscale` multiplies the weight itself (folded constants such as the attention logit scale); `s8` is the power of two that only the
+// fp8 units carry: the fp16 high parts are stored UNSCALED, so the F8 kernels accumulate in the output's own unit (acc_scale = 1:
+// the residual can enter as the accumulators' initial value) and the E8M0 operand scale of the MFMA undoes s8.
 __global__ void pack_conv_weight_f8_kernel(const float* __restrict__ w, unsigned char* __restrict__ wd, int O, int I, int Cin_pad, int Cout_pad,
-                                           int ci_off, float scale, int ntaps, int co_off, int geglu) {
+                                           int ci_off, float wscale, float s8, int ntaps, int co_off, int geglu) {
   const int nd = ntaps == 9 ? 3 : 1;
   const size_t total = (size_t)(Cin_pad / 32) * nd * 4 * 2 * nd * Cout_pad;         // 16-byte rows
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -1378,7 +1492,7 @@ __global__ void pack_conv_weight_f8_kernel(const float* __restrict__ w, unsigned
     if (ntaps != 9 && srow < 0) continue;                                            // another slot's rows / padding: leave
     auto wv = [&](int c) {
       const int ci = c - ci_off;
-      return (srow >= 0 && ci >= 0 && ci < I) ? w[((size_t)srow * I + ci) * ntaps + (ntaps == 9 ? dy * 3 + dx : 0)] * scale : 0.0f;
+      return (srow >= 0 && ci >= 0 && ci < I) ? w[((size_t)srow * I + ci) * ntaps + (ntaps == 9 ? dy * 3 + dx : 0)] * wscale : 0.0f;
     };
     unsigned char* dst = wd + idx * 16;
     if (u < 2) {
@@ -1391,7 +1505,7 @@ __global__ void pack_conv_weight_f8_kernel(const float* __restrict__ w, unsigned
 #pragma unroll
       for (int b = 0; b < 16; ++b) {
         const float x = wv(chunk * 32 + pl * 16 + b);
-        const float r = (u == 2) ? x : (x - (float)(half_t)x) * 2048.0f;
+        const float r = ((u == 2) ? x : (x - (float)(half_t)x) * 2048.0f) * s8;
         v[b] = fminf(fmaxf(r, -448.0f), 448.0f);
       }
       u32x4 o;

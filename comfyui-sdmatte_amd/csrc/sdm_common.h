@@ -81,6 +81,16 @@ static inline u32x2 sdm_buffer_load8(sdm_rsrc r, unsigned int voff, unsigned int
   if (o + 8 <= r.bytes) memcpy(&v, r.base + o, 8);
   return v;
 }
+static inline float sdm_buffer_load_f32(sdm_rsrc r, unsigned int voff, unsigned int soff) {
+  float v = 0.0f;
+  const unsigned long long o = (unsigned long long)voff + soff;
+  if (o + 4 <= r.bytes) memcpy(&v, r.base + o, 4);
+  return v;
+}
+static inline void sdm_buffer_store_f32(float v, sdm_rsrc r, unsigned int voff, unsigned int soff) {      // out-of-range stores are dropped, as in hardware
+  const unsigned long long o = (unsigned long long)voff + soff;
+  if (o + 4 <= r.bytes) memcpy((unsigned char*)r.base + o, &v, 4);
+}
 #else
 typedef __amdgpu_buffer_rsrc_t sdm_rsrc;
 __device__ __forceinline__ sdm_rsrc sdm_make_rsrc(const void* p, unsigned int bytes) {
@@ -91,6 +101,13 @@ __device__ __forceinline__ u32x4 sdm_buffer_load16(sdm_rsrc r, unsigned int voff
 }
 __device__ __forceinline__ u32x2 sdm_buffer_load8(sdm_rsrc r, unsigned int voff, unsigned int soff) {
   return __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
+}
+// one dword per lane: the accumulator-layout epilogue (a 32-lane half-wave covers 128 contiguous bytes of one output row)
+__device__ __forceinline__ float sdm_buffer_load_f32(sdm_rsrc r, unsigned int voff, unsigned int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void sdm_buffer_store_f32(float v, sdm_rsrc r, unsigned int voff, unsigned int soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, (int)voff, (int)soff, 0);
 }
 #endif
 

@@ -327,6 +327,14 @@ static bool gemm_f8_enabled() {
   return !(v && v[0] == '0');
 }
 
+// epilogue of the F8 kernels (ConvParams::epi_mode): 2 = accumulator-layout stores + residual as the accumulators' initial value
+// (default), 1 = accumulator-layout stores with the residual added in the epilogue, 0 = LDS-transposed epilogue (round 2).  Read per
+// launch: A/B hook.
+static int conv_epi_mode() {
+  const char* v = getenv("SDM_CONV_EPI");
+  return (v && v[0] >= '0' && v[0] <= '3') ? v[0] - '0' : 0;
+}
+
 static int gemm_f8_min_k() {
   const char* v = getenv("SDM_GEMM_F8_MIN_K");
   return v ? atoi(v) : 1024;
@@ -836,6 +844,7 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
   p.out_ch_off = a.out_ch_off;
   if (a.res) { p.res = a.res->p; p.res_f32 = a.res->f32; p.res_C = a.res->C; }
   p.epi = L.geglu; p.out_scale = a.out_scale;
+  p.epi_mode = conv_epi_mode();
   p.gn_scale = a.gn_scale; p.gn_shift = a.gn_shift; p.gn_silu = a.gn_silu;
   if ((long)a.in0->rows() >= (1L << 31) || p.M >= (1L << 31)) SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: tensor too large for 32-bit pixel indices", L.name.c_str());
   {   // 3x3: per-tile descriptors span only the rows of the tile's halo (k_conv.h band0), so an image may exceed 4 GB; what
@@ -873,9 +882,13 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
       // the fp8-residual kernel stages 32-channel chunks: a channel concat that does not split on a chunk boundary takes the
       // register-staged split kernel (K16 weights) instead
       if (p.C1 > 0 && (p.C0 % 32)) { p.w_dma = nullptr; p.pc = 0; }
-      else { p.f8 = 1; p.f8_sa = 127 - 13; p.f8_sb = 127; }      // x_lo8 = x_lo * 2^13, x8 * w_lo8 = (x * 2^2)(w_lo * 2^11): both 2^13 too large
+      else p.f8 = 1;
     }
-    if (L.ntaps == 1 && L.f8 && L.w_dma && cfg == 4 && p.in_f32 && gemm_f8_enabled()) { p.w_dma = L.w_dma; p.f8 = 1; p.f8_sa = 127 - 13; p.f8_sb = 127; }
+    if (L.ntaps == 1 && L.f8 && L.w_dma && cfg == 4 && p.in_f32 && gemm_f8_enabled()) { p.w_dma = L.w_dma; p.f8 = 1; }
+    // F8 launches: x_lo8 = x_lo * 2^13, x8 * w_lo8 = (x * 2^2)(w_lo * 2^w_exp * 2^11), x_lo8 * w8 = (x_lo * 2^13)(w * 2^w_exp): both residual
+    // sums are 2^(13 + w_exp) too large (E8M0 operand scales); the fp16 high parts are packed unscaled -> the accumulators are in the
+    // output's unit (acc_scale 1; the K16 hi | lo copy of the same layer, used by the other kernels, keeps 2^-w_exp)
+    if (p.f8) { p.f8_sa = 127 - 13; p.f8_sb = 127 - L.w_exp; p.acc_scale = 1.0f; }
   }
   if (e->dry) return 0;
   const double flops = 2.0 * (double)p.M * L.O * L.I * L.ntaps;
@@ -1837,7 +1850,7 @@ int sdm_load_tensor(sdm_ctx* e, const char* name, int dtype, int ndim, const int
       if (L.w_dma && L.f8) {
         const size_t rows = total / 4;       // 16-byte rows: 4 bytes per weight
         SDM_LAUNCH(pack_conv_weight_f8_kernel, dim3((unsigned)std::min<size_t>((rows + 255) / 256, 65535)), dim3(256), 0, e->stream,
-                   (const float*)dsrc, (unsigned char*)L.w_dma, O, I, L.Cin_pad, L.Cout_pad, s.ci_off, s.w_scale * ldexpf(1.0f, L.w_exp), L.ntaps,
+                   (const float*)dsrc, (unsigned char*)L.w_dma, O, I, L.Cin_pad, L.Cout_pad, s.ci_off, s.w_scale, ldexpf(1.0f, L.w_exp), L.ntaps,
                    s.co_off, L.geglu);
       } else if (L.w_dma) {
         const size_t tot2 = total * (L.split ? 2 : 1);
@@ -1905,7 +1918,7 @@ static int fold_cross_kv(sdm_ctx* e) {
                L.w, 2 * C, 4, 9, L.Cin_pad, L.Cout_pad, 4, 0, 0, ldexpf(1.0f, L.w_exp), L.w_lo);
     if (L.w_dma && L.f8)
       SDM_LAUNCH(pack_conv_weight_f8_kernel, dim3((unsigned)std::min<size_t>((total / 4 + 255) / 256, 65535)), dim3(256), 0, e->stream,
-                 (const float*)e->stage, (unsigned char*)L.w_dma, 2 * C, 4, L.Cin_pad, L.Cout_pad, 4, ldexpf(1.0f, L.w_exp), 9, 0, 0);
+                 (const float*)e->stage, (unsigned char*)L.w_dma, 2 * C, 4, L.Cin_pad, L.Cout_pad, 4, 1.0f, ldexpf(1.0f, L.w_exp), 9, 0, 0);
     else if (L.w_dma)
       SDM_LAUNCH(pack_conv_weight_dma_kernel, dim3((unsigned)std::min<size_t>((total * (L.split ? 2 : 1) + 255) / 256, 65535)), dim3(256), 0, e->stream,
                  (const float*)e->stage, L.w_dma, 2 * C, 4, L.Cin_pad, L.Cout_pad, 4, ldexpf(1.0f, L.w_exp), L.split ? 2 : 1);
@@ -2122,7 +2135,7 @@ int sdm_op_conv_ex(sdm_ctx* e, const void* in0, const void* in1, int C0, int C1,
     L.f8 = (split && L.Cin_pad % 32 == 0 && conv_f8_enabled()) ? 1 : 0;
     if (L.f8)
       SDM_LAUNCH(pack_conv_weight_f8_kernel, dim3((unsigned)std::min<size_t>((total / 4 + 255) / 256, 65535)), dim3(256), 0, e->stream, w,
-                 (unsigned char*)L.w_dma, O, L.I, L.Cin_pad, L.Cout_pad, 0, ldexpf(1.0f, L.w_exp), ntaps, 0, geglu);
+                 (unsigned char*)L.w_dma, O, L.I, L.Cin_pad, L.Cout_pad, 0, 1.0f, ldexpf(1.0f, L.w_exp), ntaps, 0, geglu);
     else
     SDM_LAUNCH(pack_conv_weight_dma_kernel, dim3((unsigned)std::min<size_t>((tot2 + 255) / 256, 65535)), dim3(256), 0, e->stream, w, L.w_dma, O, L.I,
                L.Cin_pad, L.Cout_pad, 0, ldexpf(1.0f, L.w_exp), split ? 2 : 1);
@@ -2132,7 +2145,7 @@ int sdm_op_conv_ex(sdm_ctx* e, const void* in0, const void* in1, int C0, int C1,
     dev_memset(wd, 0, total * 4, e->stream);
     L.w_dma = (half_t*)wd; L.f8 = 1;
     SDM_LAUNCH(pack_conv_weight_f8_kernel, dim3((unsigned)std::min<size_t>((total / 4 + 255) / 256, 65535)), dim3(256), 0, e->stream, w,
-               (unsigned char*)L.w_dma, O, L.I, L.Cin_pad, L.Cout_pad, 0, ldexpf(1.0f, L.w_exp), 1, 0, geglu);
+               (unsigned char*)L.w_dma, O, L.I, L.Cin_pad, L.Cout_pad, 0, 1.0f, ldexpf(1.0f, L.w_exp), 1, 0, geglu);
   }
   int Ho = Hin << up, Wo = Win << up;
   if (stride == 2) { Ho /= 2; Wo /= 2; }
@@ -2227,6 +2240,8 @@ float sdm_bench_conv(sdm_ctx* e, int N, int H, int W, int Cin, int Cout, int nta
   // in_f32: bit 0 = fp32 activations, bit 1 = split-precision kernel (implies fp32), bit 2 = fused GroupNorm+SiLU staging,
   // bit 3 = producer / consumer form of the split-precision DMA kernel
   const int split = (in_f32 >> 1) & 1, gnf = (in_f32 >> 2) & 1, pcf = (in_f32 >> 3) & 1, f8f = (in_f32 >> 4) & 1;      // bit 4: fp8-residual kernel
+  // bits 5-7: what the engine's ResBlock convs do in the default precision - fp32 output, fp32 residual, GroupNorm statistics of the consumer
+  const int of32 = (in_f32 >> 5) & 1, resf = (in_f32 >> 6) & 1, statf = (in_f32 >> 7) & 1;
   in_f32 = (in_f32 & 1) | split;
   if (e) dev_use(e->device);
   if (!e) return -1.f;
@@ -2235,11 +2250,16 @@ float sdm_bench_conv(sdm_ctx* e, int N, int H, int W, int Cin, int Cout, int nta
 #else
   ConvL L;
   L.name = "bench"; L.ntaps = ntaps; L.I = Cin; L.O = Cout; L.Cin_pad = rup(Cin, 16); L.Cout_pad = rup(Cout, 32);
-  void *wp = nullptr, *bp = nullptr, *in = nullptr, *out = nullptr, *wl = nullptr, *gnt = nullptr;
+  void *wp = nullptr, *bp = nullptr, *in = nullptr, *out = nullptr, *wl = nullptr, *gnt = nullptr, *resb = nullptr, *statb = nullptr;
   const int Ho = stride == 2 ? H / 2 : H, Wo = stride == 2 ? W / 2 : W;
   const size_t wbytes = (size_t)L.Cin_pad * ntaps * L.Cout_pad * 2, inb = (size_t)N * H * W * L.Cin_pad * (in_f32 ? 4 : 2),
-               outb = (size_t)N * Ho * Wo * L.Cout_pad * 2;
+               outb = (size_t)N * Ho * Wo * L.Cout_pad * (of32 ? 4 : 2);
   if (dev_malloc(&wp, wbytes) || dev_malloc(&bp, (size_t)L.Cout_pad * 4) || dev_malloc(&in, inb) || dev_malloc(&out, outb)) return -2.f;
+  if (resf) {
+    if (dev_malloc(&resb, (size_t)N * Ho * Wo * L.Cout_pad * 4)) return -2.f;
+    SDM_LAUNCH(fill_random_f32_kernel, dim3(4096), dim3(256), 0, e->stream, (float*)resb, (long)N * Ho * Wo * L.Cout_pad, 31u, 1.0f);
+  }
+  if (statf && dev_malloc(&statb, (size_t)N * (sdm_cdiv(Ho, 4) * sdm_cdiv(Wo, 8) * 4 + 64) * L.Cout_pad * 8)) return -2.f;      // enough partial rows for every tile cfg
   if (split) { if (dev_malloc(&wl, wbytes)) return -2.f; SDM_LAUNCH(fill_random_f16_kernel, dim3(2048), dim3(256), 0, e->stream, (half_t*)wl, (long)(wbytes / 2), 19u, 0.0001f); }
   if (gnf) {      // scale = 1, shift = 0 table [N][Cin] x 2
     if (dev_malloc(&gnt, (size_t)N * L.Cin_pad * 8)) return -2.f;
@@ -2257,7 +2277,10 @@ float sdm_bench_conv(sdm_ctx* e, int N, int H, int W, int Cin, int Cout, int nta
   memset(&p, 0, sizeof(p));
   p.in0 = in; p.C0 = L.Cin_pad; p.in_f32 = in_f32; p.N = N; p.Hin = H; p.Win = W; p.Hout = Ho; p.Wout = Wo; p.pad_t = p.pad_l = 1;
   p.M = (long)N * Ho * Wo; p.w = L.w; p.bias = L.b; p.Cout_pad = L.Cout_pad; p.out = out; p.Cout_store = L.Cout_pad; p.Cout_valid = L.Cout_pad;
-  p.out_scale = 1.f; p.ablate = ablate; p.acc_scale = 1.f;
+  p.out_scale = 1.f; p.ablate = ablate; p.acc_scale = split ? ldexpf(1.0f, -kSplitWeightExp) : 1.f;
+  p.out_f32 = of32; p.epi_mode = conv_epi_mode();
+  if (resf) { p.res = resb; p.res_f32 = 1; p.res_C = L.Cout_pad; }
+  if (statf) p.stats = (float*)statb;
   void* wdm = nullptr;
   static const bool bench_dma_off = getenv("SDM_CONV_DMA") && getenv("SDM_CONV_DMA")[0] == '0';
   if (!bench_dma_off && ntaps == 9 && stride == 1 && L.Cout_pad >= 128) {
@@ -2268,11 +2291,11 @@ float sdm_bench_conv(sdm_ctx* e, int N, int H, int W, int Cin, int Cout, int nta
   }
   if (split) p.w_lo = (const half_t*)wl;
   p.pc = (split && p.w_dma && pcf) ? 1 : 0;
-  if (split && p.w_dma && f8f && L.Cin_pad % 32 == 0) { p.f8 = 1; p.f8_sa = 127 - 13; p.f8_sb = 127; }
+  if (split && p.w_dma && f8f && L.Cin_pad % 32 == 0) { p.f8 = 1; p.f8_sa = 127 - 13; p.f8_sb = 127 - kSplitWeightExp; p.acc_scale = 1.f; }
   if (split && ntaps == 1 && f8f && L.Cin_pad % 32 == 0 && L.Cout_pad >= 128) {      // 1x1 GEMM on the fp8-residual kernel (tile cfg 4)
     if (dev_malloc(&wdm, wbytes * 2)) return -2.f;
     SDM_LAUNCH(fill_random_f16_kernel, dim3(2048), dim3(256), 0, e->stream, (half_t*)wdm, (long)wbytes, 29u, 0.05f);
-    p.w_dma = (const half_t*)wdm; p.f8 = 1; p.f8_sa = 127 - 13; p.f8_sb = 127;
+    p.w_dma = (const half_t*)wdm; p.f8 = 1; p.f8_sa = 127 - 13; p.f8_sb = 127 - kSplitWeightExp; p.acc_scale = 1.f;
   }
   if (gnf) { p.gn_scale = (const float*)gnt; p.gn_shift = (const float*)gnt + (size_t)N * L.Cin_pad; p.gn_silu = 1; }
   int cfg = tile_cfg >= 0 ? tile_cfg : conv_pick_cfg(ntaps, stride, p);
@@ -2290,6 +2313,8 @@ float sdm_bench_conv(sdm_ctx* e, int N, int H, int W, int Cin, int Cout, int nta
   if (wl) dev_free(wl);
   if (gnt) dev_free(gnt);
   if (wdm) dev_free(wdm);
+  if (resb) dev_free(resb);
+  if (statb) dev_free(statb);
   return ms / (float)iters;
 #endif
 }

@@ -195,7 +195,7 @@ def _dp_worker(rank, world, port, q):
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     cfg = SDMatteConfig.tiny()
-    eng = _emu_engine(cfg)
+    eng = _emu_engine(cfg, "fp16x3")          # the default precision: the two-rank results are held to the north star's 1e-3 below
     if rank == 0:
         eng.load_state_dict(synthetic_state_dict(cfg, 0))
     parallel.broadcast_weights(eng, 0, torch.device("cpu"))
@@ -237,14 +237,14 @@ def test_data_parallel_two_ranks_gloo(pkg):
     img, tri = synthetic_inputs(2, 64, 64)
     ref, _ = O.apply_matte(w, cfg.as_dict(), img, tri, 64, mask_refine=False)
     d = (got - ref).abs()
-    assert got.shape == ref.shape and d.max().item() < 1e-2 and d.mean().item() < 1.5e-3
+    assert got.shape == ref.shape and d.max().item() <= 1e-3, (d.max().item(), d.mean().item())
     # the request stream: every alpha back on rank 0, in request order, at its own resolution
     reqs = _stream_requests()
     assert len(stream) == len(reqs)
     for (im, tr, S), a in zip(reqs, stream):
         r, _ = O.apply_matte(w, cfg.as_dict(), im[None], tr[None], S, mask_refine=False)
         dd = (a - r[0]).abs()
-        assert a.shape == im.shape[:2] and dd.max().item() < 1e-2 and dd.mean().item() < 1.5e-3
+        assert a.shape == im.shape[:2] and dd.max().item() <= 1e-3, (S, dd.max().item(), dd.mean().item())
     # partitioning helpers
     assert [parallel.shard_range(32, 8, r) for r in (0, 7)] == [(0, 4), (28, 32)]
     assert parallel.shard_range(5, 4, 3) == (5, 5)

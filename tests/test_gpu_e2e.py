@@ -41,11 +41,11 @@ def _model(cfg, w, precision=None):
     return m
 
 
-def _run(pkg, cfg, S, B, seed=1234, precision=None):
+def _run(pkg, cfg, S, B, seed=1234, precision=None, wseed=0):
     from comfyui_sdmatte_amd.weights import synthetic_state_dict
     from comfyui_sdmatte_amd.synth import synthetic_inputs
     from oracle import sdmatte_oracle as O
-    w = synthetic_state_dict(cfg, 0)
+    w = synthetic_state_dict(cfg, wseed)
     img, tri = synthetic_inputs(B, S, S, seed)
     data = O.preprocess(img, tri, S, False)
     ref = O.sdmatte_forward(w, cfg.as_dict(), data)
@@ -53,7 +53,7 @@ def _run(pkg, cfg, S, B, seed=1234, precision=None):
     dcu = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data.items()}
     out = m(dcu).cpu()
     d = (out - ref).abs()
-    print(f"\n[{cfg.name} S={S} B={B} precision={precision or 'default'}] max|d|={d.max():.3e} mean|d|={d.mean():.3e} "
+    print(f"\n[{cfg.name} S={S} B={B} wseed={wseed} precision={precision or 'default'}] max|d|={d.max():.3e} mean|d|={d.mean():.3e} "
           f"gpu_ms={m.engine.last_forward_ms():.2f}")
     return m, w, img, tri, data, ref, out, d
 
@@ -297,6 +297,28 @@ def test_e2e_full_model_512(pkg):
     from comfyui_sdmatte_amd.config import SDMatteConfig
     m, w, img, tri, data, ref, out, d = _run(pkg, SDMatteConfig.full(), 512, 1)
     assert d.max().item() <= TOL
+    m.engine.close()
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("wseed", [1, 2])
+def test_e2e_full_model_512_other_weight_seeds(pkg, wseed):
+    """The same 512x512 full-architecture parity on two more synthetic weight draws (seed 0 is the test above): the 1e-3 bar must
+    not hinge on one draw; the margin kept in reserve is asserted too (4e-4)."""
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    m, w, img, tri, data, ref, out, d = _run(pkg, SDMatteConfig.full(), 512, 1, seed=1234 + wseed, wseed=wseed)
+    assert d.max().item() <= 4e-4
+    m.engine.close()
+
+
+@pytest.mark.slow
+def test_e2e_full_model_1024_vs_oracle(pkg):
+    """BASELINE config #2 - the headline size: ONE 1024x1024 image, full SD-2.1 architecture (synthetic weights), default precision,
+    against the fp32 CPU oracle (~2 minutes of host time on the GPU box) at the north star's 1e-3."""
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    m, w, img, tri, data, ref, out, d = _run(pkg, SDMatteConfig.full(), 1024, 1)
+    assert d.max().item() <= TOL
+    assert d.mean().item() <= 1e-4
     m.engine.close()
 
 

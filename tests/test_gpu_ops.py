@@ -163,6 +163,12 @@ def test_attention_matches_reference_scores_fixture(eng, golden_dir):
         ref = tok(torch.from_numpy(g[key]))
         # fp16 operands vs the reference's fp32 q/k/v: 5e-3 on O(1) outputs
         assert (out.float().cpu() - ref).abs().max().item() < 5e-3
+        # the kernel the DEFAULT precision ships (sdm_op_attention_split: Q.K^T on split operands, P.V on fp16, fp32 output) on the
+        # reference's un-rounded fp32 q / k / v: 1e-3 on O(1) outputs (measured 1-5e-4: the fp16 rounding of P and V)
+        out2 = eng.op_attention_split(tok(q).to(DEV), tok(k).to(DEV), tok(v).to(DEV), heads, bias.to(DEV) if use_bias else None)
+        e2 = (out2.float().cpu() - ref).abs().max().item()
+        print(f"[G3 vs shipped split kernel, bias={use_bias}] max|d|={e2:.2e}")
+        assert e2 < 1e-3
 
 
 @pytest.mark.slow
