@@ -89,12 +89,19 @@ class SDMatte:
     def _upload(self):
         self.missing_keys, self.ignored = self.engine.load_state_dict(self._pending)
         self._pending = None
-        if self.missing_keys:
-            # The reference loads with strict=False and would silently keep its random initialisation; a native engine would run
-            # on zeros.  A checkpoint that lacks tensors the graph consumes is a wrong / truncated file: fail loudly
-            # (SDMATTE_ALLOW_MISSING_KEYS=1 restores the lenient behaviour for experiments).
-            msg = (f"[SDMatte] {len(self.missing_keys)} tensors the model needs are absent from the checkpoint "
-                   f"(first: {', '.join(self.missing_keys[:3])})")
+        # The reference loads with strict=False and would silently keep its random initialisation; a native engine would run on
+        # zeros.  What THIS model's graph consumes must be present (a checkpoint without it is a wrong / truncated file: fail
+        # loudly; SDMATTE_ALLOW_MISSING_KEYS=1 restores the lenient behaviour for experiments); tensors that only another prompt
+        # type reads (unet.point_embedding.* is consumed by point prompts alone, replace.py:446-450) are reported and left zero,
+        # like the reference's strict=False.
+        optional = [k for k in self.missing_keys if k.startswith("unet.point_embedding.") and self.aux_input != "point_mask"]
+        required = [k for k in self.missing_keys if k not in optional]
+        if optional:
+            print(f"[SDMatte] note: {len(optional)} tensors not used by aux_input={self.aux_input!r} are absent from the checkpoint "
+                  f"(first: {optional[0]})")
+        if required:
+            msg = (f"[SDMatte] {len(required)} tensors the model needs are absent from the checkpoint "
+                   f"(first: {', '.join(required[:3])}); tools/check_checkpoint.py lists every difference from the expected key schema")
             if os.environ.get("SDMATTE_ALLOW_MISSING_KEYS") == "1":
                 print(msg + "; they stay zero")
             else:

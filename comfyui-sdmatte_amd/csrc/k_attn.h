@@ -80,10 +80,19 @@ SDM_DEV_INLINE bool attn_block_coords(const AttnParams& p, int bid, int& b, int&
 // PREC = 2: only Q.K^T is split; P and V^T enter P.V as plain fp16 (V^T_lo is neither loaded nor staged).  The logits feed an
 // exponential, the probabilities are averaged: on the full architecture the residual terms of P.V move alpha by 9e-6 (1.055e-4 ->
 // 1.143e-4 at 512^2) and cost 16 % of the kernel (tests/tools/attn_pv_experiment.py) - PREC = 2 is what the engine uses.
+// PREC = 3: PREC = 2 with the two residual terms of Q.K^T (k_lo.q + k.q_lo) on fp8 MFMAs.  The "low" plane of q and k then holds, per 4
+// channels, [e5m2(x) x 4 | e5m2((x - hi) * 2^11) x 4] (written by the producing GEMM's epilogue, ConvParams::out_f32 == 3) - the same
+// bytes at the same addresses as the fp16 low parts.  A dot product does not care about the order of its terms, so the 64 stored
+// bytes of a key's 32 channels ARE an A operand of v_mfma_scale_f32_32x32x64_f8f6f4 (positions alternate k8 / k_lo8 in groups of
+// 4), and the matching B operand is the query's 64 bytes with the two halves of every 8-byte group swapped (q_lo8 opposite k8, q8
+// opposite k_lo8; built once per block): TWO K = 64 MFMAs per 32-key tile deliver both residual terms over d = 64, instead of eight
+// fp16 MFMAs - 24 instead of 32 fp16-MFMA times per 64-key tile.  Every product pairs an x8 with an x_lo8 byte, so one operand scale
+// of 2^-11 returns the sums to the unit of the fp16 accumulation; e5m2 has the range of fp16: nothing to calibrate or saturate.
 template <int QT, int PREC = 0, int NW = 4>
 __global__ void __launch_bounds__(64 * NW, 2) attn_d64_kernel(AttnParams p) {
   static_assert(!PREC || QT == 1, "the split-precision variant keeps one 32-query tile per wave");
   constexpr int PVS = (PREC == 1) ? 1 : 0;                       // P.V on split operands too
+  constexpr int F8Q = (PREC == 3) ? 1 : 0;                       // residual terms of Q.K^T on fp8 (pair planes)
   constexpr int NTH = 64 * NW, VPT = 512 / NTH;                  // threads, 16-byte vectors per thread and tile (K and V^T: 512 each)
   SDM_DYN_SMEM(smem);
   constexpr int PK = ATTN64_PK, PV = ATTN64_PV;
@@ -99,6 +108,7 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_kernel(AttnParams p) {
   const int q0 = qblk * (32 * NW * QT) + wave * (32 * QT);
 
   f16x8 qf[QT][4], qfl[PREC ? QT : 1][4];
+  i32x8 q8p[2];                   // F8Q: B operands of the two residual MFMAs (channels 0-31 | 32-63 of this query, x8 / x_lo8 swapped)
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     int qrow = q0 + qt * 32 + l31;
@@ -106,13 +116,22 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_kernel(AttnParams p) {
     const half_t* qp = p.q + (size_t)b * p.q_bs + (size_t)qrow * p.ldq + head * 64 + hi * 8;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[qt][ks] = *(const f16x8*)(qp + ks * 16);
-    if (PREC) {
+    if (PREC && !F8Q) {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) qfl[PREC ? qt : 0][ks] = *(const f16x8*)(qp + p.q_lo + ks * 16);
     }
+    if (F8Q) {
+      // lane l: query l & 31, MFMA positions 32 * (l >> 5) .. +31 = the stored bytes of channels m * 32 + 16 * (l >> 5) .. +15
+      const half_t* qb = p.q + (size_t)b * p.q_bs + p.q_lo + (size_t)qrow * p.ldq + head * 64 + hi * 16;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const i32x4 r0 = *(const i32x4*)(qb + m * 32), r1 = *(const i32x4*)(qb + m * 32 + 8);
+        q8p[m] = i32x8{r0[1], r0[0], r0[3], r0[2], r1[1], r1[0], r1[3], r1[2]};
+      }
+    }
     // The logit scale d^-1/2 * log2(e) lives in Q.  The engine folds it into the to_q weights at load time (exact: one fp16
     // rounding of the GEMM result either way) and passes scale_log2e == 1; the stand-alone operator entry scales Q here.
-    if (p.scale_log2e != 1.0f) {
+    if (p.scale_log2e != 1.0f && !F8Q) {      // (F8Q: the pair plane cannot be rescaled here - its producer scales Q, as the engine always does)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -238,12 +257,23 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_kernel(AttnParams p) {
         const f16x8 a = *(const f16x8*)(Ks + (kt * 32 + l31) * PK + ks * 32 + hi * 16);
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) s[qt][kt] = SDM_MFMA_32x32x16_F16(a, qf[qt][ks], s[qt][kt]);
-        if (PREC) {
+        if (PREC && !F8Q) {
           const f16x8 al = *(const f16x8*)(Ks + KLO + (kt * 32 + l31) * PK + ks * 32 + hi * 16);
           s[0][kt] = SDM_MFMA_32x32x16_F16(al, qf[0][ks], s[0][kt]);
           s[0][kt] = SDM_MFMA_32x32x16_F16(a, qfl[0][ks], s[0][kt]);
         }
       }
+    if (F8Q) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const unsigned char* kp = Ks + KLO + (kt * 32 + l31) * PK + m * 64 + hi * 32;
+          const i32x4 a0 = *(const i32x4*)kp, a1 = *(const i32x4*)(kp + 16);
+          const i32x8 a8 = i32x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+          s[0][kt] = SDM_MFMA_32x32x64_BF8_BF8(a8, q8p[m], s[0][kt], 127 - 11, 127);
+        }
+    }
     }
     if (!(p.ablate & 1)) {
 #pragma unroll

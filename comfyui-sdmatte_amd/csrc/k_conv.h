@@ -41,14 +41,17 @@ struct ConvParams {
   int rows_per_img;                     // NTAPS==1: != 0 -> row tiles are aligned to images of this many rows (needed when the
                                         // epilogue emits per-image GroupNorm statistics for a batch: one launch instead of N)
   const half_t* w;                      // packed weights, K16 layout
-  const half_t* w_dma;                  // DMAB kernels: the 3x3 weights in stage order [Cin/16][dx][hi|lo][k-half][dy][Cout_pad][8] (see pack_conv_weight_dma_kernel)
+  const half_t* w_dma;                  // DMAB kernels: the 3x3 weights in stage order [Cin/16][dx][hi|lo][k-half][dy][Cout_pad][8] (see derive_conv_weight_dma_kernel)
   const half_t* w_lo;                   // SPLIT kernels: fp16 low parts of the (scaled) weights, same layout: w = (w_hi + w_lo) * acc_scale
   float acc_scale;                      // multiplies the accumulator in the epilogue (undoes the power-of-two weight pre-scale; 1 otherwise)
-  size_t out_lo_off;                    // out_f32 == 2: element offset of the low-part plane behind the high-part plane
+  size_t out_lo_off;                    // out_f32 == 2 / 3: element offset of the low-part plane behind the high-part plane
+  int lo_cols;                          // out_f32 == 2 / 3: only output channels < lo_cols get the low-part plane (the V third of a fused q|k|v GEMM needs none)
   const float* bias;                    // [nvariants][Cout_pad]
   const int* bias_sel;                  // [N] variant per image or null
   int Cout_pad;                         // GEMM N (multiple of 32)
-  void* out; int out_f32;               // 0: fp16, 1: fp32, 2: two fp16 planes hi | lo with hi + lo = the fp32 value (attention operands of the precise mode)
+  void* out; int out_f32;               // 0: fp16, 1: fp32, 2: two fp16 planes hi | lo with hi + lo = the fp32 value (attention operands of the precise mode),
+                                        // 3: fp16 plane hi + a plane of the same size holding, per 4 channels, [e5m2(x) x 4 | e5m2((x - hi) * 2^11) x 4]: the
+                                        //    operands of the split-precision attention whose Q.K^T residual terms run on fp8 MFMAs (k_attn.h, PREC = 3)
   int Cout_store;                       // row stride (channels) of the output tensor
   int Cout_valid;                       // number of (post-epilogue) channels actually stored (mult of 4)
   int out_ch_off;                       // channel offset inside the output row (mult of 4)
@@ -59,7 +62,7 @@ struct ConvParams {
   const float* gn_shift;                // [N][C0+C1] fp32 each (from gn_finalize_*); the table of this image sits in LDS
   int gn_silu;
   int pc;                               // DMAB + SPLIT: 1 = producer / consumer form (8 waves, one block per CU), set by the launcher
-  int f8;                               // 1: w_dma holds the fp8-residual layout (pack_conv_weight_f8_kernel) -> F8 kernel
+  int f8;                               // 1: w_dma holds the fp8-residual layout (derive_conv_weight_f8_kernel) -> F8 kernel
   int f8_hint;                          // tile selection only: the layer has the fp8-residual weights (cfg 0 then beats the 256x64 tile)
   int f8_sa, f8_sb;                     // E8M0 exponents (byte 0) of the fp8 MFMA operand scales: 2^(sa-127) * 2^(sb-127) maps the residual sums to accumulator units
   int epi_mode;                         // F8 kernels: 0 = LDS-transposed epilogue; 1 = accumulator-layout epilogue for full fp32 tiles (dword stores straight from
@@ -139,10 +142,12 @@ struct ConvCfg {
 // F8 = 1 (PC kernel on 32-channel chunks): the two RESIDUAL terms of the split product, x_lo.w and x.w_lo, are evaluated on OCP
 // fp8 (e4m3) operands by ONE v_mfma_scale_f32_32x32x64_f8f6f4 per tap and 32 channels (K = 64 = [x_lo8 | x8] . [w8 | w_lo8]; twice
 // the fp16 rate and less energy per MAC - the kernel is power-limited, tools/probe/mfma_mix_probe.hip), x_hi.w_hi stays on fp16.
-// A residual term is 2^-11 of the product, so the 2^-4 relative rounding of e4m3 leaves ~2^-15: the alpha error stays ~1e-4
-// (tests/tools/exp_lowprec_residual_terms.py).  The producers write, per halo pixel and 32 channels, 4 x 16 B of fp16 high parts
-// and 2 x 32 B of fp8 (x_lo * 2^13, x * 2^2; clamped to +-448); the weights were packed to match (pack_conv_weight_f8_kernel).
-// The E8M0 operand scales of the MFMA bring both residual terms back to the unit of the fp16 accumulation.
+// A residual term is 2^-11 of the product, so a 2^-3 .. 2^-4 relative rounding leaves ~2^-14 .. 2^-15: the alpha error stays ~1e-4
+// (tests/tools/exp_lowprec_residual_terms.py).  Operand formats follow what is known about the ranges: the WEIGHT side is e4m3 with
+// a per-layer power-of-two scale chosen from max|w| when the layer is packed (derive_conv_weight_f8_kernel), the ACTIVATION side is
+// e5m2 - the range of fp16 itself, so nothing saturates whatever a checkpoint's activations look like (x8 = e5m2(x), x_lo8 =
+// e5m2(x_lo * 2^11), after one clamp of x to +-57344).  The producers write, per halo pixel and 32 channels, 4 x 16 B of fp16 high
+// parts and 2 x 32 B of fp8.  The E8M0 operand scales of the MFMA bring both residual terms back to the unit of the fp16 accumulation.
 template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN, int IN_F32, int DB, int GN, int SPLIT = 0, int DMAB = 0, int PC = 0, int F8 = 0>
 // second argument = minimum waves per SIMD: the big 4-wave tiles keep 2 blocks/CU resident (2 waves/SIMD, <= 256 registers)
 __global__ void __launch_bounds__(64 * WM * WN * (PC ? 2 : 1), (WM * WN == 4 && BN == 128) ? 2 : (WM * WN == 4 && BN == 64 && KC == 16 && TW == 32) ? 3 : 1)
@@ -613,7 +618,7 @@ conv_mfma_kernel(ConvParams p) {
       // barriers per kernel column.  Ring of 3 steps; the DMAs of step t+2 are issued at the start of step t and have landed when
       // the barrier of step t releases, so the B fragments of step t+1 are read while step t is multiplied. ----
       constexpr int NR = MT + 2, STEP = 2 * SLOT;
-      constexpr float F8_XS = 4.0f, F8_LS = 4.0f * 2048.0f;           // x8 = e4m3(x * 2^2), x_lo8 = e4m3(x_lo * 2^13)
+      constexpr float F8_LS = 2048.0f, F8_AMAX = 57344.0f;            // x8 = e5m2(x), x_lo8 = e5m2(x_lo * 2^11); |x| is clamped to the largest finite e5m2
       const int nch = Cin / 32, nsteps = nch * 6;
       auto mod3 = [](int x) { return x >= 6 ? x - 6 : (x >= 3 ? x - 3 : x); };
       const sdm_rsrc rs8 = sdm_make_rsrc(p.w_dma, (unsigned int)((size_t)Cin * NTAPS * p.Cout_pad * 4));
@@ -654,17 +659,19 @@ conv_mfma_kernel(ConvParams p) {
                 if (p.gn_silu) y = y * sdm_rcp(1.0f + sdm_exp2(-y * SDM_LOG2E));
                 if (!inside) y = 0.0f;                     // zero padding stays zero AFTER the normalisation
               }
+              // e5m2 covers the whole fp16 range: ONE clamp (v_med3) keeps hi, x8 and x_lo8 finite whatever the activation (|x_lo| * 2^11 <= |x|)
+              y = fminf(fmaxf(y, -F8_AMAX), F8_AMAX);
               const half_t h = (half_t)y;
               vh[e] = h;
-              xl[e] = fminf(fmaxf((y - (float)h) * F8_LS, -448.0f), 448.0f);
-              xx[e] = fminf(fmaxf(y * F8_XS, -448.0f), 448.0f);
+              xl[e] = (y - (float)h) * F8_LS;
+              xx[e] = y;
             }
             const int hp = a_hp0 + i * (NT / KV);
             *(f16x8*)(Ad + g * A_HALF + hp * 16) = vh;
-            int l0 = SDM_CVT_PK_FP8(xl[0], xl[1], 0, false), l1 = SDM_CVT_PK_FP8(xl[4], xl[5], 0, false);
-            l0 = SDM_CVT_PK_FP8(xl[2], xl[3], l0, true); l1 = SDM_CVT_PK_FP8(xl[6], xl[7], l1, true);
-            int x0 = SDM_CVT_PK_FP8(xx[0], xx[1], 0, false), x1 = SDM_CVT_PK_FP8(xx[4], xx[5], 0, false);
-            x0 = SDM_CVT_PK_FP8(xx[2], xx[3], x0, true); x1 = SDM_CVT_PK_FP8(xx[6], xx[7], x1, true);
+            int l0 = SDM_CVT_PK_BF8(xl[0], xl[1], 0, false), l1 = SDM_CVT_PK_BF8(xl[4], xl[5], 0, false);
+            l0 = SDM_CVT_PK_BF8(xl[2], xl[3], l0, true); l1 = SDM_CVT_PK_BF8(xl[6], xl[7], l1, true);
+            int x0 = SDM_CVT_PK_BF8(xx[0], xx[1], 0, false), x1 = SDM_CVT_PK_BF8(xx[4], xx[5], 0, false);
+            x0 = SDM_CVT_PK_BF8(xx[2], xx[3], x0, true); x1 = SDM_CVT_PK_BF8(xx[6], xx[7], x1, true);
             unsigned char* a8 = Ad + C::A_BYTES + (g >> 1) * A_HALF + hp * 16 + (g & 1) * 8;
             u32x2 wl, wx;
             wl[0] = (unsigned int)l0; wl[1] = (unsigned int)l1; wx[0] = (unsigned int)x0; wx[1] = (unsigned int)x1;
@@ -798,7 +805,7 @@ conv_mfma_kernel(ConvParams p) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-              for (int j = 0; j < NTL; ++j) acc[i][j] = SDM_MFMA_32x32x64_F8(a8[i], fb8c[j], acc[i][j], sa8, sb8);
+              for (int j = 0; j < NTL; ++j) acc[i][j] = SDM_MFMA_32x32x64_BF8A_F8B(a8[i], fb8c[j], acc[i][j], sa8, sb8);
             SDM_RAW_BARRIER();
             sl = sl == 2 ? 0 : sl + 1;
           }
@@ -932,7 +939,7 @@ conv_mfma_kernel(ConvParams p) {
                 const int i = r - dy;
                 if (i >= 0 && i < MT) {
 #pragma unroll
-                  for (int j = 0; j < NTL; ++j) acc[i][j] = SDM_MFMA_32x32x64_F8(f8a[r & 1], fb8[dy][j], acc[i][j], sa8, sb8);
+                  for (int j = 0; j < NTL; ++j) acc[i][j] = SDM_MFMA_32x32x64_BF8A_F8B(f8a[r & 1], fb8[dy][j], acc[i][j], sa8, sb8);
                 }
               }
               SDM_SCHED_FENCE();
@@ -1311,7 +1318,23 @@ conv_mfma_kernel(ConvParams p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { oh[e] = (half_t)v[e]; ol[e] = (half_t)(v[e] - (float)oh[e]); }
             *(f16x4*)((half_t*)p.out + oidx) = oh;
-            *(f16x4*)((half_t*)p.out + p.out_lo_off + oidx) = ol;
+            if (oc < p.lo_cols) *(f16x4*)((half_t*)p.out + p.out_lo_off + oidx) = ol;
+          } else if (p.out_f32 == 3) {                  // hi fp16 plane | e5m2 pair plane (same bytes, same addresses as the lo plane)
+            f16x4 oh;
+            float xx[4], xl[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float y = fminf(fmaxf(v[e], -57344.0f), 57344.0f);      // the largest finite e5m2
+              oh[e] = (half_t)y; xx[e] = y; xl[e] = (y - (float)oh[e]) * 2048.0f;
+            }
+            *(f16x4*)((half_t*)p.out + oidx) = oh;
+            if (oc < p.lo_cols) {
+              int a = SDM_CVT_PK_BF8(xx[0], xx[1], 0, false), b = SDM_CVT_PK_BF8(xl[0], xl[1], 0, false);
+              a = SDM_CVT_PK_BF8(xx[2], xx[3], a, true); b = SDM_CVT_PK_BF8(xl[2], xl[3], b, true);
+              u32x2 pr;
+              pr[0] = (unsigned int)a; pr[1] = (unsigned int)b;
+              *(u32x2*)((half_t*)p.out + p.out_lo_off + oidx) = pr;
+            }
           } else {
             f16x4 o;
 #pragma unroll
@@ -1441,12 +1464,29 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, half_t* __r
   }
 }
 
+// ---- derived weight layouts.  The canonical form of every conv / linear weight is the K16 tensor (pack_conv_weight_kernel: fp16 hi,
+//      plus lo for the split-precision layers); it is what checkpoints are packed into, what sdm_export_weight_blob hands to
+//      other ranks / devices, and what the two kernels below turn into the layouts the DMA-weight kernels stream - on every
+//      engine, by the same arithmetic, when the weights are finalised (bit-identical across ranks). ----
+
+// largest |value| of a packed fp16 tensor -> *out (float bits; non-negative floats order like unsigned integers)
+__global__ void absmax_f16_kernel(const half_t* __restrict__ w, size_t n, unsigned int* __restrict__ out) {
+  float m = 0.0f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = fabsf((float)w[i]);
+    if (v == v && v > m) m = v;
+  }
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) m = fmaxf(m, __shfl_xor(m, s));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __builtin_bit_cast(unsigned int, m));
+}
+
 // 3x3 weights in the stage order of the DMAB kernels: [Cin_pad/16][dx][part][k-half][dy][Cout_pad][8], part = hi (| lo when
-// nparts == 2: the fp16 pair of the pre-scaled weight, as in pack_conv_weight_kernel).  One stage = (chunk, dx, part) =
-// 2 x 3 x Cout_pad rows of 16 bytes; the BN rows of one (k-half, dy) of an output-channel tile are contiguous, so a DMA
-// instruction copies 64 of them (1 KB) straight into the LDS half-plane image.
-__global__ void pack_conv_weight_dma_kernel(const float* __restrict__ w, half_t* __restrict__ wd, int O, int I, int Cin_pad, int Cout_pad,
-                                            int ci_off, float scale, int nparts) {
+// nparts == 2).  One stage = (chunk, dx, part) = 2 x 3 x Cout_pad rows of 16 bytes; the BN rows of one (k-half, dy) of an
+// output-channel tile are contiguous, so a DMA instruction copies 64 of them (1 KB) straight into the LDS half-plane image.
+// A pure permutation of the K16 tensors.
+__global__ void derive_conv_weight_dma_kernel(const half_t* __restrict__ k_hi, const half_t* __restrict__ k_lo, half_t* __restrict__ wd, int Cin_pad,
+                                              int Cout_pad, int nparts) {
   const size_t total = (size_t)Cin_pad * 9 * Cout_pad * nparts;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int k8 = idx % 8;
@@ -1457,27 +1497,22 @@ __global__ void pack_conv_weight_dma_kernel(const float* __restrict__ w, half_t*
     const int part = t % nparts; t /= nparts;
     const int dx = t % 3;
     const int chunk = t / 3;
-    const int ci = chunk * 16 + half * 8 + k8 - ci_off;
-    float v = 0.0f;
-    if (co < O && ci >= 0 && ci < I) v = w[((size_t)co * I + ci) * 9 + dy * 3 + dx];
-    const float vs = v * scale;
-    const half_t hi = (half_t)vs;
-    wd[idx] = part == 0 ? hi : (half_t)(vs - (float)hi);
+    const size_t src = (((size_t)chunk * 9 + dy * 3 + dx) * Cout_pad + co) * 16 + half * 8 + k8;
+    wd[idx] = part == 0 ? k_hi[src] : k_lo[src];
   }
 }
 
 // fp8-residual layout of a 3x3 weight (F8 kernels), per 32-channel chunk and kernel column dx four 12 KB-per-128-channels units of
 // [plane][dy][Cout_pad][16 B]:  unit 0 / 1 = fp16 high parts of channels 0-15 / 16-31 (plane = 8-channel half, 8 halfs per row),
 // unit 2 = e4m3(w * s8) (plane = channels 0-15 | 16-31, one byte per channel), unit 3 = e4m3((w - hi) * s8 * 2^11), hi = fp16(w).
-// Same number of bytes as the hi | lo fp16 pair (4 per weight).  Values beyond +-448 are clamped (s8 = 2^8: |w| > 1.75).
-// ntaps == 1 (Linear / 1x1): the same without the dx / dy dimensions - [chunk32][unit][plane][Cout_pad][16 B]; as in
-// pack_conv_weight_kernel only the rows [co_off, co_off + O) of the packed layer (all rows for GEGLU) are written (fused q|k|v
-// layers are packed by three calls; the arena is zero-initialised).
-// `wscale` multiplies the weight itself (folded constants such as the attention logit scale); `s8` is the power of two that only the
-// fp8 units carry: the fp16 high parts are stored UNSCALED, so the F8 kernels accumulate in the output's own unit (acc_scale = 1:
-// the residual can enter as the accumulators' initial value) and the E8M0 operand scale of the MFMA undoes s8.
-__global__ void pack_conv_weight_f8_kernel(const float* __restrict__ w, unsigned char* __restrict__ wd, int O, int I, int Cin_pad, int Cout_pad,
-                                           int ci_off, float wscale, float s8, int ntaps, int co_off, int geglu) {
+// Same number of bytes as the hi | lo fp16 pair (4 per weight).  ntaps == 1 (Linear / 1x1): the same without the dx / dy
+// dimensions - [chunk32][unit][plane][Cout_pad][16 B].
+//   * The fp16 high parts are stored UNSCALED (K16 keeps w * 2^w_exp; inv_s = 2^-w_exp), so the F8 kernels accumulate in the
+//     output's own unit (acc_scale = 1: the residual can enter as the accumulators' initial value).
+//   * s8 = 2^e8 is the layer's own fp8 scale, the largest power of two with max|w| * s8 <= 448 (chosen by the host from
+//     absmax_f16_kernel): no weight saturates, whatever the checkpoint; the MFMA's E8M0 operand scale undoes it.
+__global__ void derive_conv_weight_f8_kernel(const half_t* __restrict__ k_hi, const half_t* __restrict__ k_lo, unsigned char* __restrict__ wd, int Cin_pad,
+                                             int Cout_pad, int ntaps, float inv_s, float s8) {
   const int nd = ntaps == 9 ? 3 : 1;
   const size_t total = (size_t)(Cin_pad / 32) * nd * 4 * 2 * nd * Cout_pad;         // 16-byte rows
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -1488,24 +1523,22 @@ __global__ void pack_conv_weight_f8_kernel(const float* __restrict__ w, unsigned
     const int u = t % 4; t /= 4;
     const int dx = t % nd;
     const int chunk = (int)(t / nd);
-    const int srow = (ntaps == 9) ? (co < O ? co : -1) : pack_src_row(co, O, co_off, geglu);
-    if (ntaps != 9 && srow < 0) continue;                                            // another slot's rows / padding: leave
-    auto wv = [&](int c) {
-      const int ci = c - ci_off;
-      return (srow >= 0 && ci >= 0 && ci < I) ? w[((size_t)srow * I + ci) * ntaps + (ntaps == 9 ? dy * 3 + dx : 0)] * wscale : 0.0f;
-    };
+    const int tap = (ntaps == 9) ? dy * 3 + dx : 0;
+    auto src = [&](int c) { return (((size_t)(c / 16) * ntaps + tap) * Cout_pad + co) * 16 + (c % 16); };
     unsigned char* dst = wd + idx * 16;
     if (u < 2) {
       f16x8 h;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) h[e] = (half_t)wv(chunk * 32 + u * 16 + pl * 8 + e);
+      for (int e = 0; e < 8; ++e) h[e] = (half_t)((float)k_hi[src(chunk * 32 + u * 16 + pl * 8 + e)] * inv_s);
       *(f16x8*)dst = h;
     } else {
       float v[16];
 #pragma unroll
       for (int b = 0; b < 16; ++b) {
-        const float x = wv(chunk * 32 + pl * 16 + b);
-        const float r = ((u == 2) ? x : (x - (float)(half_t)x) * 2048.0f) * s8;
+        const size_t si = src(chunk * 32 + pl * 16 + b);
+        const float hi = (float)k_hi[si], w = (hi + (float)k_lo[si]) * inv_s;      // the weight to 22 bits
+        const float hp = (float)(half_t)(hi * inv_s);                              // the high part the kernel multiplies (unit 0 / 1)
+        const float r = ((u == 2) ? w : (w - hp) * 2048.0f) * s8;
         v[b] = fminf(fmaxf(r, -448.0f), 448.0f);
       }
       u32x4 o;

@@ -168,6 +168,34 @@ __global__ void refine_compose_kernel(const float* __restrict__ img, const float
   }
 }
 
+// fp32 [n] -> the operand planes of the split-precision attention (what the producing GEMM's epilogue writes in the engine,
+// ConvParams::out_f32): hi = fp16(x * mult) and, behind it, either lo = fp16(x * mult - hi) (mode 2) or, per 4 values,
+// [e5m2(y) x 4 | e5m2((y - hi) * 2^11) x 4] (mode 3).  Test hook (sdm_op_attention_split).
+__global__ void split_planes_kernel(const float* __restrict__ x, half_t* __restrict__ hi, half_t* __restrict__ lo, long n, float mult, int mode) {
+  const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  f16x4 oh, ol;
+  float xx[4], xl[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float y = (i4 + e < n) ? x[i4 + e] * mult : 0.0f;
+    if (mode == 3) y = fminf(fmaxf(y, -57344.0f), 57344.0f);
+    oh[e] = (half_t)y;
+    ol[e] = (half_t)(y - (float)oh[e]);
+    xx[e] = y; xl[e] = (y - (float)oh[e]) * 2048.0f;
+  }
+  *(f16x4*)(hi + i4) = oh;
+  if (mode == 3) {
+    int a = SDM_CVT_PK_BF8(xx[0], xx[1], 0, false), b = SDM_CVT_PK_BF8(xl[0], xl[1], 0, false);
+    a = SDM_CVT_PK_BF8(xx[2], xx[3], a, true); b = SDM_CVT_PK_BF8(xl[2], xl[3], b, true);
+    u32x2 pr;
+    pr[0] = (unsigned int)a; pr[1] = (unsigned int)b;
+    *(u32x2*)(lo + i4) = pr;
+  } else {
+    *(f16x4*)(lo + i4) = ol;
+  }
+}
+
 __global__ void scale_copy_kernel(const float* __restrict__ in, float* __restrict__ out, long n, float mult) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = in[i] * mult;

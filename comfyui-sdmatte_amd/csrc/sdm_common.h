@@ -28,6 +28,9 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define SDM_MFMA_32x32x16_F16(a, b, c) emu_mfma_f32_32x32x16_f16((a), (b), (c))
 #define SDM_MFMA_32x32x64_F8(a, b, c, sa, sb) emu_mfma_scale_f32_32x32x64_fp8((a), (b), (c), (sa), (sb))
 #define SDM_CVT_PK_FP8(a, b, old, hi_word) emu_cvt_pk_fp8_f32((a), (b), (old), (hi_word))
+#define SDM_MFMA_32x32x64_BF8A_F8B(a, b, c, sa, sb) emu_mfma_scale_f32_32x32x64_bf8_fp8((a), (b), (c), (sa), (sb))
+#define SDM_CVT_PK_BF8(a, b, old, hi_word) emu_cvt_pk_bf8_f32((a), (b), (old), (hi_word))
+#define SDM_MFMA_32x32x64_BF8_BF8(a, b, c, sa, sb) emu_mfma_scale_f32_32x32x64_bf8_bf8((a), (b), (c), (sa), (sb))
 #define SDM_LAUNCH(kernel, grid, block, smem, stream, ...) \
   emu::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); })
 #define SDM_DEV_INLINE static inline
@@ -47,6 +50,13 @@ static inline float sdm_rcp(float x) { return 1.0f / x; }
 // v_cvt_pk_fp8_f32: two fp32 -> two e4m3 bytes (round to nearest even; |x| > 448 gives NaN, so callers clamp) into the low or
 // high 16 bits of `old`
 #define SDM_CVT_PK_FP8(a, b, old, hi_word) __builtin_amdgcn_cvt_pk_fp8_f32((a), (b), (old), (hi_word))
+// the same instruction with the A operand in OCP e5m2 ("bf8": 2 mantissa bits, the range of fp16) and B in e4m3 (cbsz = 1, blgp = 0):
+// activations are not bounded at pack time the way weights are, so their residual operands take the wide format
+#define SDM_MFMA_32x32x64_BF8A_F8B(a, b, c, sa, sb) __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4((a), (b), (c), 1, 0, 0, (sa), 0, (sb))
+// v_cvt_pk_bf8_f32: two fp32 -> two e5m2 bytes (round to nearest even); callers clamp to +-57344 (the largest finite e5m2) first
+#define SDM_CVT_PK_BF8(a, b, old, hi_word) __builtin_amdgcn_cvt_pk_bf8_f32((a), (b), (old), (hi_word))
+// both operands in e5m2 (cbsz = 1, blgp = 1): the residual terms of Q.K^T (k_attn.h, PREC = 3)
+#define SDM_MFMA_32x32x64_BF8_BF8(a, b, c, sa, sb) __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4((a), (b), (c), 1, 1, 0, (sa), 0, (sb))
 #define SDM_LAUNCH(kernel, grid, block, smem, stream, ...) \
   hipLaunchKernelGGL(kernel, (grid), (block), (smem), (hipStream_t)(stream), __VA_ARGS__)
 #define SDM_DEV_INLINE __device__ __forceinline__

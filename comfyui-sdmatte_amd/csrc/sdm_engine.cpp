@@ -332,7 +332,14 @@ static bool gemm_f8_enabled() {
 // launch: A/B hook.
 static int conv_epi_mode() {
   const char* v = getenv("SDM_CONV_EPI");
-  return (v && v[0] >= '0' && v[0] <= '3') ? v[0] - '0' : 0;
+  return (v && v[0] >= '0' && v[0] <= '3') ? v[0] - '0' : 3;
+}
+
+// Residual terms of Q.K^T in the split-precision attention cores on fp8 MFMAs (k_attn.h, PREC = 3; q / k arrive as fp16 + e5m2 pair planes):
+// default on; SDM_ATTN_F8=0 keeps them on fp16 MFMAs (PREC = 2, fp16 hi | lo planes).  Read per forward: A/B hook.
+static bool attn_f8_enabled() {
+  const char* v = getenv("SDM_ATTN_F8");
+  return !(v && v[0] == '0');
 }
 
 static int gemm_f8_min_k() {
@@ -354,6 +361,7 @@ struct ConvL {
   size_t wdma_off = 0, wdma_bytes = 0;
   half_t* w_dma = nullptr;
   int f8 = 0;                 // w_dma holds the fp8-residual layout (F8 conv kernel) instead of the stage-ordered hi | lo pair
+  int f8_exp = 8;             // f8: the layer's e4m3 weight scale 2^f8_exp, the largest power of two with max|w| * 2^f8_exp <= 448 (derive_layer)
 };
 static const int kSplitWeightExp = 8;      // pre-scale 2^8: typical |w| ~ 1e-2 .. 1 -> low parts ~ 1e-3 .. 1e-1 * 2^-4: fp16-normal
 struct NormL {
@@ -386,7 +394,8 @@ struct T {  // NHWC activation tensor living in the arena
   long rows() const { return (long)N * H * W; }
 };
 
-// activation element formats (T::f32): 0 fp16, 1 fp32, 2 two fp16 planes hi | lo (split-precision attention operands)
+// activation element formats (T::f32): 0 fp16, 1 fp32, 2 two fp16 planes hi | lo (split-precision attention operands),
+// 3 fp16 plane hi + e5m2 pair plane (the same, with the residual operands of Q.K^T already in fp8: ConvParams::out_f32)
 static inline size_t fmt_bytes(int f) { return f ? 4 : 2; }
 static const int kMinVariantRows = 8;     // initial rows of the per-ResBlock bias tables (one row per distinct conditioning); grows on demand
 // conditioning of one image: opacity class + either 4 box coordinates (kind 0: bbox_embedding) or N point coordinates
@@ -415,7 +424,7 @@ struct sdm_ctx {
   std::unordered_map<std::string, Slot> slots;
   std::vector<std::string> slot_order;
   unsigned char* warena = nullptr;
-  size_t warena_bytes = 0;
+  size_t warena_bytes = 0, canon_bytes = 0;      // whole arena; its leading canonical part (the exported / imported blob)
   std::vector<float> hostblob;
   int64_t n_loaded = 0, n_ignored = 0;
   std::vector<std::string> missing;
@@ -499,7 +508,8 @@ static std::string g_create_err;
 // ------------------------------------------------------------------------------------------------
 struct Builder {
   sdm_ctx* e;
-  size_t woff = 0;
+  size_t woff = 0;         // canonical region: K16 weights (hi | lo), biases, norm affine - what sdm_export_weight_blob carries
+  size_t doff = 0;         // derived region (behind the canonical one): DMA-ordered / fp8-residual copies, rebuilt by sdm_finalize_weights
   int stage = 0;           // sdm_precise_stage of the layers being built
   explicit Builder(sdm_ctx* c) : e(c) {}
   int conv(const std::string& name, int ntaps, int I_pad16_src, int O, int geglu = 0) {
@@ -518,7 +528,7 @@ struct Builder {
     static const bool dma_all = getenv("SDM_CONV_DMA_ALL") != nullptr;
     if (ntaps == 9 && L.Cout_pad >= 128 && !geglu && (L.split || dma_all)) {
       L.wdma_bytes = (size_t)L.Cin_pad * 9 * L.Cout_pad * 2 * (L.split ? 2 : 1);
-      L.wdma_off = woff; woff += rupz(L.wdma_bytes, 256);
+      L.wdma_off = doff; doff += rupz(L.wdma_bytes, 256);
       L.f8 = (L.split && L.Cin_pad % 32 == 0 && conv_f8_enabled()) ? 1 : 0;      // same bytes, fp8-residual layout
     }
     // Linear / 1x1 layers of the split-precision stages with K >= 1024: fp8-residual copy for the 8-wave GEMM kernel (k_conv.h, F8
@@ -527,7 +537,7 @@ struct Builder {
     // 4-wave kernel x1.2-1.5 for K = 1280 ... 5120, x0.84-1.0 for K <= 640 (profiles/r02_gemm_f8_ab.txt) - hence the threshold
     if (ntaps == 1 && L.split && L.Cout_pad >= 128 && L.Cin_pad % 32 == 0 && L.Cin_pad >= gemm_f8_min_k() && conv_f8_enabled() && gemm_f8_enabled()) {
       L.wdma_bytes = (size_t)L.Cin_pad * L.Cout_pad * 4;
-      L.wdma_off = woff; woff += rupz(L.wdma_bytes, 256);
+      L.wdma_off = doff; doff += rupz(L.wdma_bytes, 256);
       L.f8 = 1;
     }
     e->convs.push_back(L);
@@ -735,7 +745,8 @@ static void build_model(sdm_ctx* e) {
   }
   e->u_norm_out = B.norm_named("unet.conv_norm_out", uc[0]);
   e->u_conv_out = B.conv_named("unet.conv_out", 9, uc[0], c.unet_out_channels);
-  e->warena_bytes = B.woff;
+  e->canon_bytes = B.woff;
+  e->warena_bytes = B.woff + B.doff;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -814,6 +825,7 @@ struct ConvArgs {
   int up = 0, stride = 1, pad_mode = 0;
   T* out = nullptr;            // pre-allocated output (shape/dtype/C define the store)
   int out_ch_off = 0, cout_valid = -1;
+  int lo_cols = -1;            // plane outputs (T::f32 2 / 3): output channels that need the low-part plane (-1: all)
   const T* res = nullptr;
   float out_scale = 1.0f;
   const float* bias_override = nullptr; const int* bias_sel = nullptr;
@@ -834,6 +846,7 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
   p.Cout_pad = L.Cout_pad;
   p.out = a.out->p; p.out_f32 = a.out->f32; p.Cout_store = a.out->C;
   p.out_lo_off = (size_t)a.out->rows() * a.out->C;
+  p.lo_cols = a.lo_cols >= 0 ? a.lo_cols : (1 << 30);
   p.acc_scale = 1.0f;
   if (L.split) {
     if (!p.in_f32) SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: split-precision layers take fp32 activations", L.name.c_str());
@@ -862,7 +875,7 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
   if (a.gn_scale && !(L.ntaps == 9 && a.stride == 1 && (cfg == 0 || cfg == 4 || cfg == 5) && p.C0 + p.C1 <= 1024))
     SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: fused GroupNorm requested for an unsupported tile configuration", L.name.c_str());
   if (a.out->want_stats) {
-    if (L.geglu || a.out_ch_off || p.out_f32 == 2) SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: fused statistics unsupported with this epilogue", L.name.c_str());
+    if (L.geglu || a.out_ch_off || p.out_f32 >= 2) SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: fused statistics unsupported with this epilogue", L.name.c_str());
     const ConvCfgInfo& ci = conv_cfg_table(L.ntaps, a.stride)[cfg];
     const long tiles = (L.ntaps == 9) ? (long)sdm_cdiv(p.Hout, ci.TH) * sdm_cdiv(p.Wout, ci.TW)
                                       : ((long)p.Hout * p.Wout + ci.TH * ci.TW - 1) / (ci.TH * ci.TW);
@@ -885,10 +898,10 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
       else p.f8 = 1;
     }
     if (L.ntaps == 1 && L.f8 && L.w_dma && cfg == 4 && p.in_f32 && gemm_f8_enabled()) { p.w_dma = L.w_dma; p.f8 = 1; }
-    // F8 launches: x_lo8 = x_lo * 2^13, x8 * w_lo8 = (x * 2^2)(w_lo * 2^w_exp * 2^11), x_lo8 * w8 = (x_lo * 2^13)(w * 2^w_exp): both residual
-    // sums are 2^(13 + w_exp) too large (E8M0 operand scales); the fp16 high parts are packed unscaled -> the accumulators are in the
+    // F8 launches: x_lo8 * w8 = (x_lo * 2^11)(w * 2^e8), x8 * w_lo8 = x (w_lo * 2^e8 * 2^11), e8 = the layer's own e4m3 scale: both residual
+    // sums are 2^(11 + e8) too large (E8M0 operand scales); the fp16 high parts are packed unscaled -> the accumulators are in the
     // output's unit (acc_scale 1; the K16 hi | lo copy of the same layer, used by the other kernels, keeps 2^-w_exp)
-    if (p.f8) { p.f8_sa = 127 - 13; p.f8_sb = 127 - L.w_exp; p.acc_scale = 1.0f; }
+    if (p.f8) { p.f8_sa = 127 - 11; p.f8_sb = 127 - L.f8_exp; p.acc_scale = 1.0f; }
   }
   if (e->dry) return 0;
   const double flops = 2.0 * (double)p.M * L.O * L.I * L.ntaps;
@@ -1001,6 +1014,7 @@ static int op_ln(sdm_ctx* e, const NormL& n, const T& x, float eps, T* out) {
 // q/k/v are views into fp16 row-major buffers; v is transposed into an arena scratch first
 // Precise variant (d = 64): q / k / v point at the HIGH planes of split fp16 pairs, the low planes follow at element offsets
 // q_lo / k_lo / v_lo (written by the producing GEMM with out_f32 == 2); `out` is fp16 or fp32 (out_f32).
+// prec: 0 fp16 operands; 1 q / k / v as fp16 planes hi | lo; 2 q / k as fp16 plane + e5m2 pair plane (ConvParams::out_f32 == 3), v hi only
 struct AttnPrec { int prec = 0; long q_lo = 0, k_lo = 0, v_lo = 0; int out_f32 = 0; };
 static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* k, int ldk, const half_t* v, int ldv, const float* bias_l2,
                             int B, int heads, int Lq, int Lk, int D, void* out, int ldo, bool q_prescaled = false, const int* tiles = nullptr,
@@ -1030,7 +1044,7 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
     // split-precision variant: Q.K^T on split operands, P.V on plain fp16 (k_attn.h, PREC = 2) unless SDM_ATTN_PV_SPLIT=1 asks for
     // the residual terms of P.V too (PREC = 1: then V^T_lo is needed as well)
     const char* pvs_env = getenv("SDM_ATTN_PV_SPLIT");
-    const bool pv_split = ap.prec && pvs_env && pvs_env[0] == '1';
+    const bool pv_split = ap.prec == 1 && pvs_env && pvs_env[0] == '1';
     if (pv_split)
       SDM_LAUNCH(transpose_v_kernel, dim3(ldvt / 64, heads * (D / 64), B), dim3(256), 0, e->stream, v + ap.v_lo, (long)Lk * ldv, ldv,
                  (half_t*)vt.p + (size_t)B * vt_bs, vt_bs, vt_hs, ldvt, Lk, D);
@@ -1073,7 +1087,10 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
       p.batch = B; p.heads = heads; p.nq_blocks = sdm_cdiv(Lq, qrows); p.q_chunks = 8;     // B*heads*8 units: always a multiple of 8
       const int qb = sdm_cdiv(p.nq_blocks, p.q_chunks);
       const unsigned nblk = (unsigned)(B * heads * p.q_chunks * qb);                         // 1-D grid, XCD-aware mapping in the kernel
-      if (ap.prec && pv_split) {
+      if (ap.prec == 2) {
+        if (nw8) { auto kp = attn_d64_kernel<1, 3, 8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(512), ATTN64P_SMEM, e->stream, p); }
+        else { auto kp = attn_d64_kernel<1, 3, 4>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(256), ATTN64P_SMEM, e->stream, p); }
+      } else if (ap.prec && pv_split) {
         if (nw8) { auto kp = attn_d64_kernel<1, 1, 8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(512), ATTN64P_SMEM, e->stream, p); }
         else { auto kp = attn_d64_kernel<1, 1, 4>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(256), ATTN64P_SMEM, e->stream, p); }
       } else if (ap.prec) {
@@ -1103,13 +1120,13 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
 // blocks
 // ------------------------------------------------------------------------------------------------
 static int conv_simple(sdm_ctx* e, int layer, const T& in, T* out, int Cout_store, int out_f32, int stride = 1, int pad_mode = 0, int up = 0,
-                       const T* res = nullptr, float scale = 1.0f, bool want_stats = false) {
+                       const T* res = nullptr, float scale = 1.0f, bool want_stats = false, int lo_cols = -1) {
   const ConvL& L = e->convs[layer];
   int Ho = in.H << up, Wo = in.W << up;
   if (stride == 2) { Ho /= 2; Wo /= 2; }
   *out = talloc(e, in.N, Ho, Wo, Cout_store, out_f32);
   if (want_stats) TRY(tstats(e, *out));
-  ConvArgs a; a.in0 = &in; a.out = out; a.stride = stride; a.pad_mode = pad_mode; a.up = up; a.res = res; a.out_scale = scale;
+  ConvArgs a; a.in0 = &in; a.out = out; a.stride = stride; a.pad_mode = pad_mode; a.up = up; a.res = res; a.out_scale = scale; a.lo_cols = lo_cols;
   return op_conv(e, L, a);
 }
 
@@ -1184,10 +1201,10 @@ static int resblock(sdm_ctx* e, const ResB& r, const T& x, const T* x2, float ep
   return 0;
 }
 
-static int linear(sdm_ctx* e, int layer, const T& in, T* out, int Cout, int out_f32, const T* res = nullptr, bool want_stats = false) {
+static int linear(sdm_ctx* e, int layer, const T& in, T* out, int Cout, int out_f32, const T* res = nullptr, bool want_stats = false, int lo_cols = -1) {
   *out = talloc(e, in.N, in.H, in.W, Cout, out_f32);
   if (want_stats) TRY(tstats(e, *out));
-  ConvArgs a; a.in0 = &in; a.out = out; a.res = res;
+  ConvArgs a; a.in0 = &in; a.out = out; a.res = res; a.lo_cols = lo_cols;
   return op_conv(e, e->convs[layer], a);
 }
 
@@ -1198,12 +1215,16 @@ static int vae_attention(sdm_ctx* e, const VaeAttnB& a, const T& x, T* out) {
   // the single-head d=512 core always takes fp16 operands; a 64-channel VAE (test architectures) runs on the d=64 kernels and
   // follows the U-Net attention-core precision bit
   const int pa = ((e->cfg.precise_mask & SDM_PRECISE_UNET_ATTN) && a.C == 64) ? 1 : 0;
-  TRY(linear(e, a.qkv, hn, &qkv, 3 * a.C, pa ? 2 : 0));
+  // plane format of q | k | v: fp16 hi | lo (the logit scale is applied to Q inside the kernel here - it is not folded into these
+  // weights - which the fp8 pair planes do not allow); V needs no low-part plane unless the fully split P.V form is requested
+  const int pf = pa ? 2 : 0;
+  const bool need_vlo = pf == 2 && getenv("SDM_ATTN_PV_SPLIT") && getenv("SDM_ATTN_PV_SPLIT")[0] == '1';
+  TRY(linear(e, a.qkv, hn, &qkv, 3 * a.C, pf, nullptr, false, need_vlo ? -1 : 2 * a.C));
   tfree(e, hn);
   ao = talloc(e, x.N, x.H, x.W, a.C, e->act_f32);
   const int L = x.H * x.W;
   const half_t* q = (const half_t*)qkv.p;
-  AttnPrec ap; ap.out_f32 = ao.f32; ap.prec = pa;
+  AttnPrec ap; ap.out_f32 = ao.f32; ap.prec = pa ? pf - 1 : 0;
   ap.q_lo = ap.k_lo = ap.v_lo = (long)qkv.rows() * qkv.C;
   TRY(op_attention_raw(e, q, 3 * a.C, q ? q + a.C : nullptr, 3 * a.C, q ? q + 2 * a.C : nullptr, 3 * a.C, nullptr, x.N, 1, L, L, a.C,
                        ao.p, a.C, false, nullptr, ap));
@@ -1224,12 +1245,14 @@ static int transformer(sdm_ctx* e, const TfB& t, const T& x, const T& uin, const
   // self-attention with the trimap key bias
   TRY(op_ln(e, e->norms[t.ln1], h, e->cfg.unet_ln_eps, &n));
   const int pa = (e->cfg.precise_mask & SDM_PRECISE_UNET_ATTN) ? 1 : 0;      // split-precision attention cores: q|k|v as hi|lo planes
-  TRY(linear(e, t.qkv1, n, &qkv, 3 * C, pa ? 2 : 0));
+  const int pf = pa ? (attn_f8_enabled() ? 3 : 2) : 0;         // plane format of q | k | v; SDM_ATTN_PV_SPLIT=1 (fully split P.V, test hook) needs V_lo too
+  const bool need_vlo = pf == 2 && getenv("SDM_ATTN_PV_SPLIT") && getenv("SDM_ATTN_PV_SPLIT")[0] == '1';
+  TRY(linear(e, t.qkv1, n, &qkv, 3 * C, pf, nullptr, false, need_vlo ? -1 : 2 * C));
   tfree(e, n);
   ao = talloc(e, x.N, x.H, x.W, C, e->act_f32);
   {
     const half_t* q = (const half_t*)qkv.p;
-    AttnPrec ap; ap.prec = pa; ap.out_f32 = ao.f32;
+    AttnPrec ap; ap.prec = pa ? pf - 1 : 0; ap.out_f32 = ao.f32;
     ap.q_lo = ap.k_lo = ap.v_lo = (long)qkv.rows() * qkv.C;
     TRY(op_attention_raw(e, q, 3 * C, q ? q + C : nullptr, 3 * C, q ? q + 2 * C : nullptr, 3 * C, bias, x.N, t.heads, L, L, 64, ao.p, C, true, tiles, ap));
   }
@@ -1238,13 +1261,13 @@ static int transformer(sdm_ctx* e, const TfB& t, const T& x, const T& uin, const
   tfree(e, ao); tfree(e, h);
   // cross-attention to the trimap-latent tokens
   TRY(op_ln(e, e->norms[t.ln2], h2, e->cfg.unet_ln_eps, &n));
-  TRY(linear(e, t.q2, n, &q2, C, pa ? 2 : 0));
+  TRY(linear(e, t.q2, n, &q2, C, pf));
   tfree(e, n);
-  TRY(conv_simple(e, t.kv2, uin, &kv, 2 * C, pa ? 2 : 0));      // folded aux_conv_in + to_k|to_v: tokens = latent pixels, row-major
+  TRY(conv_simple(e, t.kv2, uin, &kv, 2 * C, pf, 1, 0, 0, nullptr, 1.0f, false, need_vlo ? -1 : C));      // folded aux_conv_in + to_k|to_v: tokens = latent pixels, row-major
   ao = talloc(e, x.N, x.H, x.W, C, e->act_f32);
   {
     const half_t* kk = (const half_t*)kv.p;
-    AttnPrec ap; ap.prec = pa; ap.out_f32 = ao.f32;
+    AttnPrec ap; ap.prec = pa ? pf - 1 : 0; ap.out_f32 = ao.f32;
     ap.q_lo = (long)q2.rows() * q2.C; ap.k_lo = ap.v_lo = (long)kv.rows() * kv.C;
     TRY(op_attention_raw(e, (const half_t*)q2.p, C, kk, 2 * C, kk ? kk + C : nullptr, 2 * C, nullptr, x.N, t.heads, L, L0, 64, ao.p, C, true, nullptr, ap));
   }
@@ -1553,7 +1576,9 @@ static int ensure_buf(sdm_ctx* e, void** p, size_t* cap, size_t need) {
 // mode 0: core API (NCHW preprocessed, S x S); mode 1: node API (BHWC image + BHW trimap at H x W)
 // mode 0 takes the inference size as (SH, SW) = (H, W) and S is ignored; mode 1 resizes H x W to S x S like the node.
 // node tail (mode 1 only): mask_refine + output composition on the GPU, sdmatte_nodes.py:365-397
-struct NodeTail { int output_mode = 0, mask_refine = 0; float c = 0.8f; float* matted = nullptr; int channels() const { return output_mode == 1 ? 4 : 3; } };
+// trimap_constraint stays a double up to the two thresholds: the reference compares fp32 tensors with the Python floats c and
+// 1.0 - c (evaluated in double), i.e. with float32(c) and float32(1.0 - c) - for c = 0.8 the latter is 0.2f, not 1.0f - 0.8f
+struct NodeTail { int output_mode = 0, mask_refine = 0; double c = 0.8; float* matted = nullptr; int TH = 0, TW = 0; int channels() const { return output_mode == 1 ? 4 : 3; } };
 
 static int forward_impl(sdm_ctx* e, int mode, const float* image, const float* trimap, int B, int H, int W, int S, const int32_t* is_trans,
                         const float* cond, int cond_dim, int cond_kind, bool use_mask, float* out, int ptr_kind, void* stream_arg,
@@ -1575,8 +1600,10 @@ static int forward_impl(sdm_ctx* e, int mode, const float* image, const float* t
 #else
   (void)stream_arg;
 #endif
+  // node API: the trimap may have its own size (the reference resizes image and trimap independently, sdmatte_nodes.py:212-214,349)
+  const int TH = (tail && tail->TH > 0) ? tail->TH : H, TW = (tail && tail->TW > 0) ? tail->TW : W;
   const size_t in_img = (size_t)B * H * W * 3 * 4;          // mode 0: [B,3,SH,SW]; mode 1: [B,H,W,3]
-  const size_t in_tri = (size_t)B * H * W * 4;
+  const size_t in_tri = (size_t)B * TH * TW * 4;
   const size_t alpha_bytes = (size_t)B * H * W * 4;
   const size_t out_bytes = alpha_bytes * (tail ? 1 + tail->channels() : 1);      // host hand-over: alpha, then the composed image
   const float* d_img = image; const float* d_tri = trimap; float* d_out = out;
@@ -1613,7 +1640,7 @@ static int forward_impl(sdm_ctx* e, int mode, const float* image, const float* t
         SDM_LAUNCH(prep_nchw_kernel, dim3(nb), dim3(256), 0, e->stream, d_img, d_tri, img16, tri16, x16.f32, (float*)plane.p, B, SH, SW);
       } else {
         SDM_LAUNCH(prep_image_kernel, dim3(nb), dim3(256), 0, e->stream, d_img, img16, x16.f32, B, H, W, S);
-        SDM_LAUNCH(prep_trimap_kernel, dim3(nb), dim3(256), 0, e->stream, d_tri, tri16, x16.f32, (float*)plane.p, B, H, W, S);
+        SDM_LAUNCH(prep_trimap_kernel, dim3(nb), dim3(256), 0, e->stream, d_tri, tri16, x16.f32, (float*)plane.p, B, TH, TW, S);
       }
     }
     T alpha;
@@ -1627,7 +1654,7 @@ static int forward_impl(sdm_ctx* e, int mode, const float* image, const float* t
                    S, S, H, W, 1);
         if (tail)
           SDM_LAUNCH(refine_compose_kernel, dim3((unsigned)(((long)B * H * W + 255) / 256)), dim3(256), 0, e->stream, d_img, d_tri, d_out, d_matted,
-                     (long)B * H * W, tail->output_mode, tail->mask_refine, tail->c, (float)(1.0 - (double)tail->c));
+                     (long)B * H * W, tail->output_mode, tail->mask_refine, (float)tail->c, (float)(1.0 - tail->c));
       }
     }
     tfree(e, alpha); tfree(e, plane); tfree(e, x16);
@@ -1689,6 +1716,7 @@ void sdm_default_config(sdm_config* c) {
   c->vae_eps = 1e-6f; c->unet_res_eps = 1e-5f; c->unet_tf_gn_eps = 1e-6f; c->unet_ln_eps = 1e-5f;
   c->vae_scaling_factor = 0.18215f; c->attn_mask_value = -10000.0f;
   c->stream_f32 = 1;
+  c->precise_mask = SDM_PRECISE_ALL;      // the precision that meets the 1e-3 parity bar (include/sdmatte.h); 0 selects the fast fp16-operand graph
 }
 
 int sdm_create(sdm_ctx** out, int device_id, const sdm_config* cfg) {
@@ -1741,7 +1769,7 @@ int sdm_create(sdm_ctx** out, int device_id, const sdm_config* cfg) {
   for (auto& L : e->convs) {
     L.w = (half_t*)(e->warena + L.w_off); L.b = (float*)(e->warena + L.b_off);
     if (L.split) L.w_lo = (half_t*)(e->warena + L.wlo_off);
-    if (L.wdma_bytes) L.w_dma = (half_t*)(e->warena + L.wdma_off);
+    if (L.wdma_bytes) L.w_dma = (half_t*)(e->warena + e->canon_bytes + L.wdma_off);
   }
   for (auto& n : e->norms) { n.g = (float*)(e->warena + n.g_off); n.b = (float*)(e->warena + n.b_off); }
   for (auto& t : e->tembs) {
@@ -1847,16 +1875,6 @@ int sdm_load_tensor(sdm_ctx* e, const char* name, int dtype, int ndim, const int
       SDM_LAUNCH(pack_conv_weight_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 65535)), dim3(256), 0, e->stream,
                  (const float*)dsrc, L.w, O, I, L.ntaps, L.Cin_pad, L.Cout_pad, s.ci_off, s.co_off, L.geglu,
                  s.w_scale * ldexpf(1.0f, L.w_exp), L.w_lo);
-      if (L.w_dma && L.f8) {
-        const size_t rows = total / 4;       // 16-byte rows: 4 bytes per weight
-        SDM_LAUNCH(pack_conv_weight_f8_kernel, dim3((unsigned)std::min<size_t>((rows + 255) / 256, 65535)), dim3(256), 0, e->stream,
-                   (const float*)dsrc, (unsigned char*)L.w_dma, O, I, L.Cin_pad, L.Cout_pad, s.ci_off, s.w_scale, ldexpf(1.0f, L.w_exp), L.ntaps,
-                   s.co_off, L.geglu);
-      } else if (L.w_dma) {
-        const size_t tot2 = total * (L.split ? 2 : 1);
-        SDM_LAUNCH(pack_conv_weight_dma_kernel, dim3((unsigned)std::min<size_t>((tot2 + 255) / 256, 65535)), dim3(256), 0, e->stream,
-                   (const float*)dsrc, L.w_dma, O, I, L.Cin_pad, L.Cout_pad, s.ci_off, s.w_scale * ldexpf(1.0f, L.w_exp), L.split ? 2 : 1);
-      }
     } else if (s.kind == SLOT_CONV_B) {
       ConvL& L = e->convs[s.layer];
       SDM_LAUNCH(pack_bias_kernel, dim3(sdm_cdiv(L.Cout_pad, 256)), dim3(256), 0, e->stream, (const float*)dsrc, L.b, (int)s.shape[0],
@@ -1916,17 +1934,55 @@ static int fold_cross_kv(sdm_ctx* e) {
     const size_t total = (size_t)L.Cin_pad * 9 * L.Cout_pad;
     SDM_LAUNCH(pack_conv_weight_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 65535)), dim3(256), 0, e->stream, (const float*)e->stage,
                L.w, 2 * C, 4, 9, L.Cin_pad, L.Cout_pad, 4, 0, 0, ldexpf(1.0f, L.w_exp), L.w_lo);
-    if (L.w_dma && L.f8)
-      SDM_LAUNCH(pack_conv_weight_f8_kernel, dim3((unsigned)std::min<size_t>((total / 4 + 255) / 256, 65535)), dim3(256), 0, e->stream,
-                 (const float*)e->stage, (unsigned char*)L.w_dma, 2 * C, 4, L.Cin_pad, L.Cout_pad, 4, 1.0f, ldexpf(1.0f, L.w_exp), 9, 0, 0);
-    else if (L.w_dma)
-      SDM_LAUNCH(pack_conv_weight_dma_kernel, dim3((unsigned)std::min<size_t>((total * (L.split ? 2 : 1) + 255) / 256, 65535)), dim3(256), 0, e->stream,
-                 (const float*)e->stage, L.w_dma, 2 * C, 4, L.Cin_pad, L.Cout_pad, 4, ldexpf(1.0f, L.w_exp), L.split ? 2 : 1);
     SDM_CHECK_DEV(e, dev_sync(e->stream));
     SDM_CHECK_DEV(e, dev_memcpy_h2d(e->stage, bf.data(), bf.size() * 4, e->stream));
     SDM_LAUNCH(pack_bias_kernel, dim3(sdm_cdiv(L.Cout_pad, 256)), dim3(256), 0, e->stream, (const float*)e->stage, L.b, 2 * C, L.Cout_pad, 0, 0);
     SDM_CHECK_DEV(e, dev_sync(e->stream));
   }
+  return 0;
+}
+
+// Derived weight layouts (k_conv.h "derived weight layouts") of a set of layers from their canonical K16 tensors.  Two passes so that
+// ONE host round trip serves every layer: the |max| of each fp8-residual layer (device reductions into a small table), then the
+// layout kernels with the per-layer e4m3 scale 2^e8 = the largest power of two that keeps max|w| * 2^e8 <= 448.
+static int derive_layers(sdm_ctx* e, std::vector<ConvL*>& layers) {
+  std::vector<ConvL*> f8;
+  for (ConvL* L : layers) if (L->w_dma && L->f8) f8.push_back(L);
+  if (!f8.empty()) {
+    const size_t tb = rupz(f8.size() * 4, 256);
+    if (ensure_buf(e, &e->stage, &e->stage_bytes, std::max(tb, (size_t)1 << 20)) != 0) return SDM_ERR_NOMEM;
+    SDM_CHECK_DEV(e, dev_memset(e->stage, 0, tb, e->stream));
+    for (size_t i = 0; i < f8.size(); ++i) {
+      const size_t n = (size_t)f8[i]->Cin_pad * f8[i]->ntaps * f8[i]->Cout_pad;
+      SDM_LAUNCH(absmax_f16_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, e->stream, (const half_t*)f8[i]->w, n,
+                 (unsigned int*)e->stage + i);
+    }
+    std::vector<float> mx(f8.size());
+    SDM_CHECK_DEV(e, dev_memcpy_d2h(mx.data(), e->stage, f8.size() * 4, e->stream));
+    SDM_CHECK_DEV(e, dev_sync(e->stream));
+    for (size_t i = 0; i < f8.size(); ++i) {
+      const float wmax = ldexpf(mx[i], -f8[i]->w_exp);            // K16 keeps w * 2^w_exp
+      int ex = 8;
+      if (wmax > 0.0f && std::isfinite(wmax)) {
+        ex = (int)floorf(log2f(448.0f / wmax));
+        while (ldexpf(wmax, ex) > 448.0f) --ex;                   // guard the rounding of log2f
+        ex = std::max(-60, std::min(60, ex));
+      }
+      f8[i]->f8_exp = ex;
+    }
+  }
+  for (ConvL* L : layers) {
+    if (!L->w_dma) continue;
+    const size_t total = (size_t)L->Cin_pad * L->ntaps * L->Cout_pad;
+    if (L->f8)
+      SDM_LAUNCH(derive_conv_weight_f8_kernel, dim3((unsigned)std::min<size_t>((total / 4 + 255) / 256, 65535)), dim3(256), 0, e->stream,
+                 (const half_t*)L->w, (const half_t*)L->w_lo, (unsigned char*)L->w_dma, L->Cin_pad, L->Cout_pad, L->ntaps, ldexpf(1.0f, -L->w_exp),
+                 ldexpf(1.0f, L->f8_exp));
+    else
+      SDM_LAUNCH(derive_conv_weight_dma_kernel, dim3((unsigned)std::min<size_t>((total * (L->split ? 2 : 1) + 255) / 256, 65535)), dim3(256), 0, e->stream,
+                 (const half_t*)L->w, (const half_t*)L->w_lo, L->w_dma, L->Cin_pad, L->Cout_pad, L->split ? 2 : 1);
+  }
+  SDM_CHECK_DEV(e, dev_sync(e->stream));
   return 0;
 }
 
@@ -1950,6 +2006,12 @@ int sdm_finalize_weights(sdm_ctx* e) {
   SDM_CHECK_DEV(e, dev_sync(e->stream));
   load_ring_release(e);          // the checkpoint is in: give the pinned / device staging ring back
   { int rc = fold_cross_kv(e); if (rc) return rc; }
+  {   // the canonical K16 tensors are complete: build every derived layout from them
+    std::vector<ConvL*> all;
+    for (auto& L : e->convs) all.push_back(&L);
+    int rc = derive_layers(e, all);
+    if (rc) return rc;
+  }
   e->missing.clear();
   for (auto& k : e->slot_order) if (!e->slots[k].loaded) e->missing.push_back(k);
   e->variants.clear();
@@ -1970,18 +2032,18 @@ const char* sdm_missing_key(sdm_ctx* e, int64_t i) {
   return e->missing[(size_t)i].c_str();
 }
 
-int64_t sdm_weight_blob_bytes(sdm_ctx* e) { return e ? (int64_t)e->warena_bytes : 0; }
+int64_t sdm_weight_blob_bytes(sdm_ctx* e) { return e ? (int64_t)e->canon_bytes : 0; }
 int sdm_export_weight_blob(sdm_ctx* e, void* dst) {
   if (e) dev_use(e->device);
   if (!e || !dst) return SDM_ERR_INVALID;
-  SDM_CHECK_DEV(e, dev_memcpy_d2d(dst, e->warena, e->warena_bytes, e->stream));
+  SDM_CHECK_DEV(e, dev_memcpy_d2d(dst, e->warena, e->canon_bytes, e->stream));
   SDM_CHECK_DEV(e, dev_sync(e->stream));
   return SDM_OK;
 }
 int sdm_import_weight_blob(sdm_ctx* e, const void* src) {
   if (e) dev_use(e->device);
   if (!e || !src) return SDM_ERR_INVALID;
-  SDM_CHECK_DEV(e, dev_memcpy_d2d(e->warena, src, e->warena_bytes, e->stream));
+  SDM_CHECK_DEV(e, dev_memcpy_d2d(e->warena, src, e->canon_bytes, e->stream));
   SDM_CHECK_DEV(e, dev_sync(e->stream));
   for (auto& kv : e->slots) if (kv.second.kind != SLOT_HOST && !kv.second.loaded) { kv.second.loaded = true; e->n_loaded++; }
   e->finalized = false;
@@ -2048,13 +2110,20 @@ int64_t sdm_resident_bytes(sdm_ctx* e) {
   return e ? (int64_t)(e->warena_bytes + e->arena_bytes + e->io_in_bytes + e->io_out_bytes + e->stage_bytes) : 0;
 }
 
-int sdm_apply_matte_node(sdm_ctx* e, const float* image, const float* trimap, int B, int H, int W, int S, int is_transparent, int output_mode,
-                         int mask_refine, float trimap_constraint, float* alpha, float* matted, int ptr_kind, void* stream) {
+int sdm_apply_matte_node(sdm_ctx* e, const float* image, const float* trimap, int B, int H, int W, int trimap_h, int trimap_w, int S,
+                         int is_transparent, int output_mode, int mask_refine, double trimap_constraint, float* alpha, float* matted, int ptr_kind,
+                         void* stream) {
   if (e) dev_use(e->device);
   if (!e || !image || !trimap || !alpha || !matted) return SDM_ERR_INVALID;
   if (output_mode < 0 || output_mode > 2) SDM_FAIL(e, SDM_ERR_INVALID, "unknown output mode %d", output_mode);
+  if (trimap_h <= 0 || trimap_w <= 0) SDM_FAIL(e, SDM_ERR_INVALID, "bad trimap size %dx%d", trimap_h, trimap_w);
+  // the reference indexes the (H, W) alpha with the trimap only for mask_refine and matted_rgb (sdmatte_nodes.py:365-380,390-394):
+  // only those need equal sizes
+  if ((trimap_h != H || trimap_w != W) && (mask_refine || output_mode == 2))
+    SDM_FAIL(e, SDM_ERR_INVALID, "trimap %dx%d does not match the image %dx%d (needed by mask_refine / matted_rgb)", trimap_h, trimap_w, H, W);
   std::vector<int32_t> it((size_t)std::max(B, 1), is_transparent ? 1 : 0);
   NodeTail tail; tail.output_mode = output_mode; tail.mask_refine = mask_refine ? 1 : 0; tail.c = trimap_constraint; tail.matted = matted;
+  tail.TH = trimap_h; tail.TW = trimap_w;
   return forward_impl(e, 1, image, trimap, B, H, W, S, it.data(), nullptr, 4, 0, true, alpha, ptr_kind, stream, &tail);
 }
 
@@ -2129,24 +2198,16 @@ int sdm_op_conv_ex(sdm_ctx* e, const void* in0, const void* in1, int C0, int C1,
   if (bias) SDM_LAUNCH(pack_bias_kernel, dim3(sdm_cdiv(L.Cout_pad, 256)), dim3(256), 0, e->stream, bias, L.b, O, L.Cout_pad, 0, geglu);
   void* wd = nullptr;
   if (ntaps == 9 && L.Cout_pad >= 128 && !geglu) {      // stage-ordered copy for the DMA-weight kernel (tile cfg 0), as in the engine
-    const size_t tot2 = total * (split ? 2 : 1);
-    SDM_CHECK_DEV(e, dev_malloc(&wd, tot2 * 2));
+    SDM_CHECK_DEV(e, dev_malloc(&wd, total * (split ? 2 : 1) * 2));
     L.w_dma = (half_t*)wd;
     L.f8 = (split && L.Cin_pad % 32 == 0 && conv_f8_enabled()) ? 1 : 0;
-    if (L.f8)
-      SDM_LAUNCH(pack_conv_weight_f8_kernel, dim3((unsigned)std::min<size_t>((total / 4 + 255) / 256, 65535)), dim3(256), 0, e->stream, w,
-                 (unsigned char*)L.w_dma, O, L.I, L.Cin_pad, L.Cout_pad, 0, 1.0f, ldexpf(1.0f, L.w_exp), ntaps, 0, geglu);
-    else
-    SDM_LAUNCH(pack_conv_weight_dma_kernel, dim3((unsigned)std::min<size_t>((tot2 + 255) / 256, 65535)), dim3(256), 0, e->stream, w, L.w_dma, O, L.I,
-               L.Cin_pad, L.Cout_pad, 0, ldexpf(1.0f, L.w_exp), split ? 2 : 1);
   }
   if (ntaps == 1 && split && L.Cout_pad >= 128 && L.Cin_pad % 32 == 0 && conv_f8_enabled() && gemm_f8_enabled()) {      // fp8-residual copy for the 8-wave GEMM kernel
     SDM_CHECK_DEV(e, dev_malloc(&wd, total * 4));
     dev_memset(wd, 0, total * 4, e->stream);
     L.w_dma = (half_t*)wd; L.f8 = 1;
-    SDM_LAUNCH(pack_conv_weight_f8_kernel, dim3((unsigned)std::min<size_t>((total / 4 + 255) / 256, 65535)), dim3(256), 0, e->stream, w,
-               (unsigned char*)L.w_dma, O, L.I, L.Cin_pad, L.Cout_pad, 0, 1.0f, ldexpf(1.0f, L.w_exp), 1, 0, geglu);
   }
+  if (L.w_dma) { std::vector<ConvL*> one{&L}; TRY(derive_layers(e, one)); }
   int Ho = Hin << up, Wo = Win << up;
   if (stride == 2) { Ho /= 2; Wo /= 2; }
   const int Cst = rup(geglu ? O / 2 : O, 4);   // rows are stored with 4-channel vectors
@@ -2291,11 +2352,11 @@ float sdm_bench_conv(sdm_ctx* e, int N, int H, int W, int Cin, int Cout, int nta
   }
   if (split) p.w_lo = (const half_t*)wl;
   p.pc = (split && p.w_dma && pcf) ? 1 : 0;
-  if (split && p.w_dma && f8f && L.Cin_pad % 32 == 0) { p.f8 = 1; p.f8_sa = 127 - 13; p.f8_sb = 127 - kSplitWeightExp; p.acc_scale = 1.f; }
+  if (split && p.w_dma && f8f && L.Cin_pad % 32 == 0) { p.f8 = 1; p.f8_sa = 127 - 11; p.f8_sb = 127 - kSplitWeightExp; p.acc_scale = 1.f; }
   if (split && ntaps == 1 && f8f && L.Cin_pad % 32 == 0 && L.Cout_pad >= 128) {      // 1x1 GEMM on the fp8-residual kernel (tile cfg 4)
     if (dev_malloc(&wdm, wbytes * 2)) return -2.f;
     SDM_LAUNCH(fill_random_f16_kernel, dim3(2048), dim3(256), 0, e->stream, (half_t*)wdm, (long)wbytes, 29u, 0.05f);
-    p.w_dma = (const half_t*)wdm; p.f8 = 1; p.f8_sa = 127 - 13; p.f8_sb = 127 - kSplitWeightExp; p.acc_scale = 1.f;
+    p.w_dma = (const half_t*)wdm; p.f8 = 1; p.f8_sa = 127 - 11; p.f8_sb = 127 - kSplitWeightExp; p.acc_scale = 1.f;
   }
   if (gnf) { p.gn_scale = (const float*)gnt; p.gn_shift = (const float*)gnt + (size_t)N * L.Cin_pad; p.gn_silu = 1; }
   int cfg = tile_cfg >= 0 ? tile_cfg : conv_pick_cfg(ntaps, stride, p);
@@ -2405,23 +2466,34 @@ int sdm_op_attention(sdm_ctx* e, const void* q, int ldq, const void* k, int ldk,
   });
 }
 
-/* Split-precision d = 64 attention (the default precision's attention cores): q / k / v arrive as two fp16 planes hi | lo (the lo plane
- * `*_lo_off` ELEMENTS behind the hi plane, same strides), the output is fp32.  Test hook for the kernel the engine runs. */
-int sdm_op_attention_split(sdm_ctx* e, const void* q, int ldq, long q_lo_off, const void* k, int ldk, long k_lo_off, const void* v, int ldv,
-                           long v_lo_off, const float* bias, int B, int heads, int Lq, int Lk, float* out, int ldo) {
+/* Split-precision d = 64 attention cores as the default precision runs them.  q [B,Lq,heads*64], k / v [B,Lk,heads*64]: contiguous fp32
+ * DEVICE tensors.  They are first turned into the operand planes the producing GEMMs write in the engine (split_planes_kernel: fp16 hi plane
+ * + fp16 lo plane, or + e5m2 pair plane when the Q.K^T residual terms run on fp8 MFMAs - the default; SDM_ATTN_F8=0 selects the former),
+ * with the logit scale d^-1/2 * log2(e) applied to Q as the engine's to_q weights do; fp32 output [B,Lq,heads*64].  Test hook. */
+int sdm_op_attention_split(sdm_ctx* e, const float* q, const float* k, const float* v, const float* bias, int B, int heads, int Lq, int Lk, float* out) {
   if (e) dev_use(e->device);
   if (!e || !q || !k || !v || !out) return SDM_ERR_INVALID;
+  const int C = heads * 64;
+  const char* pvs = getenv("SDM_ATTN_PV_SPLIT");
+  const int mode = (attn_f8_enabled() && !(pvs && pvs[0] == '1')) ? 3 : 2;
   return run_two_pass(e, [&]() {
     T b2 = talloc(e, B, 1, 1, Lk, 1);
+    T qp = talloc(e, B, 1, Lq, C, mode), kp = talloc(e, B, 1, Lk, C, mode), vp = talloc(e, B, 1, Lk, C, mode);
     const float* bl2 = nullptr;
-    if (bias) {
-      bl2 = (const float*)b2.p;
-      if (!e->dry) SDM_LAUNCH(scale_copy_kernel, dim3(sdm_cdiv(B * Lk, 256)), dim3(256), 0, e->stream, bias, (float*)b2.p, (long)B * Lk, SDM_LOG2E);
+    const long nq = (long)B * Lq * C, nk = (long)B * Lk * C;
+    if (!e->dry) {
+      if (bias) {
+        bl2 = (const float*)b2.p;
+        SDM_LAUNCH(scale_copy_kernel, dim3(sdm_cdiv(B * Lk, 256)), dim3(256), 0, e->stream, bias, (float*)b2.p, (long)B * Lk, SDM_LOG2E);
+      }
+      SDM_LAUNCH(split_planes_kernel, dim3((unsigned)((nq / 4 + 255) / 256)), dim3(256), 0, e->stream, q, (half_t*)qp.p, (half_t*)qp.p + nq, nq, 0.125f * SDM_LOG2E, mode);
+      SDM_LAUNCH(split_planes_kernel, dim3((unsigned)((nk / 4 + 255) / 256)), dim3(256), 0, e->stream, k, (half_t*)kp.p, (half_t*)kp.p + nk, nk, 1.0f, mode);
+      SDM_LAUNCH(split_planes_kernel, dim3((unsigned)((nk / 4 + 255) / 256)), dim3(256), 0, e->stream, v, (half_t*)vp.p, (half_t*)vp.p + nk, nk, 1.0f, 2);
     }
-    AttnPrec ap; ap.prec = 1; ap.q_lo = q_lo_off; ap.k_lo = k_lo_off; ap.v_lo = v_lo_off; ap.out_f32 = 1;
-    int rc = op_attention_raw(e, (const half_t*)q, ldq, (const half_t*)k, ldk, (const half_t*)v, ldv, bias ? bl2 : nullptr, B, heads, Lq, Lk, 64,
-                              out, ldo, false, nullptr, ap);
-    tfree(e, b2);
+    AttnPrec ap; ap.prec = mode - 1; ap.q_lo = nq; ap.k_lo = nk; ap.v_lo = nk; ap.out_f32 = 1;
+    int rc = op_attention_raw(e, (const half_t*)qp.p, C, (const half_t*)kp.p, C, (const half_t*)vp.p, C, bias ? bl2 : nullptr, B, heads, Lq, Lk, 64,
+                              out, C, true, nullptr, ap);
+    tfree(e, vp); tfree(e, kp); tfree(e, qp); tfree(e, b2);
     return rc;
   });
 }

@@ -113,7 +113,7 @@ class Bindings:
             "sdm_forward_ex": (i32, [vp, vp, vp, i32, i32, vp, vp, i32, i32, i32, vp, i32, vp]),
             "sdm_forward_rect": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, i32, i32, i32, vp, i32, vp]),
             "sdm_apply_matte": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, vp]),
-            "sdm_apply_matte_node": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, i32, vp]),
+            "sdm_apply_matte_node": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, C.c_double, vp, vp, i32, vp]),
             "sdm_synchronize": (i32, [vp]),
             "sdm_release_memory": (i32, [vp]),
             "sdm_resident_bytes": (i64, [vp]),
@@ -135,7 +135,7 @@ class Bindings:
             "sdm_op_groupnorm": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, f32, i32, vp]),
             "sdm_op_layernorm": (i32, [vp, vp, i32, C.c_long, i32, vp, vp, f32, vp]),
             "sdm_op_attention": (i32, [vp, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32]),
-            "sdm_op_attention_split": (i32, [vp, vp, i32, C.c_long, vp, i32, C.c_long, vp, i32, C.c_long, vp, i32, i32, i32, i32, vp, i32]),
+            "sdm_op_attention_split": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
             "sdm_op_resize_aa": (i32, [vp, vp, i32, i32, i32, vp, i32, i32]),
             "sdm_op_mask_bias": (i32, [vp, vp, i32, i32, i32, vp]),
         }
@@ -282,7 +282,9 @@ class Engine:
 
     def apply_matte(self, image_bhwc: torch.Tensor, trimap_bhw: torch.Tensor, S: int, is_transparent=False, out=None, sync=True):
         """Device part of SDMatteApply.apply_matte: raw image [B,H,W,3] + trimap [B,H,W] in [0,1] -> alpha [B,H,W]."""
-        B, H, W, _ = image_bhwc.shape
+        B, H, W, Cc = image_bhwc.shape
+        if Cc != 3:
+            raise ValueError(f"apply_matte: image must be [B,H,W,3], got {tuple(image_bhwc.shape)}")
         image_bhwc = image_bhwc.float().contiguous()
         trimap_bhw = trimap_bhw.float().contiguous()
         if tuple(trimap_bhw.shape) != (B, H, W):
@@ -305,16 +307,22 @@ class Engine:
         the GPU.  Returns (alpha [B,H,W], matted [B,H,W,3|4]) on the inputs' device."""
         if output_mode not in self.OUTPUT_MODES:
             raise ValueError(f"unknown output_mode {output_mode!r}")
-        B, H, W, _ = image_bhwc.shape
+        B, H, W, Cc = image_bhwc.shape
+        if Cc != 3:
+            raise ValueError(f"apply_matte_node: image must be [B,H,W,3], got {tuple(image_bhwc.shape)}")
         image_bhwc = image_bhwc.float().contiguous()
         trimap_bhw = trimap_bhw.float().contiguous()
-        if tuple(trimap_bhw.shape) != (B, H, W):
-            raise ValueError(f"apply_matte_node: trimap must be [B,H,W] = {(B, H, W)}, got {tuple(trimap_bhw.shape)}")
+        if trimap_bhw.dim() != 3 or trimap_bhw.shape[0] != B:
+            raise ValueError(f"apply_matte_node: trimap must be [B,h,w] with B = {B}, got {tuple(trimap_bhw.shape)}")
+        TH, TW = int(trimap_bhw.shape[1]), int(trimap_bhw.shape[2])
         mode = self.OUTPUT_MODES[output_mode]
+        if (TH, TW) != (H, W) and (mask_refine or mode == 2):
+            # where the reference fails too: it indexes the (H, W) alpha with the trimap (sdmatte_nodes.py:365-380,390-394)
+            raise IndexError(f"apply_matte_node: the trimap {(TH, TW)} must match the image {(H, W)} for mask_refine / matted_rgb")
         alpha = torch.empty(B, H, W, dtype=torch.float32, device=image_bhwc.device)
         matted = torch.empty(B, H, W, 4 if mode == 1 else 3, dtype=torch.float32, device=image_bhwc.device)
         stream = self._check_io("apply_matte_node", image_bhwc, trimap_bhw, alpha, matted)
-        self._check(self.lib.sdm_apply_matte_node(self.h, _ptr(image_bhwc), _ptr(trimap_bhw), B, H, W, int(S), 1 if is_transparent else 0, mode,
+        self._check(self.lib.sdm_apply_matte_node(self.h, _ptr(image_bhwc), _ptr(trimap_bhw), B, H, W, TH, TW, int(S), 1 if is_transparent else 0, mode,
                                                   1 if mask_refine else 0, float(trimap_constraint), _ptr(alpha), _ptr(matted),
                                                   self._kind(image_bhwc), stream), "sdm_apply_matte_node")
         if sync:
@@ -424,17 +432,13 @@ class Engine:
         return out
 
     def op_attention_split(self, q, k, v, heads, bias=None):
-        """Split-precision attention cores (head dim 64): q [B,Lq,h*64], k / v [B,Lk,h*64] fp32; they are split into fp16 planes
-        hi | lo here, as the producing GEMM's epilogue does in the engine; fp32 output."""
-        def planes(x):
-            hi = x.half()
-            return torch.stack([hi, (x - hi.float()).half()]).contiguous()
+        """Split-precision attention cores (head dim 64): q [B,Lq,h*64], k / v [B,Lk,h*64] fp32; the C side splits them into the operand
+        planes the producing GEMM epilogues write in the engine (fp16 high parts + fp8 residual pairs for Q.K^T); fp32 output."""
         B, Lq, HD = q.shape
         Lk = k.shape[1]
-        qp, kp, vp_ = planes(q.float()), planes(k.float()), planes(v.float())
+        qf, kf, vf = q.float().contiguous(), k.float().contiguous(), v.float().contiguous()
         out = torch.empty(B, Lq, HD, dtype=torch.float32, device=q.device)
-        self._check(self.lib.sdm_op_attention_split(self.h, _ptr(qp), HD, qp[0].numel(), _ptr(kp), HD, kp[0].numel(), _ptr(vp_), HD, vp_[0].numel(),
-                                                    _ptr(bias), B, heads, Lq, Lk, _ptr(out), HD), "sdm_op_attention_split")
+        self._check(self.lib.sdm_op_attention_split(self.h, _ptr(qf), _ptr(kf), _ptr(vf), _ptr(bias), B, heads, Lq, Lk, _ptr(out)), "sdm_op_attention_split")
         return out
 
     def op_resize_aa(self, planes, Hout, Wout):

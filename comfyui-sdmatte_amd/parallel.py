@@ -31,7 +31,10 @@ def broadcast_weights(engine, src: int = 0, device=None):
         buf[nw:].copy_(hblob)
     dist.broadcast(buf, src)
     if rank != src:
-        engine.import_weights(buf[:nw], buf[nw:].cpu())
+        hblob = buf[nw:].cpu()
+        if buf.is_cuda:
+            torch.cuda.current_stream(buf.device).synchronize()      # the import reads `buf` on the engine's own stream: the broadcast must have landed
+        engine.import_weights(buf[:nw], hblob)
 
 
 def gather_alphas(alpha: torch.Tensor, dst: int = 0):
@@ -151,15 +154,47 @@ class MultiGpuEngine:
         return res
 
     def _copy_weights(self):
+        """Packed (canonical) weight arena of engine 0 -> every other engine.  The peer copies run concurrently, one torch stream
+        per destination (xGMI is point to point: every peer has its own link to device 0), and every copy has COMPLETED before
+        the receiving engine imports the blob: `sdm_import_weight_blob` reads it on the engine's own non-blocking stream, which
+        is not ordered against torch's streams."""
         e0 = self.engines[0]
-        if len(self.engines) > 1:
-            dev0 = torch.device("cuda", self.devices[0]) if self._on_device else torch.device("cpu")
-            blob = torch.empty(e0.weight_blob_bytes(), dtype=torch.uint8, device=dev0)
-            hblob = torch.empty(e0.host_blob_bytes(), dtype=torch.uint8)
+        if len(self.engines) < 2:
+            return
+        hblob = torch.empty(e0.host_blob_bytes(), dtype=torch.uint8)
+        if not self._on_device:                                    # emulator engines (tests): host memory
+            blob = torch.empty(e0.weight_blob_bytes(), dtype=torch.uint8)
             e0.export_weights(blob, hblob)
-            for d, e in zip(self.devices[1:], self.engines[1:]):
-                peer = blob.to(torch.device("cuda", d)) if self._on_device else blob      # hipMemcpyPeer over xGMI
-                e.import_weights(peer, hblob)
+            for e in self.engines[1:]:
+                e.import_weights(blob, hblob)
+            return
+        dev0 = torch.device("cuda", self.devices[0])
+        blob = torch.empty(e0.weight_blob_bytes(), dtype=torch.uint8, device=dev0)
+        e0.export_weights(blob, hblob)                             # returns after a host sync of engine 0's stream
+        peers, streams = [], []
+        for d in self.devices[1:]:
+            st = torch.cuda.Stream(device=dev0)
+            with torch.cuda.stream(st):
+                peers.append(blob.to(torch.device("cuda", d), non_blocking=True))      # hipMemcpyPeerAsync over that peer's xGMI link
+            streams.append(st)
+        for st, d in zip(streams, self.devices[1:]):
+            st.synchronize()
+            torch.cuda.synchronize(d)
+        for e, peer in zip(self.engines[1:], peers):
+            e.import_weights(peer, hblob)
+
+    def _host(self, *shape):
+        """Host tensor the engines copy into / out of: page-locked when GPUs are driven (pageable memory would make every shard's
+        hipMemcpyAsync a staged, blocking copy), plain otherwise."""
+        return torch.empty(*shape, dtype=torch.float32, pin_memory=self._on_device)
+
+    def _to_host(self, t):
+        t = t.detach().float()
+        if t.device.type == "cpu" and (not self._on_device or t.is_pinned()):
+            return t.contiguous()
+        buf = self._host(*t.shape)
+        buf.copy_(t)
+        return buf
 
     def _fan(self, B, call):
         import threading
@@ -187,9 +222,9 @@ class MultiGpuEngine:
     def apply_matte(self, image_bhwc, trimap_bhw, S, is_transparent=False):
         """image [B,H,W,3], trimap [B,H,W] (host or any device) -> alpha [B,H,W] fp32 on the HOST (what the node returns)."""
         B, H, W, _ = image_bhwc.shape
-        out = torch.empty(B, H, W, dtype=torch.float32)
-        img = image_bhwc.detach().float().cpu().contiguous()
-        tri = trimap_bhw.detach().float().cpu().contiguous()
+        out = self._host(B, H, W)
+        img = self._to_host(image_bhwc)
+        tri = self._to_host(trimap_bhw)
 
         def call(eng, dev, lo, hi):
             # host pointers: the engine copies its shard in on its own stream, runs, copies the alphas out and synchronises
@@ -204,10 +239,10 @@ class MultiGpuEngine:
         from .engine import Engine
         B, H, W, _ = image_bhwc.shape
         ch = 4 if Engine.OUTPUT_MODES[output_mode] == 1 else 3
-        alpha = torch.empty(B, H, W, dtype=torch.float32)
-        matted = torch.empty(B, H, W, ch, dtype=torch.float32)
-        img = image_bhwc.detach().float().cpu().contiguous()
-        tri = trimap_bhw.detach().float().cpu().contiguous()
+        alpha = self._host(B, H, W)
+        matted = self._host(B, H, W, ch)
+        img = self._to_host(image_bhwc)
+        tri = self._to_host(trimap_bhw)
 
         def call(eng, dev, lo, hi):
             a, m = eng.apply_matte_node(img[lo:hi], tri[lo:hi], S, is_transparent, output_mode, mask_refine, trimap_constraint)

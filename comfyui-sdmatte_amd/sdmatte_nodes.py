@@ -147,13 +147,30 @@ def _torch_device():
     return torch.device("cuda", torch.cuda.current_device())
 
 
+class LazyCheckpoint:
+    """`state_dict`-like view of a .safetensors file that materialises ONE tensor at a time from the memory map (the engine packs
+    every tensor into its own arena as it arrives; a dict of all tensors would hold the whole 3.8 GB checkpoint on the host).
+    Only `text_encoder.*` is skipped up front: dead on this path (meta_arch.py:220-234 is never consumed, replace.py:414-416)."""
+
+    def __init__(self, path):
+        self.path = path
+
+    def keys(self):
+        from safetensors import safe_open
+        with safe_open(self.path, framework="pt", device="cpu") as f:
+            return [k for k in f.keys()]
+
+    def items(self):
+        from safetensors import safe_open
+        with safe_open(self.path, framework="pt", device="cpu") as f:
+            for key in f.keys():
+                if key.startswith("text_encoder."):
+                    continue
+                yield key, f.get_tensor(key)
+
+
 def load_checkpoint_state_dict(path):
-    from safetensors import safe_open
-    sd = {}
-    with safe_open(path, framework="pt", device="cpu") as f:
-        for key in f.keys():
-            sd[key] = f.get_tensor(key)
-    return sd
+    return LazyCheckpoint(path)
 
 
 def get_model(ckpt_name, device):
@@ -206,9 +223,11 @@ def unload_models():
 
 
 def _fan_out(model, batch):
-    """Multi-GPU fan-out of one node call: used when the batch has more than one image, more than one GPU is visible and
-    SDMATTE_MULTI_GPU is not "0".  The extra engines live as long as the cached model they were copied from."""
-    if batch < 2 or os.environ.get("SDMATTE_MULTI_GPU", "1") == "0" or not torch.cuda.is_available():
+    """Multi-GPU fan-out of one node call.  OPT-IN (SDMATTE_MULTI_GPU=1): every extra GPU receives its own copy of the packed weights
+    (~12 GB in the default precision) plus an activation arena, outside ComfyUI's memory manager, and those GPUs may belong to
+    other models or processes.  Used when the batch has more than one image and more than one GPU is visible; the extra engines
+    live as long as the cached model they were copied from (`unload_models()` frees them)."""
+    if batch < 2 or os.environ.get("SDMATTE_MULTI_GPU", "0") != "1" or not torch.cuda.is_available():
         return None
     ndev = torch.cuda.device_count()
     if ndev < 2:
@@ -279,8 +298,10 @@ class SDMatteApply:
                                "(no CPU path).  Use the reference plugin for CPU inference.")
         if image.dim() != 4 or image.shape[-1] != 3:
             raise ValueError(f"[SDMatte] image must be [B,H,W,3], got {tuple(image.shape)}")
-        if trimap.dim() != 3 or tuple(trimap.shape) != tuple(image.shape[:3]):
-            raise ValueError(f"[SDMatte] trimap must be [B,H,W] matching the image, got {tuple(trimap.shape)}")
+        # the trimap is resized to the inference size on its own, as in the reference (sdmatte_nodes.py:212-214,349); its size only has
+        # to equal the image's where the reference indexes the alpha with it (mask_refine, matted_rgb): the engine raises there
+        if trimap.dim() != 3 or trimap.shape[0] != image.shape[0]:
+            raise ValueError(f"[SDMatte] trimap must be [B,h,w] with the image's batch size, got {tuple(trimap.shape)}")
         model = get_model(ckpt_name, _torch_device())
         fan = _fan_out(model, image.shape[0])
         # one C-ABI call per device: resize / normalise / model / resize back / clamp AND mask_refine + output composition, all on

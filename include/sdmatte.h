@@ -76,7 +76,8 @@ enum sdm_precise_stage {
   SDM_PRECISE_ALL = 63            /* (the single-head d=512 VAE attention core always runs on fp16 operands) */
 };
 
-/* Fill `cfg` with the SD-2.1-base / SDMatte constants. */
+/* Fill `cfg` with the SD-2.1-base / SDMatte constants and precise_mask = SDM_PRECISE_ALL (the precision that
+ * meets the parity bar; set it to 0 for the fast fp16-operand graph). */
 void sdm_default_config(sdm_config* cfg);
 
 /* Create an engine on GPU `device_id`.  Replaces SDMatte.__init__ / init_submodule (meta_arch.py:31-124)
@@ -143,8 +144,7 @@ int sdm_forward_rect(sdm_ctx* ctx, const float* image_b3hw, const float* aux_b1h
 /* Node-level call.  Replaces the device part of SDMatteApply.apply_matte (sdmatte_nodes.py:339-363):
  *   image fp32 [B,H,W,3] in [0,1], trimap fp32 [B,H,W] in [0,1]  ->  antialiased resize to SxS, normalise,
  *   forward, resize back to (H,W), clamp(0,1)  ->  alpha fp32 [B,H,W].
- * mask_refine / output_mode composition (sdmatte_nodes.py:365-397) stay in the Python node, as in the
- * reference, where they run on the CPU copy. */
+ * (alpha only; sdm_apply_matte_node below adds mask_refine and the output composition on the GPU.) */
 int sdm_apply_matte(sdm_ctx* ctx, const float* image_bhwc, const float* trimap_bhw, int B, int H, int W, int S,
                     int is_transparent, float* alpha_bhw, int ptr_kind, void* stream);
 
@@ -152,9 +152,13 @@ int sdm_apply_matte(sdm_ctx* ctx, const float* image_bhwc, const float* trimap_b
  * mask_refine (trimap_constraint; sdmatte_nodes.py:365-380) and the output composition (sdmatte_nodes.py:382-397):
  * output_mode 0 = alpha_only (matted = zeros [B,H,W,3]), 1 = matted_rgba ([B,H,W,4] = image | alpha), 2 = matted_rgb
  * ([B,H,W,3] = image gated by (trimap > 0.2) & (alpha > 0.1)).  Bit-identical to the reference's CPU tensor arithmetic. */
-int sdm_apply_matte_node(sdm_ctx* ctx, const float* image_bhwc, const float* trimap_bhw, int B, int H, int W, int S, int is_transparent,
-                         int output_mode, int mask_refine, float trimap_constraint, float* alpha_bhw, float* matted_bhwc, int ptr_kind,
-                         void* stream);
+/* The trimap [B,trimap_h,trimap_w] is resized to SxS on its own, as in the reference (sdmatte_nodes.py:212-214,349): it only has to
+ * match the image where the reference indexes the alpha with it, i.e. with mask_refine != 0 or output_mode 2 (SDM_ERR_INVALID otherwise).
+ * trimap_constraint is a double: the thresholds are float32(c) and float32(1.0 - c) with 1.0 - c evaluated in double, as torch does
+ * for the reference's Python-float comparisons. */
+int sdm_apply_matte_node(sdm_ctx* ctx, const float* image_bhwc, const float* trimap_bhw, int B, int H, int W, int trimap_h, int trimap_w, int S,
+                         int is_transparent, int output_mode, int mask_refine, double trimap_constraint, float* alpha_bhw, float* matted_bhwc,
+                         int ptr_kind, void* stream);
 
 /* Memory the engine holds outside any framework allocator: packed weights + activation arena (sized by the largest batch /
  * resolution seen) + I/O staging.  sdm_release_memory frees everything but the weights (the next forward re-allocates). */
@@ -216,9 +220,10 @@ int sdm_op_layernorm(sdm_ctx* ctx, const void* x, int in_f32, long rows, int C, 
  * every tile; setting the environment variable SDM_ATTN_DENSE disables the skip. */
 int sdm_op_attention(sdm_ctx* ctx, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* bias,
                      int B, int heads, int Lq, int Lk, int D, void* out, int ldo);
-/* Split-precision attention cores (head dim 64): q / k / v as fp16 planes hi | lo (lo plane `*_lo_off` elements behind), fp32 output. */
-int sdm_op_attention_split(sdm_ctx* ctx, const void* q, int ldq, long q_lo_off, const void* k, int ldk, long k_lo_off, const void* v, int ldv,
-                           long v_lo_off, const float* bias, int B, int heads, int Lq, int Lk, float* out, int ldo);
+/* Split-precision attention cores (head dim 64) as the default precision runs them: contiguous fp32 q [B,Lq,heads*64], k / v [B,Lk,heads*64]
+ * are split into the operand planes the engine's GEMM epilogues produce (fp16 high parts + e5m2 residual pairs for Q.K^T, fp16 V), the
+ * logit scale goes into Q; fp32 output [B,Lq,heads*64].  Test hook for the kernel the engine runs. */
+int sdm_op_attention_split(sdm_ctx* ctx, const float* q, const float* k, const float* v, const float* bias, int B, int heads, int Lq, int Lk, float* out);
 /* Antialiased bilinear resize of fp32 planes [P, Hin, Win] -> [P, Hout, Wout] (torchvision Resize). */
 int sdm_op_resize_aa(sdm_ctx* ctx, const float* in, int P, int Hin, int Win, float* out, int Hout, int Wout);
 /* Level-k additive key bias (natural-log domain) from the [-1,1] trimap plane [B,S,S] -> [B,(S/8>>k)^2]. */

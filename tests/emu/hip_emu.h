@@ -89,6 +89,7 @@ static inline int __any(int pred) {
 // ---- atomics (global memory may be touched by several OS threads = several workgroups) ----
 static inline float atomicAdd(float* p, float v) { std::lock_guard<std::mutex> g(emu::g_atomic_mu); float o = *p; *p = o + v; return o; }
 static inline double atomicAdd(double* p, double v) { std::lock_guard<std::mutex> g(emu::g_atomic_mu); double o = *p; *p = o + v; return o; }
+static inline unsigned int atomicMax(unsigned int* p, unsigned int v) { std::lock_guard<std::mutex> g(emu::g_atomic_mu); unsigned int o = *p; if (v > o) *p = v; return o; }
 static inline int atomicAdd(int* p, int v) { std::lock_guard<std::mutex> g(emu::g_atomic_mu); int o = *p; *p = o + v; return o; }
 
 // ---- MFMA 32x32x16 f16 (gfx950): A[i][k]: lane l holds i=l&31, k=8*(l>>5)+j; B[k][n]: n=l&31, same k;
@@ -147,6 +148,35 @@ static inline int emu_cvt_pk_fp8_f32(float a, float b, int old, bool hi_word) {
   const unsigned int o = (unsigned int)old;
   return (int)(hi_word ? ((o & 0x0000ffffu) | (pk << 16)) : ((o & 0xffff0000u) | pk));
 }
+// OCP e5m2 ("bf8"): 1-5-2, bias 15, inf / NaN as in fp16 (it is the top byte of an fp16); round to nearest even
+static inline float emu_e5m2_to_f32(unsigned char v) {
+  const int s = v >> 7, e = (v >> 2) & 31, m = v & 3;
+  float r;
+  if (e == 0) r = ldexpf((float)m, -16);
+  else if (e == 31) r = m ? NAN : INFINITY;
+  else r = ldexpf(1.0f + m / 4.0f, e - 15);
+  return s ? -r : r;
+}
+static inline unsigned char emu_f32_to_e5m2(float x) {
+  const unsigned char sign = std::signbit(x) ? 0x80 : 0;
+  float a = fabsf(x);
+  if (!(a == a)) return sign | 0x7f;
+  if (a >= 61440.0f) return sign | 0x7c;                   // rounds beyond the largest finite value 57344 (callers clamp): inf
+  if (a < ldexpf(1.0f, -17)) return sign;                  // below half of the smallest subnormal 2^-16 (tie -> even = 0)
+  int e; frexpf(a, &e); e -= 1;                            // a = 1.xxx * 2^e
+  if (e < -14) e = -14;                                    // subnormal range: fixed step 2^-16
+  const float step = ldexpf(1.0f, e - 2);
+  const float v = nearbyintf(a / step) * step;             // default rounding mode: nearest even
+  if (v < ldexpf(1.0f, -14)) return sign | (unsigned char)nearbyintf(v / ldexpf(1.0f, -16));
+  int ee; frexpf(v, &ee); ee -= 1;
+  const int m = (int)nearbyintf((v / ldexpf(1.0f, ee) - 1.0f) * 4.0f);
+  return sign | (unsigned char)(((ee + 15) << 2) | m);
+}
+static inline int emu_cvt_pk_bf8_f32(float a, float b, int old, bool hi_word) {
+  const unsigned int pk = (unsigned int)emu_f32_to_e5m2(a) | ((unsigned int)emu_f32_to_e5m2(b) << 8);
+  const unsigned int o = (unsigned int)old;
+  return (int)(hi_word ? ((o & 0x0000ffffu) | (pk << 16)) : ((o & 0xffff0000u) | pk));
+}
 typedef int emu_i8v __attribute__((ext_vector_type(8)));
 static inline emu_f16v emu_mfma_scale_f32_32x32x64_fp8(emu_i8v a, emu_i8v b, emu_f16v c, int sa, int sb) {
   auto& w = emu::wave(); int l = emu::lane_id();
@@ -160,6 +190,46 @@ static inline emu_f16v emu_mfma_scale_f32_32x32x64_fp8(emu_i8v a, emu_i8v b, emu
       const unsigned char* av = (const unsigned char*)&w.slot[row + 32 * kh][0];
       const unsigned char* bv = (const unsigned char*)&w.slot[col + 32 * kh][8];
       for (int j = 0; j < 32; ++j) acc += (double)emu_e4m3_to_f32(av[j]) * (double)emu_e4m3_to_f32(bv[j]);
+    }
+    c[r] = c[r] + (float)acc * scale;
+  }
+  emu::wave_barrier();
+  return c;
+}
+
+// the same MFMA with the A operand in e5m2 (cbsz = 1) and B in e4m3
+static inline emu_f16v emu_mfma_scale_f32_32x32x64_bf8_fp8(emu_i8v a, emu_i8v b, emu_f16v c, int sa, int sb) {
+  auto& w = emu::wave(); int l = emu::lane_id();
+  memcpy(&w.slot[l][0], &a, 32); memcpy(&w.slot[l][8], &b, 32); emu::wave_barrier();
+  const float scale = ldexpf(1.0f, (sa & 255) - 127 + (sb & 255) - 127);
+  int col = l & 31, hi = l >> 5;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    double acc = 0.0;
+    for (int kh = 0; kh < 2; ++kh) {
+      const unsigned char* av = (const unsigned char*)&w.slot[row + 32 * kh][0];
+      const unsigned char* bv = (const unsigned char*)&w.slot[col + 32 * kh][8];
+      for (int j = 0; j < 32; ++j) acc += (double)emu_e5m2_to_f32(av[j]) * (double)emu_e4m3_to_f32(bv[j]);
+    }
+    c[r] = c[r] + (float)acc * scale;
+  }
+  emu::wave_barrier();
+  return c;
+}
+
+// ... and with both operands in e5m2 (cbsz = blgp = 1)
+static inline emu_f16v emu_mfma_scale_f32_32x32x64_bf8_bf8(emu_i8v a, emu_i8v b, emu_f16v c, int sa, int sb) {
+  auto& w = emu::wave(); int l = emu::lane_id();
+  memcpy(&w.slot[l][0], &a, 32); memcpy(&w.slot[l][8], &b, 32); emu::wave_barrier();
+  const float scale = ldexpf(1.0f, (sa & 255) - 127 + (sb & 255) - 127);
+  int col = l & 31, hi = l >> 5;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    double acc = 0.0;
+    for (int kh = 0; kh < 2; ++kh) {
+      const unsigned char* av = (const unsigned char*)&w.slot[row + 32 * kh][0];
+      const unsigned char* bv = (const unsigned char*)&w.slot[col + 32 * kh][8];
+      for (int j = 0; j < 32; ++j) acc += (double)emu_e5m2_to_f32(av[j]) * (double)emu_e5m2_to_f32(bv[j]);
     }
     c[r] = c[r] + (float)acc * scale;
   }

@@ -8,6 +8,7 @@ import sys
 import pytest
 import torch
 import torch.multiprocessing as mp
+import torch.nn.functional as F
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -78,6 +79,22 @@ def test_emu_gpu_node_tail_bit_exact_vs_reference_fixture(pkg, golden_dir):
         assert torch.equal(a, wa) and torch.equal(m, wm), str(tag)
     with pytest.raises(ValueError):
         eng.apply_matte_node(image, tri, 64, False, "nope", True, 0.8)
+    # a trimap of another size than the image: resized to the inference size on its own, as in the reference (sdmatte_nodes.py:212-214,
+    # 349); it only has to match where the reference indexes the alpha with it (mask_refine / matted_rgb), and fails there like it
+    from oracle import sdmatte_oracle as O
+    tri_small = F.interpolate(tri[:1, None], size=(29, 41), mode="bilinear", align_corners=False)[:, 0].contiguous()
+    a2, m2 = eng.apply_matte_node(image[:1], tri_small, 64, False, "matted_rgba", False, 0.8)
+    w = synthetic_state_dict(cfg, 0)
+    pred = O.sdmatte_forward(w, cfg.as_dict(), O.preprocess(image[:1], tri_small, 64, False))
+    ra, _ = O.postprocess(pred, image[:1], tri_small, "alpha_only", False, 0.8)
+    assert a2.shape == image.shape[1:3] or a2.shape == (1,) + tuple(image.shape[1:3])
+    assert (a2 - ra).abs().max().item() < 1e-2 and torch.equal(m2[..., :3], image[:1]) and torch.equal(m2[..., 3], a2)
+    with pytest.raises(IndexError):
+        eng.apply_matte_node(image[:1], tri_small, 64, False, "alpha_only", True, 0.8)       # mask_refine indexes alpha with the trimap
+    with pytest.raises(IndexError):
+        eng.apply_matte_node(image[:1], tri_small, 64, False, "matted_rgb", False, 0.8)
+    with pytest.raises(ValueError):
+        eng.apply_matte_node(image[:1, :, :, :2], tri[:1], 64, False, "alpha_only", False, 0.8)    # not an RGB image
     eng.close()
 
 

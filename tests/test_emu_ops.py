@@ -103,6 +103,19 @@ def test_f8_accumulator_layout_epilogue(emu_engine, monkeypatch, mode):
     S.check_conv(emu_engine, DEV, 1, 8, 32, 32, 128, ntaps=1, tile_cfg=4, in_f32=True, out_f32=True, split=True, f8=True, seed=75, atol=3e-4)
 
 
+def test_f8_residual_operand_ranges(emu_engine):
+    """The fp8 residual operands must not saturate on real-checkpoint ranges: activations x300 (e5m2 operands: the range of fp16),
+    weights x4 and x1/64 (e4m3 with the layer's own power-of-two scale, chosen from max|w| when the layer is packed) stay at the
+    ~2^-14 relative level of the arithmetic; with fixed scales the residual terms clamp and the result drops to the fp16-operand
+    level (~1e-3 relative)."""
+    for xs, ws, seed in ((300.0, 1.0, 91), (1.0, 4.0, 92), (300.0, 4.0, 93), (0.01, 1.0 / 64, 94)):
+        e = S.check_conv(emu_engine, DEV, 1, 8, 32, 64, 128, tile_cfg=0, in_f32=True, out_f32=True, split=True, f8=True, seed=seed, atol=3e-4,
+                         xscale=xs, wscale=ws, rel=True)
+        assert e < 1e-4, (xs, ws, e)
+    S.check_conv(emu_engine, DEV, 1, 8, 32, 64, 128, ntaps=1, tile_cfg=4, in_f32=True, out_f32=True, split=True, f8=True, res="f32", seed=95, atol=3e-4,
+                 xscale=300.0, wscale=4.0, rel=True)
+
+
 def test_conv3x3_thin_output_tile(emu_engine):
     S.check_conv(emu_engine, DEV, 2, 10, 33, 32, 3, in_f32=True, tile_cfg=4, seed=9)          # conv_out shape: Cout 3 -> one 32-wide tile
 
@@ -168,6 +181,17 @@ def test_attention_d64_split_precision(emu_engine, monkeypatch):
     monkeypatch.setenv("SDM_ATTN_PV_SPLIT", "1")
     e1 = S.check_attention(emu_engine, DEV, 1, 2, 70, 100, 64, use_bias=True, split=True, atol=3e-5)
     assert e1 < e2
+    monkeypatch.delenv("SDM_ATTN_PV_SPLIT")
+    # the residual terms of Q.K^T on fp8 MFMAs (PREC = 3, the default) against the same kernel with fp16 residual terms (SDM_ATTN_F8=0,
+    # PREC = 2): P.V is rounded identically in both, so the difference isolates the logit error of the e5m2 residual pairs
+    import torch
+    g = torch.Generator().manual_seed(21)
+    q, k, v = torch.randn(1, 70, 128, generator=g) * 1.5, torch.randn(1, 130, 128, generator=g) * 1.5, torch.randn(1, 130, 128, generator=g)
+    a8 = emu_engine.op_attention_split(q, k, v, 2)
+    monkeypatch.setenv("SDM_ATTN_F8", "0")
+    a16 = emu_engine.op_attention_split(q, k, v, 2)
+    d = (a8 - a16).abs().max().item()
+    assert 0.0 < d < 4e-4, d            # logit spread ~3x that of unit-variance q / k; fp16 operands alone are off by ~1e-2 here
 
 
 def test_attention_d64_skips_underflowing_key_tiles(emu_engine, monkeypatch):

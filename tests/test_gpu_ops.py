@@ -206,6 +206,27 @@ def test_conv3x3_fp8_residual_terms(eng, cin, cout, H, W, gn, res, up):
     print(f"[F8 conv {cin}->{cout}] max|d|={err:.2e}")
 
 
+@pytest.mark.parametrize("xs,ws", [(300.0, 1.0), (1.0, 4.0), (300.0, 4.0), (0.01, 1.0 / 64)])
+def test_f8_residual_operand_ranges(eng, xs, ws):
+    """Real-checkpoint ranges must not saturate the fp8 residual operands: activations x300 (e5m2 A operands = the range of fp16),
+    weights x4 / x1/64 (e4m3 with the layer's own power-of-two scale from max|w|), for the 3x3 and the GEMM form of the F8 kernel:
+    relative error stays at the ~2^-14 level of the arithmetic (fixed scales would clamp and fall to ~1e-3)."""
+    e = S.check_conv(eng, DEV, 2, 40, 96, 128, 128, tile_cfg=0, in_f32=True, out_f32=True, split=True, f8=True, seed=91, atol=3e-4, xscale=xs, wscale=ws, rel=True)
+    g = S.check_conv(eng, DEV, 1, 64, 64, 1280, 320, ntaps=1, tile_cfg=4, in_f32=True, out_f32=True, split=True, f8=True, res="f32", seed=95, atol=3e-4,
+                     xscale=xs, wscale=ws, rel=True)
+    print(f"[F8 ranges x{xs} w{ws}] conv {e:.2e} gemm {g:.2e}")
+    assert e < 1.5e-4 and g < 1.5e-4
+
+
+@pytest.mark.parametrize("mode", ["0", "3"])
+def test_f8_epilogue_modes(eng, monkeypatch, mode):
+    """SDM_CONV_EPI: residual as the accumulators' initial value (3) against the epilogue add (0), full and ragged tiles."""
+    monkeypatch.setenv("SDM_CONV_EPI", mode)
+    S.check_conv(eng, DEV, 2, 64, 128, 128, 160, tile_cfg=0, in_f32=True, out_f32=True, split=True, f8=True, gn=(1e-6, True), res="f32", seed=71, atol=3e-4)
+    S.check_conv(eng, DEV, 1, 44, 72, 64, 128, tile_cfg=0, in_f32=True, out_f32=True, split=True, f8=True, res="f32", seed=73, atol=3e-4)
+    S.check_conv(eng, DEV, 1, 64, 64, 1280, 320, ntaps=1, tile_cfg=4, in_f32=True, out_f32=True, split=True, f8=True, res="f32", seed=74, atol=3e-4)
+
+
 def test_attention_d64_split_precision(eng, monkeypatch):
     """Split-precision attention cores as the engine runs them (Q.K^T on hi | lo pairs, P.V on fp16; 4- and 8-wave blocks), and the
     fully split form, against un-rounded fp64 attention."""

@@ -109,3 +109,39 @@ def test_precision_floor_of_fp16_operands(pkg):
     w16 = {k: (v.half().float() if (k.endswith(".weight") and v.dim() >= 2) else v) for k, v in w.items()}
     d = (O.sdmatte_forward(w16, cfg.as_dict(), data) - ref).abs()
     assert d.max().item() > 1e-3 and d.mean().item() < 1.5e-3
+
+
+def test_checkpoint_checker_and_lazy_loader(pkg, tmp_path):
+    """tools/check_checkpoint.py compares a .safetensors header with the key schema the engine expects (the schema is inferred from the
+    reference's module names - no real checkpoint was ever available); `LazyCheckpoint` streams tensors one at a time and skips
+    text_encoder.* (dead on this path)."""
+    import subprocess
+    import sys
+    from safetensors.torch import save_file
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    from comfyui_sdmatte_amd.weights import synthetic_state_dict
+    from comfyui_sdmatte_amd.sdmatte_nodes import LazyCheckpoint
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = SDMatteConfig.tiny()
+    w = {k: v.contiguous() for k, v in synthetic_state_dict(cfg, 0).items()}
+    w["text_encoder.embeddings.weight"] = torch.zeros(4, 4)
+    # legacy VAE attention names are accepted (SURVEY.md A.9 (2))
+    legacy = {(k.replace(".to_q.", ".query.").replace(".to_out.0.", ".proj_attn.") if (k.startswith("vae.") and "mid_block.attentions.0" in k) else k): v
+              for k, v in w.items()}
+    good = tmp_path / "good.safetensors"
+    save_file(legacy, str(good))
+    tool = os.path.join(root, "tools", "check_checkpoint.py")
+    r = subprocess.run([sys.executable, tool, str(good), "--config", "tiny"], capture_output=True, text=True)
+    assert r.returncode == 0 and "missing (engine would refuse to load): 0" in r.stdout and "text_encoder" in r.stdout, r.stdout + r.stderr
+    bad = dict(w)
+    del bad["unet.conv_in.weight"]
+    bad["vae.decoder.conv_out.bias"] = torch.zeros(5)
+    badf = tmp_path / "bad.safetensors"
+    save_file(bad, str(badf))
+    r = subprocess.run([sys.executable, tool, str(badf), "--config", "tiny"], capture_output=True, text=True)
+    assert r.returncode == 1 and "unet.conv_in.weight" in r.stdout and "vae.decoder.conv_out.bias" in r.stdout
+    lz = LazyCheckpoint(str(good))
+    keys = [k for k, _ in lz.items()]
+    assert "text_encoder.embeddings.weight" not in keys and len(keys) == len(w) - 1
+    k0, t0 = next(iter(lz.items()))
+    assert torch.equal(t0, legacy[k0])
