@@ -65,9 +65,9 @@ struct ConvParams {
   int f8;                               // 1: w_dma holds the fp8-residual layout (derive_conv_weight_f8_kernel) -> F8 kernel
   int f8_hint;                          // tile selection only: the layer has the fp8-residual weights (cfg 0 then beats the 256x64 tile)
   int f8_sa, f8_sb;                     // E8M0 exponents (byte 0) of the fp8 MFMA operand scales: 2^(sa-127) * 2^(sb-127) maps the residual sums to accumulator units
-  int epi_mode;                         // F8 kernels: 0 = LDS-transposed epilogue; 1 = accumulator-layout epilogue for full fp32 tiles (dword stores straight from
-                                        // the MFMA registers, no LDS, in-lane statistics); 2 = 1 + the residual enters as the accumulators' initial value;
-                                        // 3 = LDS-transposed epilogue + residual as the accumulators' initial value
+  int epi_mode;                         // F8 kernels (accumulators [channel][pixel]): 0 = LDS-staged epilogue; 3 = 0 + the residual enters as the accumulators'
+                                        // initial value; 4 = 3 + full fp32 tiles are stored straight from the registers (16-byte stores, bias from LDS,
+                                        // statistics by DPP row sums) - the default
   int ablate;                           // debug/bench only (sdm_bench_conv): 1 skip global loads, 2 skip LDS writes, 4 skip MFMA,
                                         // 8 skip the epilogue stores -- after the first K-chunk; always 0 in the engine
   int vgrid, tpb;                       // F8 (tpb tiles per block): number of virtual block ids = the grid of the one-tile-per-block forms
@@ -168,7 +168,7 @@ conv_mfma_kernel(ConvParams p) {
   // are in the epilogue of tile k, the producer waves already stage the first chunk and the first weight steps of tile k+1 (the
   // epilogue's LDS staging lives in the second A buffer, which that prologue does not touch); the ~16 us of fixed cost per tile
   // (launch, first loads, epilogue) is what separated the 4-chunk 128-channel layers from the 16-chunk ones.
-  auto run_tile = [&](const int vbid) {
+  auto run_tile = [&](const int vbid, const int tile_par) {
   // PC: `tid` / `wave` are the index inside the role (consumers: MFMA tile position; producers: staging decomposition)
   int tx = (int)threadIdx.x;
   if (F8) SDM_OPAQUE_I(tx);          // per tile: nothing derived from the lane index is shared between the inlined tiles and kept live across an epilogue
@@ -213,45 +213,57 @@ conv_mfma_kernel(ConvParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  // ---- accumulator-layout epilogue (F8 kernels; ConvParams::epi_mode).  After the MFMA chain register r of lane l holds output row
-  //      (r & 3) + 8 * (r >> 2) + 4 * (l >> 5) and column l & 31 of a 32 x 32 sub-tile: a 32-lane half-wave covers 128 contiguous bytes of
-  //      one fp32 output row, so ONE buffer_store_dword per register writes two full 128-byte lines - no LDS transpose, no wait in
-  //      the store stream (the accumulators are free again as soon as the stores have issued, and the next tile's MFMAs run while
-  //      they drain), per-channel statistics are in-lane sums.  With 32-pixel-wide tiles the 32 rows of sub-tile i are the 32
-  //      pixels of ONE image row, so every address is lane part (voffset, constant for the tile) + wave-uniform part (soffset).
-  //      Ragged tiles, fp16 / plane outputs and GEGLU keep the LDS-transposed epilogue below. ----
+  // ---- F8 kernels: the accumulators are [channel][pixel].  The consumers pass the WEIGHT fragment as the MFMA's A operand and the
+  //      activation fragment as B, so register r of lane l holds channel (r & 3) + 8 * (r >> 2) + 4 * (l >> 5) of pixel l & 31 of a
+  //      32 x 32 sub-tile: every register quad is 4 consecutive output channels of one pixel = ONE 16-byte store / load per lane, no
+  //      LDS transpose.  ConvParams::epi_mode 4 (full fp32 tiles): bias from a small LDS table, buffer_store_dwordx4 straight from
+  //      the registers - the accumulators are free as soon as the stores have issued, and the stores drain underneath the next
+  //      tile's MFMAs (tools/probe/store_overlap_probe.hip: 32 such stores per wave cost 5 us alone and nothing beside >= 576 MFMAs;
+  //      the memory pipeline accepts one store instruction per ~65 cycles whatever its width, so the 128 dword stores of the
+  //      natural [pixel][channel] layout were 4x slower than the LDS transpose they replaced, profiles/r03_conv_epilogue_ab.txt) -
+  //      the residual enters as the accumulators' initial value (16-byte loads issued before the tile's first barrier), and the
+  //      GroupNorm statistics of the consumer are in-lane sums reduced over the 32 pixel lanes with DPP adds.  Ragged tiles, fp16 /
+  //      plane outputs and GEGLU go through the (swizzled) LDS staging below.  With 32-pixel-wide tiles the 32 pixels of sub-tile i
+  //      are ONE image row, so every address is lane part (voffset, constant for the tile) + wave-uniform part (soffset). ----
   constexpr bool FASTEPI = (F8 != 0) && (NTAPS == 1 || (TW == 32 && WTM % TW == 0));
   const int wmu = SDM_UNIFORM_I(wm), wnu = SDM_UNIFORM_I(wn);
+  (void)wnu;
   bool fast_epi = false, res_init = false;
   if (FASTEPI) {
     const bool full = (NTAPS == 9) ? (oy0 + TH <= p.Hout && ox0 + TW <= p.Wout) : (m0 + (long)C::BM <= m_end);
     const bool ok = p.out_f32 == 1 && p.epi == 0 && full && (!p.res || p.res_f32);
-    fast_epi = ok && (p.epi_mode == 1 || p.epi_mode == 2);
-    res_init = ok && p.epi_mode >= 2 && p.res != nullptr && p.out_scale == 1.0f;      // mode 3: residual as accumulator init + the LDS-transposed store epilogue
+    fast_epi = ok && p.epi_mode == 4;
+    res_init = ok && p.epi_mode >= 3 && p.res != nullptr && p.out_scale == 1.0f;      // mode 3: residual as accumulator init + the LDS-staged store epilogue
   }
   // first output pixel of this wave's sub-tile i, relative to the tile's first pixel (px_tile0)
   const size_t px_tile0 = (NTAPS == 9) ? ((size_t)img * p.Hout + oy0) * p.Wout : (size_t)m0;
   auto sub_px = [&](int i) { return (NTAPS == 9) ? (unsigned int)((wmu * (WTM / TW) + i) * p.Wout + ox0) : (unsigned int)(wmu * WTM + i * 32); };
+  const int ch_lane = n0 + wn * WTN + 4 * (lane >> 5);        // first output channel of this lane's register quad (j, g) = ch_lane + j * 32 + 8 * g
+  // bias of the tile's BN output channels: written by the producer waves in their prologue (two tables: the consumers may still read
+  // the previous tile's while the next prologue runs), read by the accumulator-layout epilogue
+  float* bias_tab = (float*)(smem + C::TILE_BYTES) + tile_par * BN;
   auto acc_init_residual = [&]() {
   if (FASTEPI && res_init) {
     // the residual is the accumulators' initial value: out = (acc + bias) + res.  F8 layers carry acc_scale == 1 (their fp16 high parts
-    // are packed unscaled, the fp8 operand scales absorb the rest), so the loaded dwords ARE the accumulator registers: any arithmetic
+    // are packed unscaled, the fp8 operand scales absorb the rest), so the loaded quads ARE accumulator registers: any arithmetic
     // on them made hipcc stage all 128 values in a second register set (1.2 KB / lane of scratch).  Called by the CONSUMER branch only,
     // in front of the barrier that ends the producers' prologue: the accumulators must not be live across the producers' code (the
     // register allocation is the union of both roles), and the loads fly while the consumers wait for the first operands.
     const unsigned int rs4 = (unsigned int)p.res_C * 4u;
     const sdm_rsrc rsi = sdm_make_rsrc((const unsigned char*)p.res + px_tile0 * rs4, (unsigned int)(((NTAPS == 9) ? (size_t)TH * p.Wout : (size_t)C::BM) * rs4));
-    const unsigned int vr = (unsigned int)(4 * (lane >> 5)) * rs4 + (unsigned int)(n0 + wn * WTN + (lane & 31)) * 4u;
+    const unsigned int vr = (unsigned int)(lane & 31) * rs4 + (unsigned int)ch_lane * 4u;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const unsigned int so = sub_px(i) * rs4;
 #pragma unroll
-      for (int j = 0; j < NTL; ++j) {
-        const bool ok = (n0 + wn * WTN + j * 32 + (lane & 31)) < p.Cout_valid;
+      for (int j = 0; j < NTL; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          acc[i][j][r] = sdm_buffer_load_f32(rsi, ok ? vr + (unsigned int)(j * 128) : SDM_BUF_INVALID, so + (unsigned int)((r & 3) + 8 * (r >> 2)) * rs4);
-      }
+        for (int g = 0; g < 4; ++g) {
+          const bool ok = (ch_lane + j * 32 + 8 * g) < p.Cout_valid;
+          const f32x4 q = __builtin_bit_cast(f32x4, sdm_buffer_load16(rsi, ok ? vr + (unsigned int)((j * 32 + 8 * g) * 4) : SDM_BUF_INVALID, so));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] = q[e];
+        }
     }
   }
   };
@@ -725,6 +737,11 @@ conv_mfma_kernel(ConvParams p) {
           }
         };
         if (role) {
+          {   // bias of this tile's output channels -> LDS (read by the consumers' accumulator-layout epilogue)
+            const float* bsrc = p.bias;
+            if (bsrc && p.bias_sel) bsrc += (size_t)p.bias_sel[img] * p.Cout_pad;
+            if (tid < BN) bias_tab[tid] = (bsrc && n0 + tid < p.Cout_pad) ? bsrc[n0 + tid] : 0.0f;
+          }
           dma_step1(0, 0);
           if (1 < nch) dma_step1(1, 1);
           SDM_SCHED_FENCE();
@@ -782,7 +799,7 @@ conv_mfma_kernel(ConvParams p) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-              for (int j = 0; j < NTL; ++j) acc[i][j] = SDM_MFMA_32x32x16_F16(ah[0][i], fbh[0][j], acc[i][j]);
+              for (int j = 0; j < NTL; ++j) acc[i][j] = SDM_MFMA_32x32x16_F16(fbh[0][j], ah[0][i], acc[i][j]);
             i32x8 a8[MT];
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
@@ -794,7 +811,7 @@ conv_mfma_kernel(ConvParams p) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-              for (int j = 0; j < NTL; ++j) acc[i][j] = SDM_MFMA_32x32x16_F16(ah[1][i], fbh[1][j], acc[i][j]);
+              for (int j = 0; j < NTL; ++j) acc[i][j] = SDM_MFMA_32x32x16_F16(fbh[1][j], ah[1][i], acc[i][j]);
             SDM_SCHED_FENCE();
             // the residual pair of this chunk; the fp16 fragments of the NEXT chunk's weights (landed one barrier ago) are read underneath
             i32x8 fb8c[NTL];
@@ -805,13 +822,18 @@ conv_mfma_kernel(ConvParams p) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-              for (int j = 0; j < NTL; ++j) acc[i][j] = SDM_MFMA_32x32x64_BF8A_F8B(a8[i], fb8c[j], acc[i][j], sa8, sb8);
+              for (int j = 0; j < NTL; ++j) acc[i][j] = SDM_MFMA_32x32x64_F8A_BF8B(fb8c[j], a8[i], acc[i][j], sb8, sa8);
             SDM_RAW_BARRIER();
             sl = sl == 2 ? 0 : sl + 1;
           }
         }
       } else {
       if (role) {
+        {   // bias of this tile's output channels -> LDS (read by the consumers' accumulator-layout epilogue)
+          const float* bsrc = p.bias;
+          if (bsrc && p.bias_sel) bsrc += (size_t)p.bias_sel[img] * p.Cout_pad;
+          if (tid < BN) bias_tab[tid] = (bsrc && n0 + tid < p.Cout_pad) ? bsrc[n0 + tid] : 0.0f;
+        }
         dma_step(0, 0);
         if (1 < nsteps) dma_step(1, 1);
         SDM_SCHED_FENCE();
@@ -903,7 +925,7 @@ conv_mfma_kernel(ConvParams p) {
                 const int i = r - dy;
                 if (i >= 0 && i < MT) {
 #pragma unroll
-                  for (int j = 0; j < NTL; ++j) acc[i][j] = SDM_MFMA_32x32x16_F16(fa[r & 1], fbh[0][dy][j], acc[i][j]);
+                  for (int j = 0; j < NTL; ++j) acc[i][j] = SDM_MFMA_32x32x16_F16(fbh[0][dy][j], fa[r & 1], acc[i][j]);
                 }
               }
               SDM_SCHED_FENCE();
@@ -920,7 +942,7 @@ conv_mfma_kernel(ConvParams p) {
                 const int i = r - dy;
                 if (i >= 0 && i < MT) {
 #pragma unroll
-                  for (int j = 0; j < NTL; ++j) acc[i][j] = SDM_MFMA_32x32x16_F16(fa[(NR + r) & 1], fbh[1][dy][j], acc[i][j]);
+                  for (int j = 0; j < NTL; ++j) acc[i][j] = SDM_MFMA_32x32x16_F16(fbh[1][dy][j], fa[(NR + r) & 1], acc[i][j]);
                 }
               }
               SDM_SCHED_FENCE();
@@ -939,7 +961,7 @@ conv_mfma_kernel(ConvParams p) {
                 const int i = r - dy;
                 if (i >= 0 && i < MT) {
 #pragma unroll
-                  for (int j = 0; j < NTL; ++j) acc[i][j] = SDM_MFMA_32x32x64_BF8A_F8B(f8a[r & 1], fb8[dy][j], acc[i][j], sa8, sb8);
+                  for (int j = 0; j < NTL; ++j) acc[i][j] = SDM_MFMA_32x32x64_F8A_BF8B(fb8[dy][j], f8a[r & 1], acc[i][j], sb8, sa8);
                 }
               }
               SDM_SCHED_FENCE();
@@ -1165,66 +1187,100 @@ conv_mfma_kernel(ConvParams p) {
   if (!DB) __syncthreads();      // all waves are done with the A/B tiles (DB: the loop ended with a barrier)
   if (PC && role) return;        // the accumulators live in the consumer waves; no block-wide barrier below this line
   if (FASTEPI && fast_epi) {
-    const unsigned int cs4 = (unsigned int)p.Cout_store * 4u, rs4 = (unsigned int)p.res_C * 4u;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const unsigned int cs4 = (unsigned int)p.Cout_store * 4u;
     const size_t span = (NTAPS == 9) ? (size_t)TH * p.Wout : (size_t)C::BM;
     const sdm_rsrc rso = sdm_make_rsrc((unsigned char*)p.out + px_tile0 * cs4, (unsigned int)(span * cs4));
-    const bool res_epi = p.res != nullptr && !res_init;
-    const sdm_rsrc rsr2 = sdm_make_rsrc(res_epi ? (const unsigned char*)p.res + px_tile0 * rs4 : (const unsigned char*)p.out, res_epi ? (unsigned int)(span * rs4) : 0u);
-    const int cl = n0 + wn * WTN + (lane & 31);                      // output channel of j = 0
-    const unsigned int vo = (unsigned int)(4 * (lane >> 5)) * cs4 + (unsigned int)(p.out_ch_off + cl) * 4u;
-    const unsigned int vr = (unsigned int)(4 * (lane >> 5)) * rs4 + (unsigned int)cl * 4u;
-    const float* biasp = p.bias;
-    if (biasp && p.bias_sel) biasp += (size_t)p.bias_sel[img] * p.Cout_pad;
-    float bj[NTL], s1[NTL], s2[NTL];
-    bool okj[NTL];
+    const unsigned int vo = (unsigned int)l31 * cs4 + (unsigned int)(p.out_ch_off + ch_lane) * 4u;
+    f32x4 b4[NTL][4];
+    bool okq[NTL][4];
 #pragma unroll
-    for (int j = 0; j < NTL; ++j) {
-      const int occ = cl + j * 32;
-      okj[j] = occ < p.Cout_valid;
-      bj[j] = (biasp && occ < p.Cout_pad) ? biasp[occ] : 0.0f;
-      s1[j] = 0.0f; s2[j] = 0.0f;
-    }
-    const bool do_store = !(p.ablate & 8);
+    for (int j = 0; j < NTL; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        b4[j][g] = *(const f32x4*)(bias_tab + wn * WTN + j * 32 + 8 * g + 4 * hi);
+        okq[j][g] = (ch_lane + j * 32 + 8 * g) < p.Cout_valid;
+      }
+    float s1[NTL][16], s2[NTL][16];
+#pragma unroll
+    for (int j = 0; j < NTL; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s1[j][r] = 0.0f; s2[j][r] = 0.0f; }
+    const bool do_store = !(p.ablate & 8), do_stats = p.stats != nullptr;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      const unsigned int px = sub_px(i);
-      float rv[NTL][16];
-      if (res_epi) {
+      const unsigned int so = sub_px(i) * cs4;
 #pragma unroll
-        for (int j = 0; j < NTL; ++j)
+      for (int j = 0; j < NTL; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            rv[j][r] = sdm_buffer_load_f32(rsr2, okj[j] ? vr + (unsigned int)(j * 128) : SDM_BUF_INVALID, (px + (unsigned int)((r & 3) + 8 * (r >> 2))) * rs4);
-      }
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v;
 #pragma unroll
-      for (int j = 0; j < NTL; ++j) {
+          for (int e = 0; e < 4; ++e) v[e] = ((SPLIT ? acc[i][j][4 * g + e] * p.acc_scale : acc[i][j][4 * g + e]) + b4[j][g][e]) * p.out_scale;
+          if (okq[j][g]) {
+            if (do_store) sdm_buffer_store16(__builtin_bit_cast(u32x4, v), rso, vo + (unsigned int)((j * 32 + 8 * g) * 4), so);
+            if (do_stats) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = ((SPLIT ? acc[i][j][r] * p.acc_scale : acc[i][j][r]) + bj[j]) * p.out_scale;
-          if (res_epi) v += rv[j][r];
-          if (okj[j]) {
-            if (do_store) sdm_buffer_store_f32(v, rso, vo + (unsigned int)(j * 128), (px + (unsigned int)((r & 3) + 8 * (r >> 2))) * cs4);
-            s1[j] += v; s2[j] += v * v;
+              for (int e = 0; e < 4; ++e) { s1[j][4 * g + e] += v[e]; s2[j][4 * g + e] += v[e] * v[e]; }
+            }
           }
         }
-      }
     }
-    if (p.stats) {      // lanes l and l + 32 own the same channel (rows 4 apart): one partial row per (tile, wave-row), as below
+    if (do_stats) {
+      // per-channel sums over this wave's 128 pixels: in-lane over the 4 sub-tiles (above), then over the 16 lanes of each DPP row;
+      // the two rows of a lane half meet in a wave-private LDS scratch (the second A buffer is free during the epilogue), from which
+      // lane c writes channel c of the partial row - one coalesced store, as the LDS-staged epilogue does
+      float* sc = (float*)(smem + 2 * C::A_BYTES) + wave * 256;            // [2 rows][64 channels][sum, sumsq]
 #pragma unroll
-      for (int j = 0; j < NTL; ++j) { s1[j] += __shfl_xor(s1[j], 32); s2[j] += __shfl_xor(s2[j], 32); }
-      const size_t prow = (size_t)img * (p.tiles_m * WM) + (size_t)mt * WM + wm;
+      for (int j = 0; j < NTL; ++j)
 #pragma unroll
-      for (int j = 0; j < NTL; ++j) {
-        if (lane < 32 && okj[j]) {
-          f32x2 o2;
-          o2[0] = s1[j]; o2[1] = s2[j];
-          *(f32x2*)(p.stats + (prow * p.Cout_store + p.out_ch_off + cl + j * 32) * 2) = o2;
+        for (int r = 0; r < 16; ++r) {
+          const float t1 = sdm_sum_row16(s1[j][r]), t2 = sdm_sum_row16(s2[j][r]);
+          if ((lane & 15) == 0) {
+            f32x2 o2;
+            o2[0] = t1; o2[1] = t2;
+            *(f32x2*)(sc + (((lane >> 4) & 1) * WTN + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 2) = o2;
+          }
         }
+      SDM_WAVE_SYNC();
+      if (lane < WTN && (n0 + wn * WTN + lane) < p.Cout_valid) {
+        const f32x2 a = *(const f32x2*)(sc + lane * 2), b = *(const f32x2*)(sc + (WTN + lane) * 2);
+        f32x2 o2;
+        o2[0] = a[0] + b[0]; o2[1] = a[1] + b[1];
+        const size_t prow = (size_t)img * (p.tiles_m * WM) + (size_t)mt * WM + wm;
+        *(f32x2*)(p.stats + (prow * p.Cout_store + p.out_ch_off + n0 + wn * WTN + lane) * 2) = o2;
       }
+      SDM_WAVE_SYNC();
     }
     return;
   }
   float* stg = (float*)(smem + (F8 ? 2 * C::A_BYTES : 0)) + wave * (32 * WTN);      // F8: second A buffer (the next tile's prologue fills the first)
+  // accumulators of sub-tile i -> the wave's [32 pixels][WTN channels] staging tile.  F8 kernels hold [channel][pixel]: a register quad
+  // is 4 consecutive channels of pixel (lane & 31) - one ds_write_b128 into 16-byte block ((channel / 4) ^ (pixel & 15)) of the
+  // pixel's row (the XOR keeps 8 consecutive lanes = 8 rows on distinct banks without padding the tile; readers apply it again)
+  auto stage_acc = [&](int i) {
+    if (F8) {
+#pragma unroll
+      for (int j = 0; j < NTL; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int blk = (j * 8 + 2 * g + (lane >> 5)) ^ (lane & 15);
+          f32x4 q;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) q[e] = acc[i][j][4 * g + e];
+          *(f32x4*)(stg + (lane & 31) * WTN + blk * 4) = q;
+        }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NTL; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          stg[row * WTN + j * 32 + (lane & 31)] = acc[i][j][r];
+        }
+    }
+  };
+  auto stg_at = [&](int row, int col) { return stg + row * WTN + (F8 ? (((col >> 2) ^ (row & 15)) << 2) : col); };      // col % 4 == 0
   const bool geglu = (p.epi == 1);
   constexpr int LPR = WTN / 4;                    // lanes per output row (linear epilogue: 4 channels per lane)
   const float* bias = p.bias;
@@ -1278,20 +1334,14 @@ conv_mfma_kernel(ConvParams p) {
           }
         }
       }
-#pragma unroll
-      for (int j = 0; j < NTL; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          stg[row * WTN + j * 32 + (lane & 31)] = acc[i][j][r];
-        }
+      stage_acc(i);
       SDM_WAVE_SYNC();
 #pragma unroll
       for (int pass = 0; pass < NPASS; ++pass) {
         const int row = pass * RPP + lane / LPR;
         long lp;
         const bool valid = pix_of(i, row, lp);
-        const f32x4 t = *(const f32x4*)(stg + row * WTN + lc);
+        const f32x4 t = *(const f32x4*)stg_at(row, lc);
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = ((SPLIT ? t[e] * p.acc_scale : t[e]) + bu[e]) * p.out_scale;
@@ -1360,21 +1410,15 @@ conv_mfma_kernel(ConvParams p) {
     if (bias && colbase + ucol + 32 < p.Cout_pad + 4) { bu = *(const f32x4*)(bias + colbase + ucol); bg = *(const f32x4*)(bias + colbase + ucol + 32); }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-#pragma unroll
-      for (int j = 0; j < NTL; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          stg[row * WTN + j * 32 + (lane & 31)] = acc[i][j][r];
-        }
+      stage_acc(i);
       SDM_WAVE_SYNC();
 #pragma unroll
       for (int pass = 0; pass < NPASS; ++pass) {
         const int row = pass * RPP + lane / GL;
         long lp;
         const bool valid = pix_of(i, row, lp);
-        const f32x4 t = *(const f32x4*)(stg + row * WTN + ucol);
-        const f32x4 g4 = *(const f32x4*)(stg + row * WTN + ucol + 32);
+        const f32x4 t = *(const f32x4*)stg_at(row, ucol);
+        const f32x4 g4 = *(const f32x4*)stg_at(row, ucol + 32);
         f32x4 o4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1418,10 +1462,10 @@ conv_mfma_kernel(ConvParams p) {
   if (F8) {
     for (int k = 0; k < p.tpb; ++k) {
       const int v = (int)blockIdx.x + k * (int)gridDim.x;
-      if (v < p.vgrid) run_tile(v);
+      if (v < p.vgrid) run_tile(v, k & 1);
     }
   } else {
-    run_tile((int)blockIdx.x);
+    run_tile((int)blockIdx.x, 0);
   }
 }
 

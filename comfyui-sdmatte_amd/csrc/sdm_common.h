@@ -31,6 +31,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define SDM_MFMA_32x32x64_BF8A_F8B(a, b, c, sa, sb) emu_mfma_scale_f32_32x32x64_bf8_fp8((a), (b), (c), (sa), (sb))
 #define SDM_CVT_PK_BF8(a, b, old, hi_word) emu_cvt_pk_bf8_f32((a), (b), (old), (hi_word))
 #define SDM_MFMA_32x32x64_BF8_BF8(a, b, c, sa, sb) emu_mfma_scale_f32_32x32x64_bf8_bf8((a), (b), (c), (sa), (sb))
+#define SDM_MFMA_32x32x64_F8A_BF8B(a, b, c, sa, sb) emu_mfma_scale_f32_32x32x64_fp8_bf8((a), (b), (c), (sa), (sb))
 #define SDM_LAUNCH(kernel, grid, block, smem, stream, ...) \
   emu::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); })
 #define SDM_DEV_INLINE static inline
@@ -57,6 +58,8 @@ static inline float sdm_rcp(float x) { return 1.0f / x; }
 #define SDM_CVT_PK_BF8(a, b, old, hi_word) __builtin_amdgcn_cvt_pk_bf8_f32((a), (b), (old), (hi_word))
 // both operands in e5m2 (cbsz = 1, blgp = 1): the residual terms of Q.K^T (k_attn.h, PREC = 3)
 #define SDM_MFMA_32x32x64_BF8_BF8(a, b, c, sa, sb) __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4((a), (b), (c), 1, 1, 0, (sa), 0, (sb))
+// A in e4m3 (weights), B in e5m2 (activations): the F8 conv / GEMM kernels, whose accumulators are [channel][pixel] (k_conv.h)
+#define SDM_MFMA_32x32x64_F8A_BF8B(a, b, c, sa, sb) __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4((a), (b), (c), 0, 1, 0, (sa), 0, (sb))
 #define SDM_LAUNCH(kernel, grid, block, smem, stream, ...) \
   hipLaunchKernelGGL(kernel, (grid), (block), (smem), (hipStream_t)(stream), __VA_ARGS__)
 #define SDM_DEV_INLINE __device__ __forceinline__
@@ -101,6 +104,10 @@ static inline void sdm_buffer_store_f32(float v, sdm_rsrc r, unsigned int voff, 
   const unsigned long long o = (unsigned long long)voff + soff;
   if (o + 4 <= r.bytes) memcpy((unsigned char*)r.base + o, &v, 4);
 }
+static inline void sdm_buffer_store16(u32x4 v, sdm_rsrc r, unsigned int voff, unsigned int soff) {
+  const unsigned long long o = (unsigned long long)voff + soff;
+  if (o + 16 <= r.bytes) memcpy((unsigned char*)r.base + o, &v, 16);
+}
 #else
 typedef __amdgpu_buffer_rsrc_t sdm_rsrc;
 __device__ __forceinline__ sdm_rsrc sdm_make_rsrc(const void* p, unsigned int bytes) {
@@ -118,6 +125,9 @@ __device__ __forceinline__ float sdm_buffer_load_f32(sdm_rsrc r, unsigned int vo
 }
 __device__ __forceinline__ void sdm_buffer_store_f32(float v, sdm_rsrc r, unsigned int voff, unsigned int soff) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ void sdm_buffer_store16(u32x4 v, sdm_rsrc r, unsigned int voff, unsigned int soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, 0);
 }
 #endif
 
@@ -187,6 +197,24 @@ __device__ __forceinline__ void sdm_glds16_buf(sdm_rsrc r, unsigned int voff, un
 #define SDM_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define SDM_WAIT_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define SDM_RAW_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+#endif
+
+// sum over the 16 lanes of this lane's DPP row (lanes 16r .. 16r+15), returned in every lane of the row: four VALU adds with DPP
+// operands (quad_perm [1,0,3,2], [2,3,0,1], row_ror:4, row_ror:8) - no LDS crossbar
+#ifdef SDM_EMU
+static inline float sdm_sum_row16(float v) {
+  v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+  return v;
+}
+#else
+#define SDM_DPP_ADD(v, ctrl) ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, false)))
+__device__ __forceinline__ float sdm_sum_row16(float v) {
+  v = SDM_DPP_ADD(v, 0xB1);
+  v = SDM_DPP_ADD(v, 0x4E);
+  v = SDM_DPP_ADD(v, 0x124);
+  v = SDM_DPP_ADD(v, 0x128);
+  return v;
+}
 #endif
 
 #define SDM_LOG2E 1.4426950408889634f

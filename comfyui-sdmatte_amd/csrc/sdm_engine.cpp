@@ -249,7 +249,7 @@ static void launch_conv_dma(const ConvParams& p_in, void* stream) {
     p.tpb = conv_f8_tiles_per_block((long)grid.x);                                                           \
     unsigned pg = (grid.x + p.tpb - 1) / p.tpb;                                                              \
     pg = (pg + 7) & ~7u;              /* block id % 8 = XCD: the stride between a block's tiles stays a multiple of 8 */ \
-    SDM_LAUNCH(k, dim3(pg, 1, 1), dim3(CD::LAUNCH_THREADS), (size_t)CD::SMEM, stream, p);                    \
+    SDM_LAUNCH(k, dim3(pg, 1, 1), dim3(CD::LAUNCH_THREADS), (size_t)CD::SMEM + 2 * 128 * 4, stream, p);     /* + two bias tables */ \
   } while (0)
     if (gn) SDM_F8_CASE(1); else SDM_F8_CASE(0);
 #undef SDM_F8_CASE
@@ -276,7 +276,7 @@ static void launch_gemm_f8(const ConvParams& p_in, void* stream) {
   pg = (pg + 7) & ~7u;
   auto k = conv_mfma_kernel<1, 1, 8, 32, 128, 32, 2, 2, 1, 0, 0, 1, 1, 1, 1>;
   SDM_SET_SMEM(k, 160 * 1024);
-  SDM_LAUNCH(k, dim3(pg, 1, 1), dim3(CD::LAUNCH_THREADS), (size_t)CD::SMEM, stream, p);
+  SDM_LAUNCH(k, dim3(pg, 1, 1), dim3(CD::LAUNCH_THREADS), (size_t)CD::SMEM + 2 * 128 * 4, stream, p);      // + two bias tables
 }
 
 static int launch_conv(int ntaps, int stride, int cfg, const ConvParams& p, void* stream) {
@@ -327,12 +327,12 @@ static bool gemm_f8_enabled() {
   return !(v && v[0] == '0');
 }
 
-// epilogue of the F8 kernels (ConvParams::epi_mode): 2 = accumulator-layout stores + residual as the accumulators' initial value
-// (default), 1 = accumulator-layout stores with the residual added in the epilogue, 0 = LDS-transposed epilogue (round 2).  Read per
-// launch: A/B hook.
+// epilogue of the F8 kernels (ConvParams::epi_mode): 4 = register-direct 16-byte stores + residual as the accumulators' initial value
+// (default), 3 = LDS-staged stores + residual as initial value, 0 = LDS-staged stores, residual added in the epilogue.  Read per launch:
+// A/B hook.
 static int conv_epi_mode() {
   const char* v = getenv("SDM_CONV_EPI");
-  return (v && v[0] >= '0' && v[0] <= '3') ? v[0] - '0' : 3;
+  return (v && (v[0] == '0' || v[0] == '3' || v[0] == '4')) ? v[0] - '0' : 4;
 }
 
 // Residual terms of Q.K^T in the split-precision attention cores on fp8 MFMAs (k_attn.h, PREC = 3; q / k arrive as fp16 + e5m2 pair planes):

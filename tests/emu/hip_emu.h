@@ -237,6 +237,26 @@ static inline emu_f16v emu_mfma_scale_f32_32x32x64_bf8_bf8(emu_i8v a, emu_i8v b,
   return c;
 }
 
+// A in e4m3, B in e5m2 (cbsz = 0, blgp = 1)
+static inline emu_f16v emu_mfma_scale_f32_32x32x64_fp8_bf8(emu_i8v a, emu_i8v b, emu_f16v c, int sa, int sb) {
+  auto& w = emu::wave(); int l = emu::lane_id();
+  memcpy(&w.slot[l][0], &a, 32); memcpy(&w.slot[l][8], &b, 32); emu::wave_barrier();
+  const float scale = ldexpf(1.0f, (sa & 255) - 127 + (sb & 255) - 127);
+  int col = l & 31, hi = l >> 5;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    double acc = 0.0;
+    for (int kh = 0; kh < 2; ++kh) {
+      const unsigned char* av = (const unsigned char*)&w.slot[row + 32 * kh][0];
+      const unsigned char* bv = (const unsigned char*)&w.slot[col + 32 * kh][8];
+      for (int j = 0; j < 32; ++j) acc += (double)emu_e4m3_to_f32(av[j]) * (double)emu_e5m2_to_f32(bv[j]);
+    }
+    c[r] = c[r] + (float)acc * scale;
+  }
+  emu::wave_barrier();
+  return c;
+}
+
 // ---- host runtime stand-ins used by the engine ----
 typedef void* hipStream_t;
 typedef int hipError_t;

@@ -353,3 +353,20 @@ def test_emu_rectangular_inference_matches_oracle(pkg):
     with pytest.raises(RuntimeError):
         eng.forward(data["image"][..., :96], data["trimap"][..., :96])          # 96 is not a multiple of 64
     eng.close()
+
+
+def test_bench_two_ranks_control_flow(pkg):
+    """`bench.py --gpus 2` has never met a second GPU in the build container: its launcher re-exec, rank / world bookkeeping, weight
+    broadcast, per-step gather, max-over-ranks timing and rank-0 JSON line are exercised here on the kernel emulator over gloo
+    (`--emu`: tiny architecture, 64x64, one step - a control-flow test, not a measurement)."""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--emu", "--gpus", "2", "--size", "64", "--batch", "1", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]              # ONE JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["steps"] == 1
+    assert d["config"]["global_batch"] == 2 and d["config"]["parallelism"] == "dp2"
+    assert d["cpu_baseline"] is None

@@ -218,9 +218,10 @@ def test_f8_residual_operand_ranges(eng, xs, ws):
     assert e < 1.5e-4 and g < 1.5e-4
 
 
-@pytest.mark.parametrize("mode", ["0", "3"])
+@pytest.mark.parametrize("mode", ["0", "3", "4"])
 def test_f8_epilogue_modes(eng, monkeypatch, mode):
-    """SDM_CONV_EPI: residual as the accumulators' initial value (3) against the epilogue add (0), full and ragged tiles."""
+    """SDM_CONV_EPI: register-direct 16-byte stores + residual as the accumulators' initial value (4, default), residual init alone (3),
+    LDS-staged epilogue (0); full and ragged tiles."""
     monkeypatch.setenv("SDM_CONV_EPI", mode)
     S.check_conv(eng, DEV, 2, 64, 128, 128, 160, tile_cfg=0, in_f32=True, out_f32=True, split=True, f8=True, gn=(1e-6, True), res="f32", seed=71, atol=3e-4)
     S.check_conv(eng, DEV, 1, 44, 72, 64, 128, tile_cfg=0, in_f32=True, out_f32=True, split=True, f8=True, res="f32", seed=73, atol=3e-4)

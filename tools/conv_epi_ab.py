@@ -1,7 +1,7 @@
 """A/B of the F8 conv / GEMM kernel's epilogue on the layer shapes that dominate the step, in the engine's real I/O format
 (fp32 activations in, fp32 out, optional fp32 residual, GroupNorm statistics of the consumer; random operands).
-SDM_CONV_EPI: 0 = LDS-transposed epilogue (round 2), 1 = accumulator-layout dword stores, 2 = 1 + residual as accumulator init,
-3 = LDS-transposed epilogue + residual as accumulator init.
+SDM_CONV_EPI: 0 = LDS-staged epilogue, 3 = 0 + residual as accumulator init, 4 = 3 + register-direct 16-byte stores (default).
+(profiles/r03_conv_epilogue_ab.txt holds the round-3 measurement of the abandoned dword-store variants 1 / 2.)
 Bench helper, not part of the product path.  usage: python tools/conv_epi_ab.py [quick]
 flag bits: 1 fp32 in, 2 split, 4 fused GroupNorm+SiLU, 16 fp8 residual terms, 32 fp32 out, 64 fp32 residual, 128 statistics"""
 import os
@@ -13,7 +13,7 @@ from comfyui_sdmatte_amd.engine import Engine
 from comfyui_sdmatte_amd.config import SDMatteConfig
 eng = Engine(SDMatteConfig.tiny(), 0, precision="fp16")
 quick = len(sys.argv) > 1 and sys.argv[1].startswith("quick")
-MODES = ("0", "3") if (len(sys.argv) > 1 and sys.argv[1] == "quick03") else ("0", "1", "2", "3")
+MODES = ("0", "3", "4")
 shapes = [(8, 1024, 1024, 128, 128, 9), (4, 1024, 1024, 128, 128, 9), (8, 512, 512, 256, 256, 9), (8, 256, 256, 512, 512, 9), (4, 1024, 1024, 256, 128, 9),
           (4, 128, 128, 320, 320, 9), (4, 64, 64, 640, 640, 9), (4, 32, 32, 1280, 1280, 9),
           (4, 128, 128, 1280, 320, 1), (4, 64, 64, 2560, 640, 1), (4, 32, 32, 5120, 1280, 1)]
@@ -34,8 +34,8 @@ for (N, H, W, ci, co, nt) in shapes:
         s = " | ".join(f"epi{m} {res[m]:7.3f} ms {fl / res[m] / 1e9:6.1f} TF/s" for m in MODES)
         print(f"N={N} {H}x{W} {ci}->{co} taps={nt} {name:19s} {s} | x{res['0'] / res[MODES[-1]]:5.3f} | no-store {tn:7.3f} ms", flush=True)
 if not quick:
-    print("== tiles per block (SDM_CONV_F8_TPB) with SDM_CONV_EPI=2, conv2 form")
-    os.environ["SDM_CONV_EPI"] = "2"
+    print("== tiles per block (SDM_CONV_F8_TPB) with SDM_CONV_EPI=4, conv2 form")
+    os.environ["SDM_CONV_EPI"] = "4"
     for (N, H, W, ci, co, nt) in shapes[:5]:
         fl = 2.0 * N * H * W * ci * co * nt
         out = []
