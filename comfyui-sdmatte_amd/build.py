@@ -31,14 +31,16 @@ def _stamp():
     return h.hexdigest()
 
 
-def build_all(verbose=False, force=False, extra_flags=()):
-    stamp_file = LIB + ".stamp"
-    stamp = _stamp()
-    if not force and os.path.exists(LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+def build_all(verbose=False, force=False, extra_flags=(), out=None):
+    """out: another output path (bench-only variants such as the -DSDM_CONV_TRACE build of tools/conv_trace.py); default: the product library."""
+    lib = out or LIB
+    stamp_file = lib + ".stamp"
+    stamp = _stamp() + " ".join(extra_flags)
+    if not force and os.path.exists(lib) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
         if verbose:
-            print(f"[sdmatte] {LIB} is up to date")
-        return LIB
-    cmd = [_hipcc()] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+            print(f"[sdmatte] {lib} is up to date")
+        return lib
+    cmd = [_hipcc()] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", lib]
     if verbose:
         print("[sdmatte] " + " ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -49,7 +51,7 @@ def build_all(verbose=False, force=False, extra_flags=()):
         print(r.stderr[-4000:])
     with open(stamp_file, "w") as f:
         f.write(stamp)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

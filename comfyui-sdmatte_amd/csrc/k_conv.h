@@ -24,6 +24,7 @@
 //                 channel-offset stores (writes straight into the 8-ch U-Net input tensor).
 #pragma once
 #include "sdm_common.h"
+#include <type_traits>
 
 #ifndef SDM_CONV_VREUSE
 #define SDM_CONV_VREUSE 1   /* vertical A-fragment reuse across taps (A/B switch for experiments) */
@@ -65,6 +66,9 @@ struct ConvParams {
   int f8;                               // 1: w_dma holds the fp8-residual layout (derive_conv_weight_f8_kernel) -> F8 kernel
   int f8_hint;                          // tile selection only: the layer has the fp8-residual weights (cfg 0 then beats the 256x64 tile)
   int f8_sa, f8_sb;                     // E8M0 exponents (byte 0) of the fp8 MFMA operand scales: 2^(sa-127) * 2^(sb-127) maps the residual sums to accumulator units
+  unsigned long long* trace;            // bench only (sdm_bench_conv, ablate bit 256): per-event shader-clock stamps of the first 8 blocks' consumer wave 0 and
+                                        // producer wave 0 of the F8 3x3 kernel, [block][role][tile < 8][event < 16]; null in the engine
+  int xtile;                            // F8 3x3 kernels: 1 = the producers run the next tile's prologue during the current tile's last chunk (cross-tile prefetch)
   int epi_mode;                         // F8 kernels (accumulators [channel][pixel]): 0 = LDS-staged epilogue; 3 = 0 + the residual enters as the accumulators'
                                         // initial value; 4 = 3 + full fp32 tiles are stored straight from the registers (16-byte stores, bias from LDS,
                                         // statistics by DPP row sums) - the default
@@ -168,13 +172,38 @@ conv_mfma_kernel(ConvParams p) {
   // are in the epilogue of tile k, the producer waves already stage the first chunk and the first weight steps of tile k+1 (the
   // epilogue's LDS staging lives in the second A buffer, which that prologue does not touch); the ~16 us of fixed cost per tile
   // (launch, first loads, epilogue) is what separated the 4-chunk 128-channel layers from the 16-chunk ones.
-  auto run_tile = [&](const int vbid, const int tile_par) {
+  // F8 3x3, producer waves: cross-tile prefetch.  During a tile's LAST chunk the producers are idle (nothing left to stage), so they run
+  // the NEXT tile's prologue there - its first weight steps into the ring slots that have just been consumed, its chunk 0 into the A
+  // buffer that chunk nch-2 released, its chunk 1 loads into the registers below - and the next tile starts with its operands in
+  // LDS: the consumers leave their epilogue straight into MFMAs, whose first steps cover the drain of the epilogue's stores (the
+  // memory pipeline serves the CU's stores and loads in order; with the prologue's loads queued BEHIND the stores every tile paid
+  // the store drain plus a full load latency).  pre_done: the tile about to start was prepared that way.
+  int pre_done = 0;
+  u32x4 a_nx[A_PER][IN_F32 ? 2 : 1];
+  f32x4 gqn[4];
+  // role_c: std::integral_constant<int, R>.  R = 0 / 1: this copy of the tile body is executed by consumer / producer waves only (the F8
+  // tile loop below branches on the role ONCE and instantiates the body per role, so that neither role's registers - the consumers'
+  // accumulators and epilogue, the producers' staging sets and the chunk they carry across tiles - are live inside the other's code:
+  // one body for both roles spilled 360-420 B / lane once a_nx had to survive the tile boundary); R = -1: role computed here.
+  auto run_tile = [&](auto role_c, const int vbid, const int tile_par, const bool more_tiles) {
+  constexpr int ROLE_C = decltype(role_c)::value;
   // PC: `tid` / `wave` are the index inside the role (consumers: MFMA tile position; producers: staging decomposition)
   int tx = (int)threadIdx.x;
   if (F8) SDM_OPAQUE_I(tx);          // per tile: nothing derived from the lane index is shared between the inlined tiles and kept live across an epilogue
-  const int role = PC ? SDM_UNIFORM_I(tx / NT) : 0;                  // 0: consumer (or everything), 1: producer
+  const int role = (ROLE_C >= 0) ? ROLE_C : (PC ? SDM_UNIFORM_I(tx / NT) : 0);                  // 0: consumer (or everything), 1: producer
   const int tid = PC ? (tx & (NT - 1)) : tx, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
+  // bench-only event stamps (ConvParams::trace)
+  int trace_ev = 0;
+  auto stamp = [&]() {
+#if defined(SDM_CONV_TRACE) && !defined(SDM_EMU)      // compiled in by tools/conv_trace.py only (the stamps cost registers: 212 B / lane of scratch)
+    if (F8 && NTAPS == 9 && p.trace && blockIdx.x < 8 && tid == 0 && trace_ev < 16) {
+      const int tile_k = (vbid - (int)blockIdx.x) / (int)gridDim.x;
+      if (tile_k < 8) p.trace[(((size_t)blockIdx.x * 2 + role) * 8 + tile_k) * 16 + trace_ev] = __builtin_amdgcn_s_memtime();
+    }
+    ++trace_ev;
+#endif
+  };
   // XCD-aware 1-D grid.  The dispatcher places block id on XCD id % 8 (speed only, never needed for correctness).  XCD x owns
   // the contiguous M-tile range [x*chunk, (x+1)*chunk) and walks it in order, running the tiles_n output-channel tiles of
   // one M tile back to back: the A operand (halo tile / GEMM rows) is fetched from HBM once and re-read from that XCD's L2
@@ -635,15 +664,16 @@ conv_mfma_kernel(ConvParams p) {
       auto mod3 = [](int x) { return x >= 6 ? x - 6 : (x >= 3 ? x - 3 : x); };
       const sdm_rsrc rs8 = sdm_make_rsrc(p.w_dma, (unsigned int)((size_t)Cin * NTAPS * p.Cout_pad * 4));
       // 24 pieces of 1 KB per step: piece q = (unit, plane, dy, 64-channel half); this wave issues pieces 6*wave .. 6*wave+5
-      auto dma_step = [&](int t, int sl) {
+      auto dma_step_v = [&](int t, int sl, unsigned int voff) {
         unsigned char* dst = Bring + sl * STEP;
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
           const int q = wv * 6 + k, ul = q / 12, qq = q % 12, pl = qq / 6, dy = (qq >> 1) % 3, ch = qq & 1;
           const unsigned int row = (unsigned int)(((t * 2 + ul) * 2 + pl) * 3 + dy);
-          sdm_glds16_buf(rs8, dma_voff + (unsigned int)(ch * 1024), row * stage_rows, dst + ul * SLOT + pl * PLANE + dy * (BN * 16) + ch * 1024);
+          sdm_glds16_buf(rs8, voff + (unsigned int)(ch * 1024), row * stage_rows, dst + ul * SLOT + pl * PLANE + dy * (BN * 16) + ch * 1024);
         }
       };
+      auto dma_step = [&](int t, int sl) { dma_step_v(t, sl, dma_voff); };
       f32x4 gq[4];                  // producers, GN: scale[0:4], scale[4:8], shift[0:4], shift[4:8] of this thread's channels in the next chunk
       auto issue_gn = [&](int c0w) {
         if (GN) {
@@ -654,13 +684,13 @@ conv_mfma_kernel(ConvParams p) {
       };
       // fp32 (after the fused GroupNorm / SiLU) -> fp16 high parts (4 planes of 16-B rows: channel group g of the chunk) and the
       // fp8 images of x_lo and x (region behind: sub-planes [x_lo8 ch 0-15 | x_lo8 ch 16-31 | x8 ch 0-15 | x8 ch 16-31] of 16-B rows)
-      auto write_lds_a_f8 = [&](unsigned char* Ad, int i0, int i1) {        // vectors i0 .. i1-1 of this thread
+      auto write_lds_a_f8 = [&](unsigned char* Ad, int i0, int i1, bool nxt = false, const int* npix = nullptr) {        // vectors i0 .. i1-1 of this thread
         const int g = a_part >> 3;
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
           if (i >= i0 && i < i1 && tid + i * NT < A_VEC) {
             const f32x4 v0 = __builtin_bit_cast(f32x4, a_raw[i][0]), v1 = __builtin_bit_cast(f32x4, a_raw[i][IN_F32 ? 1 : 0]);
-            const bool inside = a_pix[i] >= 0;
+            const bool inside = (nxt ? npix[i] : a_pix[i]) >= 0;
             f16x8 vh;
             float xl[8], xx[8];
 #pragma unroll
@@ -696,22 +726,59 @@ conv_mfma_kernel(ConvParams p) {
       static_assert(!F8 || NTAPS == 1 || AFLY == 12 || AFLY == 16, "counted wait below");
       // activations (and GroupNorm coefficients) of the chunk AFTER the next one: loaded a whole chunk before they are transformed, so
       // that the transform of the next chunk can be spread evenly over the six steps of the current one (one vector per step)
-      u32x4 a_nx[A_PER][IN_F32 ? 2 : 1];
-      f32x4 gqn[4];
-      auto issue_loads_nx = [&](int c0) {
+      // (a_nx / gqn live at kernel scope: they carry the next tile's chunk 1 across the tile boundary)
+      // ---- the NEXT tile of this block, as far as the producers need it (3x3 only; even chunk counts keep the A buffer parity) ----
+      bool has_next = false;
+      int n_img = 0, n_n0 = 0;
+      int n_pix[A_PER];
+      sdm_rsrc n_rs0 = rs0, n_rs1 = rs1;
+#pragma unroll
+      for (int i = 0; i < A_PER; ++i) n_pix[i] = -1;
+      if (NTAPS == 9 && role && more_tiles && p.xtile && (nch & 1) == 0) {
+        const int bid = vbid + (int)gridDim.x;
+        const int j = bid >> 3;
+        const int ml = j / p.tiles_n;
+        const int mlin = (bid & 7) * p.xcd_chunk + ml;
+        if (mlin < p.tiles_m * p.N) {
+          has_next = true;
+          n_img = mlin / p.tiles_m;
+          const int nmt = mlin - n_img * p.tiles_m;
+          n_n0 = (j - ml * p.tiles_n) * BN;
+          const int npx = (p.Wout + TW - 1) / TW;
+          const int noy0 = (nmt / npx) * TH, nox0 = (nmt % npx) * TW;
+          const int nband0 = ((noy0 * STRIDE - p.pad_t) > 0 ? ((noy0 * STRIDE - p.pad_t) >> p.up) : 0);
+          const int nband_rows = ((p.Hin - nband0) < (C::HPH + 1) ? (p.Hin - nband0) : (C::HPH + 1));
+#pragma unroll
+          for (int i = 0; i < A_PER; ++i) {
+            const int hp = a_hp0 + i * (NT / KV);
+            if (tid + i * NT < A_VEC) {
+              const int hy = hp / HPW, hx = hp % HPW;
+              const int iy = noy0 * STRIDE + hy - p.pad_t, ix = nox0 * STRIDE + hx - p.pad_l;
+              if (iy >= 0 && iy < Hl && ix >= 0 && ix < Wl) n_pix[i] = ((iy >> p.up) - nband0) * p.Win + (ix >> p.up);
+            }
+          }
+          const size_t base_px = ((size_t)n_img * p.Hin + nband0) * p.Win, npxs = (size_t)nband_rows * p.Win;
+          n_rs0 = sdm_make_rsrc((const unsigned char*)p.in0 + base_px * p.C0 * es, (unsigned int)(npxs * p.C0 * es));
+          n_rs1 = sdm_make_rsrc(p.in1 ? (const unsigned char*)p.in1 + base_px * p.C1 * es : (const unsigned char*)p.in0, p.in1 ? (unsigned int)(npxs * p.C1 * es) : 0u);
+        }
+      }
+      const unsigned int n_dma_voff = (unsigned int)((n_n0 + lane) * 16);
+      // nxt: addresses of the next tile (cross-tile prefetch)
+      auto issue_loads_nx = [&](int c0, bool nxt = false) {
         const bool second = c0 >= p.C0;
-        const sdm_rsrc rs = second ? rs1 : rs0;
+        const sdm_rsrc rs = nxt ? (second ? n_rs1 : n_rs0) : (second ? rs1 : rs0);
         const unsigned int Cs = (unsigned int)(second ? p.C1 : p.C0) * es;
         const unsigned int cc = (unsigned int)((second ? c0 - p.C0 : c0) + a_part) * es;
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
-          const unsigned int off = a_pix[i] >= 0 ? (unsigned int)a_pix[i] * Cs + cc : SDM_BUF_INVALID;
+          const int px = nxt ? n_pix[i] : a_pix[i];
+          const unsigned int off = px >= 0 ? (unsigned int)px * Cs + cc : SDM_BUF_INVALID;
           a_nx[i][0] = sdm_buffer_load16(rs, off, 0);
           if (IN_F32) a_nx[i][IN_F32 ? 1 : 0] = sdm_buffer_load16(rs, off, 16);
         }
         if (GN) {
-          const float* ts = p.gn_scale + (size_t)img * Cin + c0 + a_part;
-          const float* th = p.gn_shift + (size_t)img * Cin + c0 + a_part;
+          const float* ts = p.gn_scale + (size_t)(nxt ? n_img : img) * Cin + c0 + a_part;
+          const float* th = p.gn_shift + (size_t)(nxt ? n_img : img) * Cin + c0 + a_part;
           gqn[0] = *(const f32x4*)ts; gqn[1] = *(const f32x4*)(ts + 4); gqn[2] = *(const f32x4*)th; gqn[3] = *(const f32x4*)(th + 4);
         }
       };
@@ -828,12 +895,14 @@ conv_mfma_kernel(ConvParams p) {
           }
         }
       } else {
-      if (role) {
-        {   // bias of this tile's output channels -> LDS (read by the consumers' accumulator-layout epilogue)
-          const float* bsrc = p.bias;
-          if (bsrc && p.bias_sel) bsrc += (size_t)p.bias_sel[img] * p.Cout_pad;
-          if (tid < BN) bias_tab[tid] = (bsrc && n0 + tid < p.Cout_pad) ? bsrc[n0 + tid] : 0.0f;
-        }
+      auto write_bias_tab = [&](float* tab, int im, int nn0) {   // bias of a tile's output channels -> LDS (read by the consumers' accumulator-layout epilogue)
+        const float* bsrc = p.bias;
+        if (bsrc && p.bias_sel) bsrc += (size_t)p.bias_sel[im] * p.Cout_pad;
+        if (tid < BN) tab[tid] = (bsrc && nn0 + tid < p.Cout_pad) ? bsrc[nn0 + tid] : 0.0f;
+      };
+      stamp();                          // ev 0: tile start (both roles)
+      if (role && !pre_done) {          // (a tile prepared by its predecessor skips all of this)
+        write_bias_tab(bias_tab, img, n0);
         dma_step(0, 0);
         if (1 < nsteps) dma_step(1, 1);
         SDM_SCHED_FENCE();
@@ -848,35 +917,45 @@ conv_mfma_kernel(ConvParams p) {
       }
       const int cm = 0;             // (6 * c) % 3 = 0 always: the chunk's first step sits in ring slot 0 (kept for clarity)
       if (role) {
+        stamp();                        // ev 1: prologue done, waiting at the first barrier
         SDM_WAIT_LGKMCNT0();
         SDM_RAW_BARRIER();
+        stamp();                        // ev 2: past the first barrier
         for (int c = 0; c < nch; ++c) {
           const bool more = c + 1 < nch;
+          const bool morex = more || has_next;             // the chunk staged during this one: c + 1, or chunk 0 of the next tile
+          if (!more && has_next) write_bias_tab((float*)(smem + C::TILE_BYTES) + (tile_par ^ 1) * BN, n_img, n_n0);
 #pragma unroll
           for (int k = 0; k < 6; ++k) {                  // step t = 6c + k: (dx = k / 2, S1 | S2)
             const int t = c * 6 + k;
             // chunk c+1's raw values arrived during chunk c-1 (every earlier step ended with vmcnt(0) or left only them in flight)
-            if (k == 0 && more) take_nx();
+            if (k == 0 && morex) take_nx();
             SDM_SCHED_FENCE();
             if (t + 2 < nsteps) dma_step(t + 2, mod3(cm + k + 2));
+            else if (has_next) dma_step_v(t + 2 - nsteps, mod3(cm + k + 2), n_dma_voff);      // the next tile's first two weight steps (nsteps % 3 == 0: same slots)
             SDM_SCHED_FENCE();
-            const bool fly = (k == 0) && (c + 2 < nch);
-            if (fly) {                                   // chunk c+2: loaded now, transformed during chunk c+1
-              issue_loads_nx((c + 2) * 32);
-              SDM_SCHED_FENCE();
-            }
+            // chunk c+2 - of this tile, or chunk 0 / 1 of the next one: loaded now, transformed one chunk later
+            const bool fly_cur = (k == 0) && (c + 2 < nch), fly_nxt = (k == 0) && !fly_cur && has_next;
+            const bool fly = fly_cur || fly_nxt;
+            if (fly_cur) issue_loads_nx((c + 2) * 32);
+            if (fly_nxt) issue_loads_nx((c + 2 - nch) * 32, true);
+            SDM_SCHED_FENCE();
             // the other A buffer was last read in chunk c-1: one vector of the next chunk's transform (GroupNorm, SiLU, hi / fp8
             // split) per step, so that no step's barrier waits for the producers
-            if (more) write_lds_a_f8(Aring + ((c + 1) & 1) * 2 * C::A_BYTES, k, k + 1);
+            if (morex) write_lds_a_f8(Aring + ((c + 1) & 1) * 2 * C::A_BYTES, k, k + 1, !more, n_pix);
             if (fly) { if (AFLY == 12) SDM_WAIT_VMCNT(12); else SDM_WAIT_VMCNT(16); }
             else SDM_WAIT_VMCNT0();
             SDM_WAIT_LGKMCNT0();
             SDM_RAW_BARRIER();
           }
+          if (c < 4 || c == nch - 1) stamp();            // ev 3..: end of chunks 0-3 and of the last chunk
         }
+        pre_done = has_next ? 1 : 0;
       } else {
         acc_init_residual();
+        stamp();                        // ev 1: accumulators initialised, waiting at the first barrier
         SDM_RAW_BARRIER();              // the producers' prologue (same barrier as in their branch)
+        stamp();                        // ev 2: past the first barrier
         const int sa8 = p.f8_sa, sb8 = p.f8_sb;
         f16x8 fbh[2][3][NTL];         // w_hi fragments of the two 16-channel halves
         i32x8 fb8[3][NTL];            // [w8 | w_lo8] fragments
@@ -968,6 +1047,7 @@ conv_mfma_kernel(ConvParams p) {
             }
             SDM_RAW_BARRIER();
           }
+          if (c < 4 || c == nch - 1) stamp();            // ev 3..: end of chunks 0-3 and of the last chunk
         }
       }
       }   // NTAPS == 9
@@ -1185,6 +1265,7 @@ conv_mfma_kernel(ConvParams p) {
 
   // ---- epilogue: per-wave PRIVATE fp32 staging tile (32 x WTN) in LDS -> coalesced row stores ----
   if (!DB) __syncthreads();      // all waves are done with the A/B tiles (DB: the loop ended with a barrier)
+  stamp();                       // tile-end barrier passed
   if (PC && role) return;        // the accumulators live in the consumer waves; no block-wide barrier below this line
   if (FASTEPI && fast_epi) {
     const int l31 = lane & 31, hi = lane >> 5;
@@ -1252,6 +1333,7 @@ conv_mfma_kernel(ConvParams p) {
       }
       SDM_WAVE_SYNC();
     }
+    stamp();                     // epilogue issued
     return;
   }
   float* stg = (float*)(smem + (F8 ? 2 * C::A_BYTES : 0)) + wave * (32 * WTN);      // F8: second A buffer (the next tile's prologue fills the first)
@@ -1460,12 +1542,19 @@ conv_mfma_kernel(ConvParams p) {
   }
   };   // run_tile
   if (F8) {
-    for (int k = 0; k < p.tpb; ++k) {
-      const int v = (int)blockIdx.x + k * (int)gridDim.x;
-      if (v < p.vgrid) run_tile(v, k & 1);
+    if (SDM_UNIFORM_I((int)threadIdx.x / NT)) {
+      for (int k = 0; k < p.tpb; ++k) {
+        const int v = (int)blockIdx.x + k * (int)gridDim.x;
+        if (v < p.vgrid) run_tile(std::integral_constant<int, 1>{}, v, k & 1, (k + 1 < p.tpb) && (v + (int)gridDim.x < p.vgrid));
+      }
+    } else {
+      for (int k = 0; k < p.tpb; ++k) {
+        const int v = (int)blockIdx.x + k * (int)gridDim.x;
+        if (v < p.vgrid) run_tile(std::integral_constant<int, 0>{}, v, k & 1, (k + 1 < p.tpb) && (v + (int)gridDim.x < p.vgrid));
+      }
     }
   } else {
-    run_tile((int)blockIdx.x, 0);
+    run_tile(std::integral_constant<int, -1>{}, (int)blockIdx.x, 0, false);
   }
 }
 

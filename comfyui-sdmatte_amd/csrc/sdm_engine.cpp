@@ -342,6 +342,12 @@ static bool attn_f8_enabled() {
   return !(v && v[0] == '0');
 }
 
+// F8 3x3 kernels: cross-tile prefetch by the producer waves (k_conv.h); SDM_CONV_XTILE=0 disables.  Read per launch: A/B hook.
+static bool conv_xtile_enabled() {
+  const char* v = getenv("SDM_CONV_XTILE");
+  return !(v && v[0] == '0');
+}
+
 static int gemm_f8_min_k() {
   const char* v = getenv("SDM_GEMM_F8_MIN_K");
   return v ? atoi(v) : 1024;
@@ -858,6 +864,7 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
   if (a.res) { p.res = a.res->p; p.res_f32 = a.res->f32; p.res_C = a.res->C; }
   p.epi = L.geglu; p.out_scale = a.out_scale;
   p.epi_mode = conv_epi_mode();
+  p.xtile = conv_xtile_enabled() ? 1 : 0;
   p.gn_scale = a.gn_scale; p.gn_shift = a.gn_shift; p.gn_silu = a.gn_silu;
   if ((long)a.in0->rows() >= (1L << 31) || p.M >= (1L << 31)) SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: tensor too large for 32-bit pixel indices", L.name.c_str());
   {   // 3x3: per-tile descriptors span only the rows of the tile's halo (k_conv.h band0), so an image may exceed 4 GB; what
@@ -2338,8 +2345,8 @@ float sdm_bench_conv(sdm_ctx* e, int N, int H, int W, int Cin, int Cout, int nta
   memset(&p, 0, sizeof(p));
   p.in0 = in; p.C0 = L.Cin_pad; p.in_f32 = in_f32; p.N = N; p.Hin = H; p.Win = W; p.Hout = Ho; p.Wout = Wo; p.pad_t = p.pad_l = 1;
   p.M = (long)N * Ho * Wo; p.w = L.w; p.bias = L.b; p.Cout_pad = L.Cout_pad; p.out = out; p.Cout_store = L.Cout_pad; p.Cout_valid = L.Cout_pad;
-  p.out_scale = 1.f; p.ablate = ablate; p.acc_scale = split ? ldexpf(1.0f, -kSplitWeightExp) : 1.f;
-  p.out_f32 = of32; p.epi_mode = conv_epi_mode();
+  p.out_scale = 1.f; p.ablate = ablate & 255; p.acc_scale = split ? ldexpf(1.0f, -kSplitWeightExp) : 1.f;
+  p.out_f32 = of32; p.epi_mode = conv_epi_mode(); p.xtile = conv_xtile_enabled() ? 1 : 0;
   if (resf) { p.res = resb; p.res_f32 = 1; p.res_C = L.Cout_pad; }
   if (statf) p.stats = (float*)statb;
   void* wdm = nullptr;
@@ -2363,6 +2370,29 @@ float sdm_bench_conv(sdm_ctx* e, int N, int H, int W, int Cin, int Cout, int nta
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   launch_conv(ntaps, stride, cfg, p, e->stream);
+  if (ablate & 256) {      // one traced launch of the F8 3x3 kernel: shader-clock stamps of the first blocks (ConvParams::trace) -> stderr
+    void* tr = nullptr;
+    const size_t tb = (size_t)8 * 2 * 8 * 16 * 8;
+    if (dev_malloc(&tr, tb) == 0) {
+      dev_memset(tr, 0, tb, e->stream);
+      ConvParams pt = p; pt.trace = (unsigned long long*)tr; pt.ablate = ablate & 255;
+      launch_conv(ntaps, stride, cfg, pt, e->stream);
+      std::vector<unsigned long long> h(tb / 8);
+      (void)dev_memcpy_d2h(h.data(), tr, tb, e->stream);
+      (void)dev_sync(e->stream);
+      for (int b = 0; b < 8; b += 4)
+        for (int k = 0; k < 8; ++k)
+          for (int r = 0; r < 2; ++r) {
+            const unsigned long long* ev = &h[(((size_t)b * 2 + r) * 8 + k) * 16];
+            if (!ev[0]) continue;
+            fprintf(stderr, "[trace] block %d tile %d %s:", b, k, r ? "producer" : "consumer");
+            for (int i = 0; i < 16 && ev[i]; ++i) fprintf(stderr, " %llu", (unsigned long long)(ev[i] - h[(((size_t)b * 2 + 0) * 8 + 0) * 16]));
+            fprintf(stderr, "\n");
+          }
+      dev_free(tr);
+    }
+    p.ablate = ablate & 255;
+  }
   (void)hipEventRecord(e0, (hipStream_t)e->stream);
   for (int i = 0; i < iters; ++i) launch_conv(ntaps, stride, cfg, p, e->stream);
   (void)hipEventRecord(e1, (hipStream_t)e->stream);
