@@ -94,17 +94,7 @@ static inline u32x2 sdm_buffer_load8(sdm_rsrc r, unsigned int voff, unsigned int
   if (o + 8 <= r.bytes) memcpy(&v, r.base + o, 8);
   return v;
 }
-static inline float sdm_buffer_load_f32(sdm_rsrc r, unsigned int voff, unsigned int soff) {
-  float v = 0.0f;
-  const unsigned long long o = (unsigned long long)voff + soff;
-  if (o + 4 <= r.bytes) memcpy(&v, r.base + o, 4);
-  return v;
-}
-static inline void sdm_buffer_store_f32(float v, sdm_rsrc r, unsigned int voff, unsigned int soff) {      // out-of-range stores are dropped, as in hardware
-  const unsigned long long o = (unsigned long long)voff + soff;
-  if (o + 4 <= r.bytes) memcpy((unsigned char*)r.base + o, &v, 4);
-}
-static inline void sdm_buffer_store16(u32x4 v, sdm_rsrc r, unsigned int voff, unsigned int soff) {
+static inline void sdm_buffer_store16(u32x4 v, sdm_rsrc r, unsigned int voff, unsigned int soff) {      // out-of-range stores are dropped, as in hardware
   const unsigned long long o = (unsigned long long)voff + soff;
   if (o + 16 <= r.bytes) memcpy((unsigned char*)r.base + o, &v, 16);
 }
@@ -119,13 +109,7 @@ __device__ __forceinline__ u32x4 sdm_buffer_load16(sdm_rsrc r, unsigned int voff
 __device__ __forceinline__ u32x2 sdm_buffer_load8(sdm_rsrc r, unsigned int voff, unsigned int soff) {
   return __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
 }
-// one dword per lane: the accumulator-layout epilogue (a 32-lane half-wave covers 128 contiguous bytes of one output row)
-__device__ __forceinline__ float sdm_buffer_load_f32(sdm_rsrc r, unsigned int voff, unsigned int soff) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
-}
-__device__ __forceinline__ void sdm_buffer_store_f32(float v, sdm_rsrc r, unsigned int voff, unsigned int soff) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, (int)voff, (int)soff, 0);
-}
+// 16 bytes per lane (the register-direct epilogue of the F8 kernels: 4 consecutive channels of one pixel)
 __device__ __forceinline__ void sdm_buffer_store16(u32x4 v, sdm_rsrc r, unsigned int voff, unsigned int soff) {
   __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, 0);
 }

@@ -144,10 +144,14 @@ def attention_core(q: Tensor, k: Tensor, v: Tensor, heads: int, bias: Optional[T
     kh = k.view(B, Lk, heads, d).permute(0, 2, 1, 3).reshape(B * heads, Lk, d)
     vh = v.view(B, Lk, heads, d).permute(0, 2, 1, 3).reshape(B * heads, Lk, d)
     out = torch.empty_like(qh)
+    # ... and, beyond 1024x1024 inputs, one block of query rows at a time (the softmax is per row: the same numbers), so that the score
+    # matrix of a 65536-token level (2048x2048 input: 17 GB per image and head) never exists in full
+    rows = max(1, min(Lq, (1 << 28) // max(Lk, 1)))
     for i in range(B * heads):
         b = None if bias is None else bias[i:i + 1]
-        p = attention_scores(qh[i:i + 1], kh[i:i + 1], b, scale)
-        out[i:i + 1] = torch.bmm(p, vh[i:i + 1])
+        for r0 in range(0, Lq, rows):
+            p = attention_scores(qh[i:i + 1, r0:r0 + rows], kh[i:i + 1], b, scale)
+            out[i:i + 1, r0:r0 + rows] = torch.bmm(p, vh[i:i + 1])
     return out.view(B, heads, Lq, d).permute(0, 2, 1, 3).reshape(B, Lq, C)
 
 

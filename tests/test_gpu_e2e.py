@@ -427,6 +427,19 @@ def test_e2e_full_model_2048_images_beyond_4gb(pkg):
     assert d.max().item() <= 1.5e-2 and d.mean().item() <= 1.5e-3          # fp16 operand floor (3.6e-3 max at 1024^2), not the parity bar
 
 
+@pytest.mark.slow
+def test_e2e_beyond_1024_vs_oracle(pkg):
+    """SURVEY.md 8(f)4, oracle-grade: an input beyond the node's 1024x1024 (1536x1536: 36864 tokens at the first U-Net level, 147456 pixels
+    per VAE attention) against the fp32 oracle, whose attention walks the query rows in blocks at this size (same numbers, bounded
+    memory).  Tiny architecture (the oracle needs minutes per image on the full one): what is exercised is the engine's size handling -
+    tile counts, key-tile lists, arena, the 8-wave attention blocks - at the north star's tolerance; the > 4 GB operand images of the
+    full architecture are covered by test_conv3x3_operand_image_beyond_4gb_matches_row_band_crops and the 2048x2048 run above."""
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    m, w, img, tri, data, ref, out, d = _run(pkg, SDMatteConfig.tiny(), 1536, 1, seed=31)
+    assert d.max().item() <= TOL
+    m.engine.close()
+
+
 def test_e2e_config5_mixed_resolution_stream_matted_rgba(pkg):
     """BASELINE config #5 on one GPU: a request stream cycling inference sizes 512 / 768 / 1024 through parallel.matte_stream
     (bucketing by size, equal-shape micro-batches) and the node's matted_rgba composition, vs the oracle (tiny architecture so
