@@ -50,12 +50,12 @@ __global__ void __launch_bounds__(256, 1) probe(float* out, int tiles, int nm, i
   if (MODE == 0) { float s = 0; for (int i = 0; i < 8; ++i) s += acc[i][0]; if (s == 123.456f) out[tid] = s; }
 }
 
-template <int MODE> static float run(float* d, int tiles, int nm, int cstride) {
+template <int MODE> static float run(float* d, int tiles, int nm, int cstride, int grid = 256) {
   hipFuncSetAttribute((const void*)probe<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  probe<MODE><<<256, 256, 120 * 1024>>>(d, tiles, nm, cstride);
+  probe<MODE><<<grid, 256, 120 * 1024>>>(d, tiles, nm, cstride);
   hipEventRecord(e0);
-  probe<MODE><<<256, 256, 120 * 1024>>>(d, tiles, nm, cstride);
+  probe<MODE><<<grid, 256, 120 * 1024>>>(d, tiles, nm, cstride);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   return ms;
@@ -68,6 +68,12 @@ int main() {
     const float t0 = run<0>(d, tiles, nm, cstride), t1 = run<1>(d, tiles, nm, cstride), t2 = run<2>(d, tiles, nm, cstride);
     printf("per tile: %4d MFMAs/wave: mfma only %7.2f us | 32 dwordx4 stores/wave only %6.2f us | both %7.2f us  (sum %7.2f, max %7.2f)\n", nm * 8,
            t0 * 1e3 / tiles, t1 * 1e3 / tiles, t2 * 1e3 / tiles, (t0 + t1) * 1e3 / tiles, (t0 > t1 ? t0 : t1) * 1e3 / tiles);
+  }
+  // the same stores from fewer CUs: is the ~5 us per 128 KB tile the CU's store path or the chip's HBM write bandwidth?
+  for (int grid : {256, 128, 64, 32, 8}) {
+    const float t1 = run<1>(d, tiles, 36, cstride, grid), t2 = run<2>(d, tiles, 36, cstride, grid), t0 = run<0>(d, tiles, 36, cstride, grid);
+    printf("grid %3d blocks: 32 dwordx4 stores/wave only %6.2f us per tile (%6.1f GB/s per CU, %5.2f TB/s chip) | 288 MFMAs only %6.2f | both %6.2f\n", grid,
+           t1 * 1e3 / tiles, 131072.0 / (t1 * 1e3 / tiles) * 1e-3, grid * 131072.0 / (t1 * 1e3 / tiles) * 1e-6, t0 * 1e3 / tiles, t2 * 1e3 / tiles);
   }
   return 0;
 }
