@@ -1304,6 +1304,9 @@ conv_mfma_kernel(ConvParams p) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) { s1[j][4 * g + e] += v[e]; s2[j][4 * g + e] += v[e] * v[e]; }
             }
+            // the store's data registers stay untouched until here: on gfx950 a v_pk_* that rewrites them two instructions behind a
+            // buffer_store_dwordx4 changes what lanes 12-15 of each 16 store (profiles/r03_conv_epilogue_branchfree_ab.txt)
+            SDM_PIN_STORE_DATA(v);
           }
         }
     }
