@@ -149,8 +149,10 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_kernel(AttnParams p) {
   }
   f32x16 o[QT][2], ls[QT];        // ls: running softmax denominators, accumulated on the matrix pipe (ones . P^T)
   float m_i[QT];
-  float lsum = 0.0f;              // PREC: the denominator is summed on the VALU instead (the matrix pipe is the bottleneck there,
-                                  // and the fp32 sum of the un-split probabilities is exact to fp32)
+  float lsum = 0.0f;              // PVS (P.V on split operands: three MFMAs per product, the matrix pipe is the bottleneck): the denominator is
+                                  // summed on the VALU instead.  Every other variant is bound by the VALU stream of the softmax (hipcc also
+                                  // SLP-packs these adds into v_pk_add_f32 + two v_mov each): the denominator rides the matrix pipe as the
+                                  // sum of the SAME fp16 probabilities that enter P.V
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     m_i[qt] = SDM_NEG_BIG;
@@ -291,7 +293,7 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_kernel(AttnParams p) {
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[qt][kt][r] = sdm_exp2(s[qt][kt][r] - mnew);
-      if (PREC) {
+      if (PVS) {
         float ts0 = 0.0f, ts1 = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { ts0 += s[qt][0][r]; ts1 += s[qt][1][r]; }
@@ -328,7 +330,7 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_kernel(AttnParams p) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) pfl[j] = (half_t)(s[0][kt][8 * u + j] - (float)pf[0][j]);
         }
-        if (!PREC) {
+        if (!PVS) {
 #pragma unroll
           for (int qt = 0; qt < QT; ++qt) ls[qt] = SDM_MFMA_32x32x16_F16(ones, pf[qt], ls[qt]);      // every row = sum_k P[k][q]
         }
@@ -365,7 +367,7 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_kernel(AttnParams p) {
     unsigned char* stf = smem + wave * (32 * PS);
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-      const float inv = 1.0f / (PREC ? (lsum + __shfl_xor(lsum, 32)) : ls[qt][0]);      // lanes l and l^32 hold the two key halves of query l&31
+      const float inv = 1.0f / (PVS ? (lsum + __shfl_xor(lsum, 32)) : ls[qt][0]);      // PVS: lanes l and l^32 hold the two key halves of query l&31
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -389,7 +391,7 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_kernel(AttnParams p) {
   }
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
-    const float l = PREC ? (lsum + __shfl_xor(lsum, 32)) : ls[qt][0];      // all 32 rows of the ones.P^T tile hold the same sum over every key (both lane halves included)
+    const float l = PVS ? (lsum + __shfl_xor(lsum, 32)) : ls[qt][0];      // all 32 rows of the ones.P^T tile hold the same sum over every key (both lane halves included)
     const float inv = 1.0f / l;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
