@@ -11,8 +11,11 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libsdmatte_hip.so")
 SOURCES = ["sdm_engine.cpp"]
 HEADERS = ["sdm_common.h", "k_conv.h", "k_norm.h", "k_attn.h", "k_misc.h", os.path.join("..", "..", "include", "sdmatte.h")]
-FLAGS = ["-x", "hip", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
+# -fno-slp-vectorize: hipcc's SLP pass turns adjacent scalar fp32 adds / multiplies into v_pk_* plus the v_mov that assemble the pairs -
+# more issue slots than the scalar form, beside MFMAs (measured: -0.5 % step time without it, profiles/r03_no_slp_ab.txt)
+FLAGS = ["-x", "hip", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc", "-fno-slp-vectorize",
          "-Wno-unused-result", "-Wno-unused-value", "-DNDEBUG", "-munsafe-fp-atomics"]
+CODEGEN_FLAGS = [f for f in FLAGS if f not in ("-shared", "-fPIC")]      # for the ISA / resource-usage tools (tools/kernel_resources.py, check_store_hazard.py)
 
 
 def _hipcc():

@@ -16,6 +16,10 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "comfyui-sdmatte_amd", "csrc", "sdm_engine.cpp")
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package
+load_package()
+from comfyui_sdmatte_amd.build import CODEGEN_FLAGS      # the product's own code-generation flags
 WINDOW = 16
 
 
@@ -31,8 +35,7 @@ def main():
     min_distance = int(sys.argv[1]) if len(sys.argv) > 1 else 6
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "engine.s")
-        subprocess.run(["/opt/rocm/bin/hipcc", "-x", "hip", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-gpu-rdc", "-DNDEBUG", "-munsafe-fp-atomics",
-                        "--cuda-device-only", "-S", SRC, "-o", out], check=True, capture_output=True)
+        subprocess.run(["/opt/rocm/bin/hipcc"] + CODEGEN_FLAGS + ["--cuda-device-only", "-S", SRC, "-o", out], check=True, capture_output=True)
         lines = open(out).read().split("\n")
     kern, per_kernel = None, {}
     for i, line in enumerate(lines):

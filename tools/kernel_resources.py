@@ -3,11 +3,14 @@ spills and silent occupancy drops after kernel edits.  Usage: python tools/kerne
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "comfyui-sdmatte_amd", "csrc", "sdm_engine.cpp")
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package
+load_package()
+from comfyui_sdmatte_amd.build import CODEGEN_FLAGS      # the product's own code-generation flags
 def main():
     filt = sys.argv[1:] or ["conv_mfma", "attn", "gemm"]
     with tempfile.TemporaryDirectory() as d:
-        r = subprocess.run(["/opt/rocm/bin/hipcc", "-x", "hip", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-DNDEBUG",
-                            "-munsafe-fp-atomics", "-Rpass-analysis=kernel-resource-usage", "-c", SRC, "-o", os.path.join(d, "e.o")],
+        r = subprocess.run(["/opt/rocm/bin/hipcc"] + CODEGEN_FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-c", SRC, "-o", os.path.join(d, "e.o")],
                            capture_output=True, text=True)
     blocks = re.split(r"remark: [^\n]*Function Name: ", r.stderr)[1:]
     names = [b.split("\n")[0].strip() for b in blocks]
