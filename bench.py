@@ -307,8 +307,8 @@ def main():
                        "arithmetic": (("split MFMA operands x = hi + lo, fp32 accumulate, fp32 activations: x_hi*w_hi on fp16; the residual "
                                        "terms x_lo*w + x*w_lo on fp8 (one K=64 MFMA; e5m2 activations x e4m3 weights with a per-layer scale) in the "
                                        "3x3 convs with >= 128 output channels, the GEMMs with K >= 1024 and (e5m2 x e5m2) Q.K^T of the d=64 "
-                                       "attention cores, on fp16 (2 more MFMAs) in every other conv / GEMM; P.V on plain fp16 operands with an "
-                                       "fp32 VALU denominator; the d=512 VAE attention core on plain fp16"
+                                       "attention cores, on fp16 (2 more MFMAs) in every other conv / GEMM; P.V and the softmax denominator on the "
+                                       "same plain fp16 probabilities (fp32 accumulate); the d=512 VAE attention core on plain fp16"
                                        if os.environ.get("SDM_CONV_F8", "1") != "0" else
                                        "split-fp16 MFMA operands (hi+lo, 3 MFMAs per product), fp32 accumulate, fp32 activations")
                                       if precision == "fp16x3" else "fp16 MFMA operands, fp32 accumulate, fp32 residual stream"),
