@@ -172,14 +172,22 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_kernel(AttnParams p) {
   const float* bbase = p.bias ? p.bias + (size_t)b * p.bias_bs : nullptr;
   const int ntiles = (p.Lk + 63) / 64;
 
-  f16x8 kreg[VPT], vreg[VPT], kregl[PREC ? VPT : 1], vregl[PVS ? VPT : 1];
-  float breg = 0.0f;
-  bool binr = true;
+  // one raw K / V^T / bias tile on its way from global memory to LDS.  AHEAD2 (F8Q): two of them alternate, so that the loads of tile
+  // t+2 are requested at the top of iteration t and written to LDS in iteration t+1 - a load that misses the L2 has a whole iteration
+  // to land instead of the Q.K^T + softmax part of one
+  struct Raw {
+    f16x8 k[VPT], v[VPT], kl[PREC ? VPT : 1], vl[PVS ? VPT : 1];
+    float b;
+    bool in;
+  };
+  constexpr bool AHEAD2 = F8Q && QT == 1 && NW == 8;      // (4-wave blocks stage two vectors per thread: a second set would spill)
+  Raw ra, rb;
+  ra.b = 0.0f; ra.in = true; rb.b = 0.0f; rb.in = true;
   // without a bias the load still happens (from the K tensor: >= Lk readable floats) and its value is discarded by a select
   const float* bsrc = bbase ? bbase : (const float*)(p.k + (size_t)b * p.k_bs);
   // all prefetch loads are UNCONDITIONAL (clamped rows): a conditional load makes hipcc wait vmcnt(0) per element.
   // Keys >= Lk are neutralised by the -1e30 bias (K rows) and by the zero padding of V^T.
-  auto prefetch = [&](int t) {
+  auto prefetch = [&](int t, Raw& r) {
     const int k0 = t * 64;
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
@@ -187,55 +195,59 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_kernel(AttnParams p) {
       const int row = v >> 3, part = v & 7;
       int kr = k0 + row;
       if (kr > p.Lk - 1) kr = p.Lk - 1;
-      kreg[i] = *(const f16x8*)(kbase + (size_t)kr * p.ldk + part * 8);
-      vreg[i] = *(const f16x8*)(vbase + (size_t)row * p.ldvt + k0 + part * 8);
-      if (PREC) kregl[PREC ? i : 0] = *(const f16x8*)(kbase + p.k_lo + (size_t)kr * p.ldk + part * 8);
-      if (PVS) vregl[PVS ? i : 0] = *(const f16x8*)(vbase + p.vt_lo + (size_t)row * p.ldvt + k0 + part * 8);
+      r.k[i] = *(const f16x8*)(kbase + (size_t)kr * p.ldk + part * 8);
+      r.v[i] = *(const f16x8*)(vbase + (size_t)row * p.ldvt + k0 + part * 8);
+      if (PREC) r.kl[PREC ? i : 0] = *(const f16x8*)(kbase + p.k_lo + (size_t)kr * p.ldk + part * 8);
+      if (PVS) r.vl[PVS ? i : 0] = *(const f16x8*)(vbase + p.vt_lo + (size_t)row * p.ldvt + k0 + part * 8);
     }
     // bias: UNCONDITIONAL raw load, consumed only in stage() after the MFMAs.  (`bbase ? bbase[kb] : 0` followed by a select
     // made hipcc branch around the load and wait vmcnt(0) right here - which also drains the four K / V^T prefetch loads
     // issued just above, i.e. every tile paid the full global-load latency.)
     int kb = k0 + (tid & 63);
-    binr = kb < p.Lk;
-    if (!binr) kb = p.Lk - 1;
-    breg = bsrc[kb];
+    r.in = kb < p.Lk;
+    if (!r.in) kb = p.Lk - 1;
+    r.b = bsrc[kb];
   };
-  auto stage = [&](int buf) {
+  auto stage = [&](int buf, const Raw& r) {
     unsigned char* base = smem + buf * BUF;
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
       const int v = tid + i * NTH;
       const int row = v >> 3, part = v & 7;
-      *(f16x8*)(base + row * PK + part * 16) = kreg[i];
+      *(f16x8*)(base + row * PK + part * 16) = r.k[i];
       // V^T rows are only 8-byte aligned (pitch 136): two ds_write_b64
       f16x4 lo, hi4;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { lo[e] = vreg[i][e]; hi4[e] = vreg[i][4 + e]; }
+      for (int e = 0; e < 4; ++e) { lo[e] = r.v[i][e]; hi4[e] = r.v[i][4 + e]; }
       *(f16x4*)(base + VOFF + row * PV + part * 16) = lo;
       *(f16x4*)(base + VOFF + row * PV + part * 16 + 8) = hi4;
-      if (PREC) *(f16x8*)(base + KLO + row * PK + part * 16) = kregl[PREC ? i : 0];
+      if (PREC) *(f16x8*)(base + KLO + row * PK + part * 16) = r.kl[PREC ? i : 0];
       if (PVS) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { lo[e] = vregl[PVS ? i : 0][e]; hi4[e] = vregl[PVS ? i : 0][4 + e]; }
+        for (int e = 0; e < 4; ++e) { lo[e] = r.vl[PVS ? i : 0][e]; hi4[e] = r.vl[PVS ? i : 0][4 + e]; }
         *(f16x4*)(base + VOFF + VLO + row * PV + part * 16) = lo;
         *(f16x4*)(base + VOFF + VLO + row * PV + part * 16 + 8) = hi4;
       }
     }
-    if (tid < 64) ((float*)(base + BOFF))[tid] = binr ? (bbase ? breg : 0.0f) : SDM_NEG_BIG;
+    if (tid < 64) ((float*)(base + BOFF))[tid] = r.in ? (bbase ? r.b : 0.0f) : SDM_NEG_BIG;
   };
   // tile walk: all ntiles tiles, or the active-tile list of this image (wave-uniform scalar loads)
   const int* tl = p.tiles ? p.tiles + (size_t)b * p.tiles_bs : nullptr;
   const int nwalk = tl ? tl[0] : ntiles;
   auto tile_at = [&](int i) { return tl ? tl[1 + i] : i; };
-  prefetch(tile_at(0));
-  stage(0);
+  prefetch(tile_at(0), ra);
+  stage(0, ra);
   __syncthreads();
+  if (AHEAD2 && 1 < nwalk && !(p.ablate & 8)) prefetch(tile_at(1), ra);
 
-  for (int t = 0; t < nwalk; ++t) {
+  // one key tile.  cur: the raw tile t+1 (AHEAD2: requested one iteration ago; otherwise requested here), written to the other LDS buffer
+  // below; nxt (AHEAD2): receives tile t+2
+  auto iter = [&](const int t, Raw& cur, Raw& nxt) {
     const unsigned char* Ks = smem + (t & 1) * BUF;
     const unsigned char* Vs = Ks + VOFF;
     const float* Bs = (const float*)(Ks + BOFF);
-    if (t + 1 < nwalk && !(p.ablate & 8)) prefetch(tile_at(t + 1));
+    if (AHEAD2) { if (t + 2 < nwalk && !(p.ablate & 8)) prefetch(tile_at(t + 2), nxt); }
+    else if (t + 1 < nwalk && !(p.ablate & 8)) prefetch(tile_at(t + 1), cur);
 
     // S^T[key][q] for 2 key tiles of 32 (x QT query tiles).  The accumulators START from the per-key additive bias (read
     // straight from LDS in accumulator layout: rows 8g+4hi..+3 = registers 4g..4g+3), so the MFMA chain delivers the final
@@ -359,7 +371,7 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_kernel(AttnParams p) {
     // next tile into the OTHER LDS buffer (nobody reads it during this iteration) - before the P.V MFMAs when early_stage is set, so
     // that the LDS writes complete under them instead of in front of the barrier
     const bool early_stage = (p.ablate & 32) == 0;
-    if (early_stage && t + 1 < nwalk) stage((t + 1) & 1);
+    if (early_stage && t + 1 < nwalk) stage((t + 1) & 1, cur);
     // O^T[d][q] += V^T[d][key] . P^T[key][q]
     if (!(p.ablate & 2)) {
 #pragma unroll
@@ -405,8 +417,16 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_kernel(AttnParams p) {
         }
       }
     }
-    if (!early_stage && t + 1 < nwalk) stage((t + 1) & 1);
+    if (!early_stage && t + 1 < nwalk) stage((t + 1) & 1, cur);
     __syncthreads();
+  };
+  if (AHEAD2) {
+    for (int t = 0; t < nwalk; t += 2) {
+      iter(t, ra, rb);
+      if (t + 1 < nwalk) iter(t + 1, rb, ra);
+    }
+  } else {
+    for (int t = 0; t < nwalk; ++t) iter(t, ra, ra);
   }
 
   // epilogue: per-wave staging [32 q][64 d] fp16 -> coalesced 16-B row stores (all waves passed the last barrier)

@@ -192,6 +192,19 @@ def test_attention_d64_split_precision(emu_engine, monkeypatch):
     a16 = emu_engine.op_attention_split(q, k, v, 2)
     d = (a8 - a16).abs().max().item()
     assert 0.0 < d < 4e-4, d            # logit spread ~3x that of unit-variance q / k; fp16 operands alone are off by ~1e-2 here
+    monkeypatch.delenv("SDM_ATTN_F8")
+    # the 8-wave form of the same kernel (level-0 attentions; global loads two key tiles ahead through two raw-tile register sets): same
+    # arithmetic per query row as the 4-wave form -> bit-identical, for 1, 2, 3 and 5 key tiles and the trimap-style tile list
+    for lk in (40, 128, 130, 300):
+        kk, vv = torch.randn(1, lk, 128, generator=g) * 1.5, torch.randn(1, lk, 128, generator=g)
+        bias = torch.where(torch.rand(1, lk, generator=g) < 0.3, torch.tensor(-10000.0), torch.tensor(0.0))
+        for bb in (None, bias):
+            monkeypatch.setenv("SDM_ATTN_NW", "4")
+            r4 = emu_engine.op_attention_split(q, kk, vv, 2, bias=bb)
+            monkeypatch.setenv("SDM_ATTN_NW", "8")
+            r8 = emu_engine.op_attention_split(q, kk, vv, 2, bias=bb)
+            assert torch.equal(r4, r8), (lk, bb is not None, (r4 - r8).abs().max().item())
+    monkeypatch.delenv("SDM_ATTN_NW")
 
 
 def test_attention_d64_skips_underflowing_key_tiles(emu_engine, monkeypatch):
