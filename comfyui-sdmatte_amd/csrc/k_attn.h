@@ -484,6 +484,211 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_kernel(AttnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// EXPERIMENTAL (SDM_ATTN_PIPE=1; off by default: built and checked bit-identical to attn_d64_kernel<1,3,8> on the emulator at the end
+// of round 3, not yet measured on hardware).  The 8-wave fp8-residual kernel above as a TWO-TILE software pipeline: the Q.K^T MFMAs
+// of key tile t+1 and the softmax of key tile t are independent and sit in ONE basic block, so the scheduler can issue the VALU stream
+// (max / sub / exp / pack: ~1000 cycles per tile) underneath the matrix stream instead of after it; both waves of a SIMD are in the
+// same phase of attn_d64_kernel (one barrier per tile), and SQ counters put 42 % of a wave's cycles into issue stalls there.
+// Three LDS buffers (108 KB, one 8-wave block per CU): iteration t reads V^T of tile t and K / bias of tile t+1 and writes tile t+2;
+// the barrier is the raw s_barrier behind an LDS-only wait, so the global loads of tile t+3 stay in flight across it.
+// Same arithmetic, same order per query row as attn_d64_kernel<1,3,8>: results are bit-identical (tests/test_emu_ops.py).
+// ------------------------------------------------------------------------------------------------
+#define ATTN64PIPE_SMEM (3 * ATTN64P_BUF)
+__global__ void __launch_bounds__(512, 2) attn_d64_pipe_kernel(AttnParams p) {
+  constexpr int NW = 8, NTH = 64 * NW;
+  SDM_DYN_SMEM(smem);
+  constexpr int PK = ATTN64_PK, PV = ATTN64_PV, BUF = ATTN64P_BUF;
+  constexpr int KLO = 64 * PK, VOFF = 2 * 64 * PK, BOFF = VOFF + 64 * PV;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, l31 = lane & 31;
+  int b, head, qblk;
+  if (!attn_block_coords(p, blockIdx.x, b, head, qblk)) return;
+  const int q0 = qblk * (32 * NW) + wave * 32;
+
+  f16x8 qf[4];
+  i32x8 q8p[2];
+  {
+    int qrow = q0 + l31;
+    if (qrow > p.Lq - 1) qrow = p.Lq - 1;
+    const half_t* qp = p.q + (size_t)b * p.q_bs + (size_t)qrow * p.ldq + head * 64 + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const f16x8*)(qp + ks * 16);
+    const half_t* qb = p.q + (size_t)b * p.q_bs + p.q_lo + (size_t)qrow * p.ldq + head * 64 + hi * 16;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const i32x4 r0 = *(const i32x4*)(qb + m * 32), r1 = *(const i32x4*)(qb + m * 32 + 8);
+      q8p[m] = i32x8{r0[1], r0[0], r0[3], r0[2], r1[1], r1[0], r1[3], r1[2]};
+    }
+  }
+  f32x16 o[2], ls;
+  float m_i = SDM_NEG_BIG;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { ls[r] = 0.0f; o[0][r] = 0.0f; o[1][r] = 0.0f; }
+  f16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (half_t)1.0f;
+
+  const half_t* kbase = p.k + (size_t)b * p.k_bs + head * 64;
+  const half_t* vbase = p.vt + (size_t)b * p.vt_bs + (size_t)head * p.vt_hs;
+  const float* bbase = p.bias ? p.bias + (size_t)b * p.bias_bs : nullptr;
+  const float* bsrc = bbase ? bbase : (const float*)(p.k + (size_t)b * p.k_bs);
+  const int ntiles = (p.Lk + 63) / 64;
+  const int* tl = p.tiles ? p.tiles + (size_t)b * p.tiles_bs : nullptr;
+  const int nwalk = tl ? tl[0] : ntiles;
+  auto tile_at = [&](int i) { return tl ? tl[1 + i] : i; };
+
+  // one raw tile between global memory and LDS (one 16-byte vector of K_hi, K pair plane and V^T per thread, one bias value per lane)
+  f16x8 rk, rkl, rv;
+  float rb = 0.0f;
+  bool rin = true;
+  const int srow = tid >> 3, spart = tid & 7;
+  auto prefetch = [&](int t) {
+    const int k0 = t * 64;
+    int kr = k0 + srow;
+    if (kr > p.Lk - 1) kr = p.Lk - 1;
+    rk = *(const f16x8*)(kbase + (size_t)kr * p.ldk + spart * 8);
+    rv = *(const f16x8*)(vbase + (size_t)srow * p.ldvt + k0 + spart * 8);
+    rkl = *(const f16x8*)(kbase + p.k_lo + (size_t)kr * p.ldk + spart * 8);
+    int kb = k0 + (tid & 63);
+    rin = kb < p.Lk;
+    if (!rin) kb = p.Lk - 1;
+    rb = bsrc[kb];
+  };
+  auto stage = [&](int buf) {
+    unsigned char* base = smem + buf * BUF;
+    *(f16x8*)(base + srow * PK + spart * 16) = rk;
+    f16x4 lo, hi4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { lo[e] = rv[e]; hi4[e] = rv[4 + e]; }
+    *(f16x4*)(base + VOFF + srow * PV + spart * 16) = lo;
+    *(f16x4*)(base + VOFF + srow * PV + spart * 16 + 8) = hi4;
+    *(f16x8*)(base + KLO + srow * PK + spart * 16) = rkl;
+    if (tid < 64) ((float*)(base + BOFF))[tid] = rin ? (bbase ? rb : 0.0f) : SDM_NEG_BIG;
+  };
+  // logits of one key tile: S^T[key][q], accumulators started from the per-key bias
+  auto qk = [&](int buf, f32x16 (&s)[2]) {
+    const unsigned char* Ks = smem + buf * BUF;
+    const float* Bs = (const float*)(Ks + BOFF);
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 b4 = *(const f32x4*)(Bs + kt * 32 + 8 * g + 4 * hi);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[kt][4 * g + e] = b4[e];
+      }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const f16x8 a = *(const f16x8*)(Ks + (kt * 32 + l31) * PK + ks * 32 + hi * 16);
+        s[kt] = SDM_MFMA_32x32x16_F16(a, qf[ks], s[kt]);
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const unsigned char* kp = Ks + KLO + (kt * 32 + l31) * PK + m * 64 + hi * 32;
+        const i32x4 a0 = *(const i32x4*)kp, a1 = *(const i32x4*)(kp + 16);
+        const i32x8 a8 = i32x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        s[kt] = SDM_MFMA_32x32x64_BF8_BF8(a8, q8p[m], s[kt], 127 - 11, 127);
+      }
+    }
+  };
+  auto lds_barrier = [&]() { SDM_WAIT_LGKMCNT0(); SDM_RAW_BARRIER(); };
+
+  // ---- prologue: tiles 0 and 1 in LDS, tile 2 on its way, logits of tile 0 in registers ----
+  prefetch(tile_at(0));
+  stage(0);
+  if (1 < nwalk) prefetch(tile_at(1));
+  lds_barrier();
+  if (1 < nwalk) stage(1);
+  if (2 < nwalk) prefetch(tile_at(2));
+  f32x16 sa[2], sb[2];
+  qk(0, sa);
+  lds_barrier();
+
+  int bt = 0;                         // buffer of tile t (t % 3 without a division)
+  // sc: logits of tile t (consumed here), sn: receives the logits of tile t+1; the two register sets swap roles every tile
+  auto iter = [&](const int t, f32x16 (&sc)[2], f32x16 (&sn)[2]) {
+    const int b1 = bt == 2 ? 0 : bt + 1, b2 = b1 == 2 ? 0 : b1 + 1;      // buffers of tiles t+1, t+2
+    // (1) logits of tile t+1 (when there is none: the same instructions on a buffer nobody consumes - no branch inside this block)
+    //     and the softmax of tile t: independent streams in one basic block
+    qk(b1, sn);
+    float mx = SDM_NEG_BIG;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, sc[kt][r]), sc[kt][r + 1]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mnew = fmaxf(m_i, mx);
+    const float alpha = sdm_exp2(m_i - mnew);
+    m_i = mnew;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[kt][r] = sdm_exp2(sc[kt][r] - mnew);
+    if (__any(alpha != 1.0f)) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ls[r] *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    }
+    // (2) tile t+2 into the buffer tile t-1 has left (its last readers passed the previous barrier), tile t+3 requested
+    if (t + 2 < nwalk) stage(b2);
+    if (t + 3 < nwalk) prefetch(tile_at(t + 3));
+    // (3) O^T[d][q] += V^T[d][key] . P^T[key][q], denominator on the same probabilities
+    const unsigned char* Vs = smem + bt * BUF + VOFF;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        f16x8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (half_t)sc[kt][8 * u + j];
+        ls = SDM_MFMA_32x32x16_F16(ones, pf, ls);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const unsigned char* vp = Vs + (dt * 32 + l31) * PV + (kt * 32 + 16 * u + 4 * hi) * 2;
+          const f16x4 v0 = *(const f16x4*)vp, v1 = *(const f16x4*)(vp + 16);
+          f16x8 vf;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { vf[e] = v0[e]; vf[4 + e] = v1[e]; }
+          o[dt] = SDM_MFMA_32x32x16_F16(vf, pf, o[dt]);
+        }
+      }
+    lds_barrier();
+    bt = b1;
+  };
+  for (int t = 0; t < nwalk; t += 2) {
+    iter(t, sa, sb);
+    if (t + 1 < nwalk) iter(t + 1, sb, sa);
+  }
+
+  // epilogue (fp32 output): per-wave staging [32 q][64 d] at pitch 272 B -> coalesced 16-byte row stores
+  constexpr int PS = 272;
+  unsigned char* stf = smem + wave * (32 * PS);
+  const float inv = 1.0f / ls[0];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) h[e] = o[dt][4 * g + e] * inv;
+      *(f32x4*)(stf + l31 * PS + (dt * 32 + 8 * g + 4 * hi) * 4) = h;
+    }
+  SDM_WAVE_SYNC();
+#pragma unroll
+  for (int pass = 0; pass < 8; ++pass) {
+    const int row = pass * 4 + (lane >> 4), part = lane & 15;
+    const int qg = q0 + row;
+    if (qg < p.Lq)
+      *(f32x4*)((float*)p.o + (size_t)b * p.o_bs + (size_t)qg * p.ldo + head * 64 + part * 4) = *(const f32x4*)(stf + row * PS + part * 16);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // d = 512, single head (VAE mid-block).  8 waves: wave w handles queries 32*(w>>1).. and the d-half
 // (w&1): partial S^T over its 256 d, exchanged with the partner wave through LDS; both then run the
 // same softmax and each accumulates O^T for its own 256 d.  32-key tiles.

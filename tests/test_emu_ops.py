@@ -195,7 +195,7 @@ def test_attention_d64_split_precision(emu_engine, monkeypatch):
     monkeypatch.delenv("SDM_ATTN_F8")
     # the 8-wave form of the same kernel (level-0 attentions; global loads two key tiles ahead through two raw-tile register sets): same
     # arithmetic per query row as the 4-wave form -> bit-identical, for 1, 2, 3 and 5 key tiles and the trimap-style tile list
-    for lk in (40, 128, 130, 300):
+    for lk in (40, 128, 130, 300, 450):
         kk, vv = torch.randn(1, lk, 128, generator=g) * 1.5, torch.randn(1, lk, 128, generator=g)
         bias = torch.where(torch.rand(1, lk, generator=g) < 0.3, torch.tensor(-10000.0), torch.tensor(0.0))
         for bb in (None, bias):
@@ -204,6 +204,11 @@ def test_attention_d64_split_precision(emu_engine, monkeypatch):
             monkeypatch.setenv("SDM_ATTN_NW", "8")
             r8 = emu_engine.op_attention_split(q, kk, vv, 2, bias=bb)
             assert torch.equal(r4, r8), (lk, bb is not None, (r4 - r8).abs().max().item())
+            # the experimental two-tile software pipeline of the 8-wave kernel (SDM_ATTN_PIPE=1, three LDS buffers): same arithmetic
+            monkeypatch.setenv("SDM_ATTN_PIPE", "1")
+            rp = emu_engine.op_attention_split(q, kk, vv, 2, bias=bb)
+            monkeypatch.delenv("SDM_ATTN_PIPE")
+            assert torch.equal(rp, r8), (lk, bb is not None, (rp - r8).abs().max().item())
     monkeypatch.delenv("SDM_ATTN_NW")
 
 
