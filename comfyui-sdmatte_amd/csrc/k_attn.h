@@ -484,8 +484,8 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_kernel(AttnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// EXPERIMENTAL (SDM_ATTN_PIPE=1; off by default: built and checked bit-identical to attn_d64_kernel<1,3,8> on the emulator at the end
-// of round 3, not yet measured on hardware).  The 8-wave fp8-residual kernel above as a TWO-TILE software pipeline: the Q.K^T MFMAs
+// The 8-wave fp8-residual kernel above as a TWO-TILE software pipeline (default for the 8-wave launches with fp32 output; SDM_ATTN_PIPE=0
+// selects attn_d64_kernel<1,3,8>; measured -9 % on those launches, bit-identical results on hardware: profiles/r03_attn_pipe_ab.txt): the Q.K^T MFMAs
 // of key tile t+1 and the softmax of key tile t are independent and sit in ONE basic block, so the scheduler can issue the VALU stream
 // (max / sub / exp / pack: ~1000 cycles per tile) underneath the matrix stream instead of after it; both waves of a SIMD are in the
 // same phase of attn_d64_kernel (one barrier per tile), and SQ counters put 42 % of a wave's cycles into issue stalls there.

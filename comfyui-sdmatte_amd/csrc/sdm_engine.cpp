@@ -1095,9 +1095,10 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
       const int qb = sdm_cdiv(p.nq_blocks, p.q_chunks);
       const unsigned nblk = (unsigned)(B * heads * p.q_chunks * qb);                         // 1-D grid, XCD-aware mapping in the kernel
       if (ap.prec == 2) {
-        // SDM_ATTN_PIPE=1: the experimental two-tile software pipeline of the 8-wave kernel (k_attn.h, attn_d64_pipe_kernel; fp32 output only)
+        // 8-wave blocks with fp32 output (the engine's level-0 attentions): the two-tile software pipeline of the kernel (k_attn.h,
+        // attn_d64_pipe_kernel: same arithmetic, bit-identical results, -9 % kernel time); SDM_ATTN_PIPE=0 selects the plain form.  A/B hook.
         const char* pipe_env = getenv("SDM_ATTN_PIPE");
-        if (nw8 && pipe_env && pipe_env[0] == '1' && p.o_f32) { auto kp = attn_d64_pipe_kernel; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(512), ATTN64PIPE_SMEM, e->stream, p); }
+        if (nw8 && !(pipe_env && pipe_env[0] == '0') && p.o_f32) { auto kp = attn_d64_pipe_kernel; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(512), ATTN64PIPE_SMEM, e->stream, p); }
         else if (nw8) { auto kp = attn_d64_kernel<1, 3, 8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(512), ATTN64P_SMEM, e->stream, p); }
         else { auto kp = attn_d64_kernel<1, 3, 4>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(256), ATTN64P_SMEM, e->stream, p); }
       } else if (ap.prec && pv_split) {

@@ -202,12 +202,12 @@ def test_attention_d64_split_precision(emu_engine, monkeypatch):
             monkeypatch.setenv("SDM_ATTN_NW", "4")
             r4 = emu_engine.op_attention_split(q, kk, vv, 2, bias=bb)
             monkeypatch.setenv("SDM_ATTN_NW", "8")
+            monkeypatch.setenv("SDM_ATTN_PIPE", "0")
             r8 = emu_engine.op_attention_split(q, kk, vv, 2, bias=bb)
             assert torch.equal(r4, r8), (lk, bb is not None, (r4 - r8).abs().max().item())
-            # the experimental two-tile software pipeline of the 8-wave kernel (SDM_ATTN_PIPE=1, three LDS buffers): same arithmetic
-            monkeypatch.setenv("SDM_ATTN_PIPE", "1")
-            rp = emu_engine.op_attention_split(q, kk, vv, 2, bias=bb)
+            # the two-tile software pipeline of the 8-wave kernel (the default for 8-wave launches; three LDS buffers): same arithmetic
             monkeypatch.delenv("SDM_ATTN_PIPE")
+            rp = emu_engine.op_attention_split(q, kk, vv, 2, bias=bb)
             assert torch.equal(rp, r8), (lk, bb is not None, (rp - r8).abs().max().item())
     monkeypatch.delenv("SDM_ATTN_NW")
 
