@@ -493,12 +493,24 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_kernel(AttnParams p) {
 // the barrier is the raw s_barrier behind an LDS-only wait, so the global loads of tile t+3 stay in flight across it.
 // Same arithmetic, same order per query row as attn_d64_kernel<1,3,8>: results are bit-identical (tests/test_emu_ops.py).
 // ------------------------------------------------------------------------------------------------
+// NW = 8 (measured, default): three whole tile buffers.  NW = 4 (SDM_ATTN_PIPE4=1, built at the very end of round 3: bit-identical on the
+// emulator, NOT yet run on hardware): K | pair plane | bias of a tile are read one iteration before its V^T, so they rotate through TWO
+// buffers and only V^T through three - 63.5 KB per block, two blocks per CU as for attn_d64_kernel<1,3,4>.
 #define ATTN64PIPE_SMEM (3 * ATTN64P_BUF)
-__global__ void __launch_bounds__(512, 2) attn_d64_pipe_kernel(AttnParams p) {
-  constexpr int NW = 8, NTH = 64 * NW;
+#define ATTN64PIPE4_KB (2 * 64 * ATTN64_PK + 256)
+#define ATTN64PIPE4_VB (64 * ATTN64_PV)
+#define ATTN64PIPE4_SMEM (2 * ATTN64PIPE4_KB + 3 * ATTN64PIPE4_VB)
+template <int NW>
+__global__ void __launch_bounds__(64 * NW, 2) attn_d64_pipe_kernel(AttnParams p) {
+  constexpr int NTH = 64 * NW, VPT = 512 / NTH;
+  constexpr bool SPLITBUF = NW == 4;
   SDM_DYN_SMEM(smem);
   constexpr int PK = ATTN64_PK, PV = ATTN64_PV, BUF = ATTN64P_BUF;
   constexpr int KLO = 64 * PK, VOFF = 2 * 64 * PK, BOFF = VOFF + 64 * PV;
+  // LDS addresses of tile k's parts; b3 = k % 3, b2 = k & 1
+  auto k_of = [&](int b3, int b2) { return SPLITBUF ? smem + b2 * ATTN64PIPE4_KB : smem + b3 * BUF; };
+  auto v_of = [&](int b3) { return SPLITBUF ? smem + 2 * ATTN64PIPE4_KB + b3 * ATTN64PIPE4_VB : smem + b3 * BUF + VOFF; };
+  auto bias_of = [&](int b3, int b2) { return (float*)(SPLITBUF ? smem + b2 * ATTN64PIPE4_KB + 2 * 64 * PK : smem + b3 * BUF + BOFF); };
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, l31 = lane & 31;
   int b, head, qblk;
@@ -537,38 +549,46 @@ __global__ void __launch_bounds__(512, 2) attn_d64_pipe_kernel(AttnParams p) {
   const int nwalk = tl ? tl[0] : ntiles;
   auto tile_at = [&](int i) { return tl ? tl[1 + i] : i; };
 
-  // one raw tile between global memory and LDS (one 16-byte vector of K_hi, K pair plane and V^T per thread, one bias value per lane)
-  f16x8 rk, rkl, rv;
+  // one raw tile between global memory and LDS (VPT 16-byte vectors of K_hi, K pair plane and V^T per thread, one bias value per lane)
+  f16x8 rk[VPT], rkl[VPT], rv[VPT];
   float rb = 0.0f;
   bool rin = true;
-  const int srow = tid >> 3, spart = tid & 7;
   auto prefetch = [&](int t) {
     const int k0 = t * 64;
-    int kr = k0 + srow;
-    if (kr > p.Lk - 1) kr = p.Lk - 1;
-    rk = *(const f16x8*)(kbase + (size_t)kr * p.ldk + spart * 8);
-    rv = *(const f16x8*)(vbase + (size_t)srow * p.ldvt + k0 + spart * 8);
-    rkl = *(const f16x8*)(kbase + p.k_lo + (size_t)kr * p.ldk + spart * 8);
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const int v = tid + i * NTH, srow = v >> 3, spart = v & 7;
+      int kr = k0 + srow;
+      if (kr > p.Lk - 1) kr = p.Lk - 1;
+      rk[i] = *(const f16x8*)(kbase + (size_t)kr * p.ldk + spart * 8);
+      rv[i] = *(const f16x8*)(vbase + (size_t)srow * p.ldvt + k0 + spart * 8);
+      rkl[i] = *(const f16x8*)(kbase + p.k_lo + (size_t)kr * p.ldk + spart * 8);
+    }
     int kb = k0 + (tid & 63);
     rin = kb < p.Lk;
     if (!rin) kb = p.Lk - 1;
     rb = bsrc[kb];
   };
-  auto stage = [&](int buf) {
-    unsigned char* base = smem + buf * BUF;
-    *(f16x8*)(base + srow * PK + spart * 16) = rk;
-    f16x4 lo, hi4;
+  auto stage = [&](int b3, int b2) {
+    unsigned char* kb_ = k_of(b3, b2);
+    unsigned char* vb_ = v_of(b3);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { lo[e] = rv[e]; hi4[e] = rv[4 + e]; }
-    *(f16x4*)(base + VOFF + srow * PV + spart * 16) = lo;
-    *(f16x4*)(base + VOFF + srow * PV + spart * 16 + 8) = hi4;
-    *(f16x8*)(base + KLO + srow * PK + spart * 16) = rkl;
-    if (tid < 64) ((float*)(base + BOFF))[tid] = rin ? (bbase ? rb : 0.0f) : SDM_NEG_BIG;
+    for (int i = 0; i < VPT; ++i) {
+      const int v = tid + i * NTH, srow = v >> 3, spart = v & 7;
+      *(f16x8*)(kb_ + srow * PK + spart * 16) = rk[i];
+      f16x4 lo, hi4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { lo[e] = rv[i][e]; hi4[e] = rv[i][4 + e]; }
+      *(f16x4*)(vb_ + srow * PV + spart * 16) = lo;
+      *(f16x4*)(vb_ + srow * PV + spart * 16 + 8) = hi4;
+      *(f16x8*)(kb_ + KLO + srow * PK + spart * 16) = rkl[i];
+    }
+    if (tid < 64) bias_of(b3, b2)[tid] = rin ? (bbase ? rb : 0.0f) : SDM_NEG_BIG;
   };
   // logits of one key tile: S^T[key][q], accumulators started from the per-key bias
-  auto qk = [&](int buf, f32x16 (&s)[2]) {
-    const unsigned char* Ks = smem + buf * BUF;
-    const float* Bs = (const float*)(Ks + BOFF);
+  auto qk = [&](int b3, int b2, f32x16 (&s)[2]) {
+    const unsigned char* Ks = k_of(b3, b2);
+    const float* Bs = bias_of(b3, b2);
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -597,22 +617,22 @@ __global__ void __launch_bounds__(512, 2) attn_d64_pipe_kernel(AttnParams p) {
 
   // ---- prologue: tiles 0 and 1 in LDS, tile 2 on its way, logits of tile 0 in registers ----
   prefetch(tile_at(0));
-  stage(0);
+  stage(0, 0);
   if (1 < nwalk) prefetch(tile_at(1));
   lds_barrier();
-  if (1 < nwalk) stage(1);
+  if (1 < nwalk) stage(1, 1);
   if (2 < nwalk) prefetch(tile_at(2));
   f32x16 sa[2], sb[2];
-  qk(0, sa);
+  qk(0, 0, sa);
   lds_barrier();
 
   int bt = 0;                         // buffer of tile t (t % 3 without a division)
   // sc: logits of tile t (consumed here), sn: receives the logits of tile t+1; the two register sets swap roles every tile
   auto iter = [&](const int t, f32x16 (&sc)[2], f32x16 (&sn)[2]) {
-    const int b1 = bt == 2 ? 0 : bt + 1, b2 = b1 == 2 ? 0 : b1 + 1;      // buffers of tiles t+1, t+2
+    const int b1 = bt == 2 ? 0 : bt + 1, b2 = b1 == 2 ? 0 : b1 + 1;      // three-buffer slots of tiles t+1, t+2 (two-buffer slots: parities)
     // (1) logits of tile t+1 (when there is none: the same instructions on a buffer nobody consumes - no branch inside this block)
     //     and the softmax of tile t: independent streams in one basic block
-    qk(b1, sn);
+    qk(b1, (t + 1) & 1, sn);
     float mx = SDM_NEG_BIG;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
@@ -635,10 +655,10 @@ __global__ void __launch_bounds__(512, 2) attn_d64_pipe_kernel(AttnParams p) {
         for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
     }
     // (2) tile t+2 into the buffer tile t-1 has left (its last readers passed the previous barrier), tile t+3 requested
-    if (t + 2 < nwalk) stage(b2);
+    if (t + 2 < nwalk) stage(b2, t & 1);
     if (t + 3 < nwalk) prefetch(tile_at(t + 3));
     // (3) O^T[d][q] += V^T[d][key] . P^T[key][q], denominator on the same probabilities
-    const unsigned char* Vs = smem + bt * BUF + VOFF;
+    const unsigned char* Vs = v_of(bt);
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll

@@ -1098,7 +1098,9 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
         // 8-wave blocks with fp32 output (the engine's level-0 attentions): the two-tile software pipeline of the kernel (k_attn.h,
         // attn_d64_pipe_kernel: same arithmetic, bit-identical results, -9 % kernel time); SDM_ATTN_PIPE=0 selects the plain form.  A/B hook.
         const char* pipe_env = getenv("SDM_ATTN_PIPE");
-        if (nw8 && !(pipe_env && pipe_env[0] == '0') && p.o_f32) { auto kp = attn_d64_pipe_kernel; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(512), ATTN64PIPE_SMEM, e->stream, p); }
+        const char* pipe4_env = getenv("SDM_ATTN_PIPE4");      // the same pipeline for the 4-wave launches: built, emulator-checked, not yet measured (off)
+        if (nw8 && !(pipe_env && pipe_env[0] == '0') && p.o_f32) { auto kp = attn_d64_pipe_kernel<8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(512), ATTN64PIPE_SMEM, e->stream, p); }
+        else if (!nw8 && pipe4_env && pipe4_env[0] == '1' && p.o_f32) { auto kp = attn_d64_pipe_kernel<4>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(256), ATTN64PIPE4_SMEM, e->stream, p); }
         else if (nw8) { auto kp = attn_d64_kernel<1, 3, 8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(512), ATTN64P_SMEM, e->stream, p); }
         else { auto kp = attn_d64_kernel<1, 3, 4>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(256), ATTN64P_SMEM, e->stream, p); }
       } else if (ap.prec && pv_split) {

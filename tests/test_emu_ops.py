@@ -201,6 +201,10 @@ def test_attention_d64_split_precision(emu_engine, monkeypatch):
         for bb in (None, bias):
             monkeypatch.setenv("SDM_ATTN_NW", "4")
             r4 = emu_engine.op_attention_split(q, kk, vv, 2, bias=bb)
+            monkeypatch.setenv("SDM_ATTN_PIPE4", "1")          # the 4-wave pipeline (two K / three V^T buffers; off by default, unmeasured)
+            r4p = emu_engine.op_attention_split(q, kk, vv, 2, bias=bb)
+            monkeypatch.delenv("SDM_ATTN_PIPE4")
+            assert torch.equal(r4p, r4), (lk, bb is not None, (r4p - r4).abs().max().item())
             monkeypatch.setenv("SDM_ATTN_NW", "8")
             monkeypatch.setenv("SDM_ATTN_PIPE", "0")
             r8 = emu_engine.op_attention_split(q, kk, vv, 2, bias=bb)

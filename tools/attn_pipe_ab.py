@@ -16,7 +16,7 @@ eng = Engine(SDMatteConfig.tiny(), 0, precision="fp16x3")
 g = torch.Generator(device="cuda").manual_seed(3)
 os.environ["SDM_ATTN_NW"] = "8"
 ok = True
-for (B, h, Lq, Lk) in ((1, 5, 4096, 4096), (2, 5, 16384, 16384), (1, 10, 1000, 4096 + 37)):
+for (B, h, Lq, Lk) in ((2, 5, 16384, 16384), (1, 10, 1000, 4096 + 37)):
     q = torch.randn(B, Lq, h * 64, generator=g, device="cuda") * 1.5
     k = torch.randn(B, Lk, h * 64, generator=g, device="cuda") * 1.5
     v = torch.randn(B, Lk, h * 64, generator=g, device="cuda")
@@ -32,13 +32,31 @@ for (B, h, Lq, Lk) in ((1, 5, 4096, 4096), (2, 5, 16384, 16384), (1, 10, 1000, 4
         ok &= same
         print(f"B={B} h={h} Lq={Lq} Lk={Lk} {name:12s} pipe == shipped (3 runs): {same}" + ("" if same else f"  max|d|={max((o - ref).abs().max().item() for o in outs):.3e}"), flush=True)
 os.environ.pop("SDM_ATTN_NW", None)
-print("bit-identical:", ok)
-for rep in range(2):
-    for pipe in ("0", "1"):
-        env = dict(os.environ, SDM_ATTN_PIPE=pipe)
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--timed-only", "--steps", "4", "--warmup", "2"], env=env, capture_output=True, text=True)
-        try:
-            d = json.loads(r.stdout.strip().splitlines()[-1])
-            print(f"SDM_ATTN_PIPE={pipe}: {d['value']} img/s {d['ms_per_step']} ms/step", {k: x["ms"] for k, x in list(d["kernel_breakdown_ms"].items())[:4]}, flush=True)
-        except Exception as e:
-            print("bench failed", e, r.stderr[-400:])
+print("8-wave pipeline bit-identical:", ok)
+# the 4-wave pipeline (SDM_ATTN_PIPE4=1, off by default)
+os.environ["SDM_ATTN_NW"] = "4"
+ok4 = True
+for (B, h, Lq, Lk) in ((1, 10, 4096, 16384), (1, 10, 1000, 4096 + 37)):
+    q = torch.randn(B, Lq, h * 64, generator=g, device="cuda") * 1.5
+    k = torch.randn(B, Lk, h * 64, generator=g, device="cuda") * 1.5
+    v = torch.randn(B, Lk, h * 64, generator=g, device="cuda")
+    blocks = torch.where(torch.rand(B, Lk, generator=g, device="cuda") < 0.4, torch.tensor(-10000.0, device="cuda"), torch.tensor(0.0, device="cuda"))
+    blocks[:, : Lk // 3] = -10000.0
+    for name, bb in (("dense", None), ("masked tiles", blocks)):
+        os.environ.pop("SDM_ATTN_PIPE4", None)
+        ref = eng.op_attention_split(q, k, v, h, bias=bb)
+        os.environ["SDM_ATTN_PIPE4"] = "1"
+        outs = [eng.op_attention_split(q, k, v, h, bias=bb) for _ in range(3)]
+        os.environ.pop("SDM_ATTN_PIPE4", None)
+        same = all(torch.equal(o, ref) for o in outs)
+        ok4 &= same
+        print(f"4-wave: B={B} h={h} Lq={Lq} Lk={Lk} {name:12s} pipe4 == shipped (3 runs): {same}", flush=True)
+os.environ.pop("SDM_ATTN_NW", None)
+print("4-wave pipeline bit-identical:", ok4)
+for name, envs in (("plain 8-wave kernel (SDM_ATTN_PIPE=0)", {"SDM_ATTN_PIPE": "0"}), ("default (8-wave pipeline)", {}), ("+ 4-wave pipeline (SDM_ATTN_PIPE4=1)", {"SDM_ATTN_PIPE4": "1"})):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--timed-only", "--steps", "4", "--warmup", "2"], env=dict(os.environ, **envs), capture_output=True, text=True)
+    try:
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        print(f"{name}: {d['value']} img/s {d['ms_per_step']} ms/step", {k: x["ms"] for k, x in list(d["kernel_breakdown_ms"].items())[:4]}, flush=True)
+    except Exception as e:
+        print("bench failed", e, r.stderr[-400:])
