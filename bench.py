@@ -76,6 +76,8 @@ def main():
                     help="TEST HOOK (tests/test_emu_e2e.py): run the same script on the CPU kernel emulator with gloo and the tiny architecture, so "
                          "that the N > 1 control flow of this file is exercised in the GPU-less build container; never a benchmark")
     ap.add_argument("--dump-profile", type=str, default=None, help="write the per-launch profile CSV here")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="engine kernel-selection option for A/B runs (sdm_set_option; see sdm_option_name / sdm_option_help)")
     ap.add_argument("--dense-attention", action="store_true",
                     help="walk every key tile in the trimap-biased self-attention instead of skipping the tiles whose bias underflows the softmax")
     args = ap.parse_args()
@@ -112,8 +114,6 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    if args.dense_attention:
-        os.environ["SDM_ATTN_DENSE"] = "1"
     load_package()
     from comfyui_sdmatte_amd import engine as E
     from comfyui_sdmatte_amd.config import SDMatteConfig
@@ -128,9 +128,16 @@ def main():
         import ctypes
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from emu.build_emu import build as _build_emu
-        eng = E.Engine(cfg, 0, precision=precision, _lib=E.Bindings(ctypes.CDLL(_build_emu())))
+        emu_lib = E.Bindings(ctypes.CDLL(_build_emu()))
+        for kv in args.opt:
+            emu_lib.set_option(kv.split("=", 1)[0], int(kv.split("=", 1)[1]))
+        eng = E.Engine(cfg, 0, precision=precision, _lib=emu_lib)
     else:
+        for kv in args.opt:                      # (before the model is built: some options select the weight layouts)
+            E.load_library().set_option(kv.split("=", 1)[0], int(kv.split("=", 1)[1]))
         eng = E.Engine(cfg, local_rank, precision=precision)
+    if args.dense_attention:
+        eng.lib.set_option("attn_dense", 1)      # (an engine option set through the C ABI: the library reads no environment variable)
     sd = None
     if rank == 0:
         sd = synthetic_state_dict(cfg, 0)
@@ -196,15 +203,15 @@ def main():
         #      the fp32 softmax - exact, but trimap-dependent): reported next to `value`, never instead of it ----
         dense = None
         if world == 1 and not args.timed_only and not args.dense_attention:
-            os.environ["SDM_ATTN_DENSE"] = "1"           # read per launch by the engine
+            eng.lib.set_option("attn_dense", 1)
             try:
                 step()
                 el_d = timed_steps(step, max(2, args.steps // 2), 1, dev)
                 nd = max(2, args.steps // 2)
                 dense = {"images_per_s": round(B * nd / el_d, 3), "ms_per_step": round(el_d * 1e3 / nd, 3),
-                         "note": "SDM_ATTN_DENSE=1: every key tile of the trimap-biased self-attention is loaded and multiplied"}
+                         "note": "engine option attn_dense = 1: every key tile of the trimap-biased self-attention is loaded and multiplied"}
             finally:
-                os.environ.pop("SDM_ATTN_DENSE", None)
+                eng.lib.set_option("attn_dense", 0)
         # ---- roofline of the dominant kernel: per-launch HIP events on the engine stream (separate pass, 1 step) ----
         eng.profile(True)
         eng.apply_matte(img_d, tri_d, S, False, out=alpha, sync=True)
@@ -235,7 +242,7 @@ def main():
                 mfma_busy = ps.get("conv3x3_mfma_busy_frac")
         except Exception:
             pass
-        f8_res = precision == "fp16x3" and os.environ.get("SDM_CONV_F8", "1") != "0"      # residual terms of the 3x3 convs on fp8 (engine default)
+        f8_res = precision == "fp16x3" and eng.lib.get_option("conv_f8") != 0      # residual terms of the 3x3 convs on fp8 (engine default)
         # matrix-pipe time per algorithmic product in units of one fp16 MFMA: fp16x3 = 3; fp16 + two fp8 residual terms at twice
         # the rate = 2 (a handful of thin / strided launches of the family stay on 3 and are counted as 2: lower bound)
         mfma_per_product = (2 if f8_res else 3) if precision == "fp16x3" else 1
@@ -271,7 +278,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             from oracle import sdmatte_oracle as O
             Sc = args.cpu_sample_size
-            ci, ct = synthetic_inputs(1, Sc, Sc, seed=1234)
+            # the oracle's input IS image 0 of the timed batch (when the sample has the benchmark's own size): `parity` then describes the
+            # kernels the headline number ran - tile and kernel selection depend on the batch size
+            from_batch = Sc == S
+            ci, ct = (img[:1].contiguous(), tri[:1].contiguous()) if from_batch else synthetic_inputs(1, Sc, Sc, seed=1234)
             data = O.preprocess(ci, ct, Sc, False)
             tc = time.perf_counter()
             ref = O.sdmatte_forward(sd, cfg.as_dict(), data)
@@ -283,6 +293,14 @@ def main():
                              f"force_cpu path) took {tcpu:.1f} s on this host"
                              + ("" if Sc == S else f"; EXTRAPOLATED to {S}x{S} by the dense-FLOP ratio {scale:.2f}")}
             parity = {"tolerance": 1e-3, "sample": f"{Sc}x{Sc}, full architecture, same synthetic weights, vs the fp32 oracle"}
+            if from_batch:
+                step()                                   # (the dense-attention / other-mode legs above may have reused the buffer)
+                torch.cuda.synchronize()
+                dt0 = (alpha[0].detach().float().cpu() - ref[0].clamp(0.0, 1.0).reshape(alpha[0].shape)).abs()
+                parity["sample"] = (f"image 0 of the timed batch (B = {B} at {S}x{S}: the kernels the headline number ran), full architecture, same "
+                                    "synthetic weights, vs the fp32 oracle clamped to [0, 1] as the node does")
+                parity["timed_batch_image0_max_abs_dalpha"] = float(dt0.max())
+                parity["timed_batch_image0_mean_abs_dalpha"] = float(dt0.mean())
             for name, en in ((precision, eng), (other, eng_o)):
                 if en is None:
                     continue
@@ -290,7 +308,8 @@ def main():
                 dd = (got - ref).abs()
                 modes[name]["max_abs_dalpha"] = float(dd.max())
                 modes[name]["mean_abs_dalpha"] = float(dd.mean())
-            parity["max_abs_dalpha"] = modes[precision]["max_abs_dalpha"]
+            parity["max_abs_dalpha"] = parity.get("timed_batch_image0_max_abs_dalpha", modes[precision]["max_abs_dalpha"])
+            parity["single_image_call_max_abs_dalpha"] = modes[precision]["max_abs_dalpha"]
             parity["mean_abs_dalpha"] = modes[precision]["mean_abs_dalpha"]
             parity["within_tolerance"] = parity["max_abs_dalpha"] <= 1e-3
             cpu["max_abs_dalpha_vs_gpu"] = parity["max_abs_dalpha"]
@@ -309,7 +328,7 @@ def main():
                                        "3x3 convs with >= 128 output channels, the GEMMs with K >= 1024 and (e5m2 x e5m2) Q.K^T of the d=64 "
                                        "attention cores, on fp16 (2 more MFMAs) in every other conv / GEMM; P.V and the softmax denominator on the "
                                        "same plain fp16 probabilities (fp32 accumulate); the d=512 VAE attention core on plain fp16"
-                                       if os.environ.get("SDM_CONV_F8", "1") != "0" else
+                                       if eng.lib.get_option("conv_f8") != 0 else
                                        "split-fp16 MFMA operands (hi+lo, 3 MFMAs per product), fp32 accumulate, fp32 activations")
                                       if precision == "fp16x3" else "fp16 MFMA operands, fp32 accumulate, fp32 residual stream"),
                        "trimap": "synthetic disc/annulus (28 % foreground / 22 % unknown / 50 % background, SURVEY.md 8d)",

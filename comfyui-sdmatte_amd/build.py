@@ -54,6 +54,10 @@ def build_all(verbose=False, force=False, extra_flags=(), out=None):
         raise RuntimeError("hipcc failed building libsdmatte_hip.so")
     if verbose and r.stderr.strip():
         print(r.stderr[-4000:])
+    # a kernel whose body the HOST pass rejects (e.g. inline asm that is only valid for gfx950) is dropped without a diagnostic and leaves
+    # an undefined stub symbol: load the library once so that this fails here, in the build container, and not on the GPU box
+    import ctypes
+    ctypes.CDLL(lib)
     with open(stamp_file, "w") as f:
         f.write(stamp)
     return lib

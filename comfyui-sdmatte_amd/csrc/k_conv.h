@@ -24,7 +24,6 @@
 //                 channel-offset stores (writes straight into the 8-ch U-Net input tensor).
 #pragma once
 #include "sdm_common.h"
-#include <type_traits>
 
 #ifndef SDM_CONV_VREUSE
 #define SDM_CONV_VREUSE 1   /* vertical A-fragment reuse across taps (A/B switch for experiments) */
@@ -66,8 +65,9 @@ struct ConvParams {
   int f8;                               // 1: w_dma holds the fp8-residual layout (derive_conv_weight_f8_kernel) -> F8 kernel
   int f8_hint;                          // tile selection only: the layer has the fp8-residual weights (cfg 0 then beats the 256x64 tile)
   int f8_sa, f8_sb;                     // E8M0 exponents (byte 0) of the fp8 MFMA operand scales: 2^(sa-127) * 2^(sb-127) maps the residual sums to accumulator units
-  unsigned long long* trace;            // bench only (sdm_bench_conv, ablate bit 256): per-event shader-clock stamps of the first 8 blocks' consumer wave 0 and
-                                        // producer wave 0 of the F8 3x3 kernel, [block][role][tile < 8][event < 16]; null in the engine
+  unsigned int* trace;                  // bench only (sdm_bench_conv, ablate bit 256; -DSDM_CONV_TRACE builds): shader-clock stamps of consumer wave 0 and
+                                        // producer wave 0 of 16 blocks of the F8 3x3 kernel, [block][role][384] (slot 383 = count); null in the engine
+  int trace_skip, trace_b0;             // tiles of a block before the first traced one; first traced block
   int xtile;                            // F8 3x3 kernels: 1 = the producers run the next tile's prologue during the current tile's last chunk (cross-tile prefetch)
   int epi_mode;                         // F8 kernels (accumulators [channel][pixel]): 0 = LDS-staged epilogue; 3 = 0 + the residual enters as the accumulators'
                                         // initial value; 4 = 3 + full fp32 tiles are stored straight from the registers (16-byte stores, bias from LDS,
@@ -112,6 +112,13 @@ struct ConvCfg {
   static constexpr int TILE_BYTES = DMAB ? (PC ? 4 : 2) * A_BYTES + DMA_SLOTS * DMA_SLOT
                                          : (SPLIT ? 2 : 1) * A_BYTES + B_BYTES;   // one K-chunk of A halo (SPLIT: high and low parts) + B taps
   static constexpr int SMEM = ((DB ? 2 : 1) * TILE_BYTES) > STG_BYTES ? ((DB ? 2 : 1) * TILE_BYTES) : STG_BYTES;
+  // F8 kernels, behind the tiles: two bias tables (BN floats each) | [traced builds: parked stamps]
+#ifdef SDM_CONV_TRACE
+  static constexpr int TRACE_BYTES = 1792;      // 64 consumer + 384 producer stamps
+#else
+  static constexpr int TRACE_BYTES = 0;
+#endif
+  static constexpr int F8_EXTRA = 2 * BN * 4 + TRACE_BYTES;
   static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of 32x32");
   static_assert(KC % 16 == 0, "KC multiple of the MFMA K (16)");
   static_assert(!DB || KC == 16, "swizzled double-buffered tiles assume 2 halves per row");
@@ -179,6 +186,9 @@ conv_mfma_kernel(ConvParams p) {
   // memory pipeline serves the CU's stores and loads in order; with the prologue's loads queued BEHIND the stores every tile paid
   // the store drain plus a full load latency).  pre_done: the tile about to start was prepared that way.
   int pre_done = 0;
+#if defined(SDM_CONV_TRACE) && !defined(SDM_EMU)
+  int tr_n = 0;
+#endif
   u32x4 a_nx[A_PER][IN_F32 ? 2 : 1];
   f32x4 gqn[4];
   // role_c: std::integral_constant<int, R>.  R = 0 / 1: this copy of the tile body is executed by consumer / producer waves only (the F8
@@ -193,17 +203,35 @@ conv_mfma_kernel(ConvParams p) {
   const int role = (ROLE_C >= 0) ? ROLE_C : (PC ? SDM_UNIFORM_I(tx / NT) : 0);                  // 0: consumer (or everything), 1: producer
   const int tid = PC ? (tx & (NT - 1)) : tx, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  // bench-only event stamps (ConvParams::trace)
-  int trace_ev = 0;
-  auto stamp = [&]() {
-#if defined(SDM_CONV_TRACE) && !defined(SDM_EMU)      // compiled in by tools/conv_trace.py only (the stamps cost registers: 212 B / lane of scratch)
-    if (F8 && NTAPS == 9 && p.trace && blockIdx.x < 8 && tid == 0 && trace_ev < 16) {
-      const int tile_k = (vbid - (int)blockIdx.x) / (int)gridDim.x;
-      if (tile_k < 8) p.trace[(((size_t)blockIdx.x * 2 + role) * 8 + tile_k) * 16 + trace_ev] = __builtin_amdgcn_s_memtime();
+  // bench-only event stamps (ConvParams::trace; -DSDM_CONV_TRACE builds of tools/conv_trace.py only).  The stamps of consumer wave 0 /
+  // producer wave 0 are PARKED IN LDS (behind the bias tables: 64 consumer + 384 producer stamps) and copied to global memory once, when the block's last
+  // tile is done: a stamp is s_memtime + one ds_write_b32 of lane 0 - no vector-memory operation, so the counted vmcnt waits of the
+  // producers and the in-order store / load queue of the CU see exactly what they see in the product build.  Bit 0 of a stamp = 1:
+  // first stamp of a tile.  Per-step stamps (arrival at / release from every barrier of the chunk loop) are taken by the PRODUCER only:
+  // the consumers' loop runs at the register limit (any stamp there spills), and a barrier is joint - the producer's wait at a barrier is
+  // the time it was ahead of the consumers, no wait means the consumers were waiting for it.  Lab-only ablations (ConvParams::ablate) live under the same macro.
+#if defined(SDM_CONV_TRACE) && !defined(SDM_EMU)
+  const bool tr_on = (F8 && NTAPS == 9) && p.trace && ((vbid - (int)blockIdx.x) / (int)gridDim.x) >= p.trace_skip;
+  auto stamp = [&](int first = 0) {
+    if (tr_on && tr_n < (ROLE_C > 0 ? 383 : 63)) {      // wave-uniform: the count stays in an SGPR
+      const unsigned int t = (unsigned int)__builtin_amdgcn_s_memtime();
+      unsigned int* tr_buf = (unsigned int*)(smem + C::TILE_BYTES + 2 * BN * 4) + (ROLE_C > 0 ? 64 : 0);
+      if (tid == 0) tr_buf[tr_n] = first ? (t | 1u) : (t & ~1u);
+      ++tr_n;
     }
-    ++trace_ev;
-#endif
   };
+#else
+  auto stamp = [&](int first = 0) { (void)first; };
+#endif
+  // -DSDM_CONV_LAB builds (tools/conv_lab.py) only - differential timing of the F8 3x3 kernel, results are garbage: ConvParams::ablate bit 0 =
+  // activation loads from a 64-pixel window (cache-resident), 1 = no weight DMAs after a tile's first two steps, 2 = no MFMAs, 4 = no
+  // operand transform / LDS writes by the producers, 5 = no activation loads after the prologue (3 = no epilogue stores)
+#if defined(SDM_CONV_LAB) && !defined(SDM_EMU)
+  const bool lab_win = (p.ablate & 1) != 0, lab_nodma = (p.ablate & 2) != 0, lab_nomm = (p.ablate & 4) != 0, lab_nowr = (p.ablate & 16) != 0, lab_nold = (p.ablate & 32) != 0;
+#else
+  constexpr bool lab_win = false, lab_nodma = false, lab_nomm = false, lab_nowr = false, lab_nold = false;
+#endif
+  (void)lab_win; (void)lab_nodma; (void)lab_nomm; (void)lab_nowr; (void)lab_nold;
   // XCD-aware 1-D grid.  The dispatcher places block id on XCD id % 8 (speed only, never needed for correctness).  XCD x owns
   // the contiguous M-tile range [x*chunk, (x+1)*chunk) and walks it in order, running the tiles_n output-channel tiles of
   // one M tile back to back: the A operand (halo tile / GEMM rows) is fetched from HBM once and re-read from that XCD's L2
@@ -261,8 +289,10 @@ conv_mfma_kernel(ConvParams p) {
   if (FASTEPI) {
     const bool full = (NTAPS == 9) ? (oy0 + TH <= p.Hout && ox0 + TW <= p.Wout) : (m0 + (long)C::BM <= m_end);
     const bool ok = p.out_f32 == 1 && p.epi == 0 && full && (!p.res || p.res_f32);
-    fast_epi = ok && p.epi_mode == 4;
     res_init = ok && p.epi_mode >= 3 && p.res != nullptr && p.out_scale == 1.0f;      // mode 3: residual as accumulator init + the LDS-staged store epilogue
+    // the register-direct epilogue stores acc + bias as it is: no output scale, every channel of the tile valid, the residual (if any) already in
+    // the accumulators; anything else takes the LDS-staged epilogue
+    fast_epi = ok && p.epi_mode == 4 && p.out_scale == 1.0f && (!p.res || res_init) && (n0 + BN <= p.Cout_valid);
   }
   // first output pixel of this wave's sub-tile i, relative to the tile's first pixel (px_tile0)
   const size_t px_tile0 = (NTAPS == 9) ? ((size_t)img * p.Hout + oy0) * p.Wout : (size_t)m0;
@@ -279,8 +309,9 @@ conv_mfma_kernel(ConvParams p) {
     // in front of the barrier that ends the producers' prologue: the accumulators must not be live across the producers' code (the
     // register allocation is the union of both roles), and the loads fly while the consumers wait for the first operands.
     const unsigned int rs4 = (unsigned int)p.res_C * 4u;
-    const sdm_rsrc rsi = sdm_make_rsrc((const unsigned char*)p.res + px_tile0 * rs4, (unsigned int)(((NTAPS == 9) ? (size_t)TH * p.Wout : (size_t)C::BM) * rs4));
     const unsigned int vr = (unsigned int)(lane & 31) * rs4 + (unsigned int)ch_lane * 4u;
+#ifdef SDM_EMU
+    const sdm_rsrc rsi = sdm_make_rsrc((const unsigned char*)p.res + px_tile0 * rs4, (unsigned int)(((NTAPS == 9) ? (size_t)TH * p.Wout : (size_t)C::BM) * rs4));
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const unsigned int so = sub_px(i) * rs4;
@@ -294,6 +325,43 @@ conv_mfma_kernel(ConvParams p) {
           for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] = q[e];
         }
     }
+#else
+    // The loads are issued through inline asm and waited for HERE, explicitly.  As compiler-visible loads they left "a load into
+    // the accumulators may be pending" in hipcc's wait-count bookkeeping along the (impossible) path that skips the chunk loop, and it
+    // guarded every quad of the epilogue with s_waitcnt vmcnt(31 - q): every consumer wave waited for the COMPLETION of its own stores
+    // inside the epilogue.  Measured (profiles/r04_conv_f8_step_trace.txt, r04_conv_f8_epilogue_ab.txt): removing those waits does not
+    // shorten the epilogue - a wave's buffer_store_dwordx4 issues at the CU's store rate (one per ~65 cycles while all four consumer waves
+    // store: 8 k cycles per 128 KB tile) whether or not anything waits for it - but it removes a false dependence, and the wait costs
+    // nothing here: the next thing a consumer does is the barrier behind which the producers already wait, then MFMAs that need the values.
+    static_assert(!FASTEPI || MT * NTL * 4 == 32, "operand lists of the wait statements below");
+    const sdm_rsrc_raw rqi = sdm_make_rsrc_raw((const unsigned char*)p.res + px_tile0 * rs4, (unsigned int)(((NTAPS == 9) ? (size_t)TH * p.Wout : (size_t)C::BM) * rs4));
+    f32x4 rq[MT][NTL][4];
+    asm volatile("s_nop 4" ::: "memory");          // the descriptor SGPRs were written by v_readfirstlane just before
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const unsigned int so = (unsigned int)__builtin_amdgcn_readfirstlane((int)(sub_px(i) * rs4));
+#pragma unroll
+      for (int j = 0; j < NTL; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const bool ok = (ch_lane + j * 32 + 8 * g) < p.Cout_valid;
+          const unsigned int vo = ok ? vr + (unsigned int)((j * 32 + 8 * g) * 4) : SDM_BUF_INVALID;
+          asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(rq[i][j][g]) : "v"(vo), "s"(rqi), "s"(so) : "memory");
+        }
+    }
+#define SDM_RQ4(i, j) "+v"(rq[i][j][0]), "+v"(rq[i][j][1]), "+v"(rq[i][j][2]), "+v"(rq[i][j][3])
+    asm volatile("s_waitcnt vmcnt(0)" : SDM_RQ4(0, 0), SDM_RQ4(0, 1), SDM_RQ4(1, 0), SDM_RQ4(1, 1) :: "memory");
+    asm volatile("" : SDM_RQ4(2, 0), SDM_RQ4(2, 1), SDM_RQ4(3, 0), SDM_RQ4(3, 1) :: "memory");
+#undef SDM_RQ4
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NTL; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] = rq[i][j][g][e];
+#endif
   }
   };
 
@@ -684,12 +752,13 @@ conv_mfma_kernel(ConvParams p) {
       };
       // fp32 (after the fused GroupNorm / SiLU) -> fp16 high parts (4 planes of 16-B rows: channel group g of the chunk) and the
       // fp8 images of x_lo and x (region behind: sub-planes [x_lo8 ch 0-15 | x_lo8 ch 16-31 | x8 ch 0-15 | x8 ch 16-31] of 16-B rows)
-      auto write_lds_a_f8 = [&](unsigned char* Ad, int i0, int i1, bool nxt = false, const int* npix = nullptr) {        // vectors i0 .. i1-1 of this thread
+      // SRC_NX (a literal at every call site): the raw values come from a_raw, or straight from a_nx
+      auto write_lds_a_f8 = [&](const bool SRC_NX, unsigned char* Ad, int i0, int i1, bool nxt = false, const int* npix = nullptr) {        // vectors i0 .. i1-1 of this thread
         const int g = a_part >> 3;
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
           if (i >= i0 && i < i1 && tid + i * NT < A_VEC) {
-            const f32x4 v0 = __builtin_bit_cast(f32x4, a_raw[i][0]), v1 = __builtin_bit_cast(f32x4, a_raw[i][IN_F32 ? 1 : 0]);
+            const f32x4 v0 = __builtin_bit_cast(f32x4, SRC_NX ? a_nx[i][0] : a_raw[i][0]), v1 = __builtin_bit_cast(f32x4, SRC_NX ? a_nx[i][IN_F32 ? 1 : 0] : a_raw[i][IN_F32 ? 1 : 0]);
             const bool inside = (nxt ? npix[i] : a_pix[i]) >= 0;
             f16x8 vh;
             float xl[8], xx[8];
@@ -771,7 +840,7 @@ conv_mfma_kernel(ConvParams p) {
         const unsigned int cc = (unsigned int)((second ? c0 - p.C0 : c0) + a_part) * es;
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
-          const int px = nxt ? n_pix[i] : a_pix[i];
+          const int px = lab_win ? ((nxt ? n_pix[i] : a_pix[i]) & 63) : (nxt ? n_pix[i] : a_pix[i]);
           const unsigned int off = px >= 0 ? (unsigned int)px * Cs + cc : SDM_BUF_INVALID;
           a_nx[i][0] = sdm_buffer_load16(rs, off, 0);
           if (IN_F32) a_nx[i][IN_F32 ? 1 : 0] = sdm_buffer_load16(rs, off, 16);
@@ -813,7 +882,7 @@ conv_mfma_kernel(ConvParams p) {
           if (1 < nch) dma_step1(1, 1);
           SDM_SCHED_FENCE();
           issue_loads_a(0);
-          write_lds_a_f8(Aring, 0, A_PER);
+          write_lds_a_f8(false, Aring, 0, A_PER);
           SDM_WAIT_VMCNT0();
           if (nch > 1) { issue_loads_nx(32); SDM_SCHED_FENCE(); }
         }
@@ -826,7 +895,7 @@ conv_mfma_kernel(ConvParams p) {
             if (more) take_nx();
             SDM_SCHED_FENCE();
             if (fly) { dma_step1(c + 2, sl); SDM_SCHED_FENCE(); issue_loads_nx((c + 2) * 32); SDM_SCHED_FENCE(); }
-            if (more) write_lds_a_f8(Aring + ((c + 1) & 1) * 2 * C::A_BYTES, 0, A_PER);
+            if (more) write_lds_a_f8(false, Aring + ((c + 1) & 1) * 2 * C::A_BYTES, 0, A_PER);
             if (fly) SDM_WAIT_VMCNT(8); else SDM_WAIT_VMCNT0();
             SDM_WAIT_LGKMCNT0();
             SDM_RAW_BARRIER();
@@ -900,7 +969,7 @@ conv_mfma_kernel(ConvParams p) {
         if (bsrc && p.bias_sel) bsrc += (size_t)p.bias_sel[im] * p.Cout_pad;
         if (tid < BN) tab[tid] = (bsrc && nn0 + tid < p.Cout_pad) ? bsrc[nn0 + tid] : 0.0f;
       };
-      stamp();                          // ev 0: tile start (both roles)
+      stamp(1);                         // tile start (both roles)
       if (role && !pre_done) {          // (a tile prepared by its predecessor skips all of this)
         write_bias_tab(bias_tab, img, n0);
         dma_step(0, 0);
@@ -908,7 +977,7 @@ conv_mfma_kernel(ConvParams p) {
         SDM_SCHED_FENCE();
         issue_loads_a(0);
         issue_gn(0);
-        write_lds_a_f8(Aring, 0, A_PER);
+        write_lds_a_f8(false, Aring, 0, A_PER);
         SDM_WAIT_VMCNT0();
         if (nch > 1) {                  // chunk 1: in flight across the first barrier
           issue_loads_nx(32);
@@ -917,10 +986,10 @@ conv_mfma_kernel(ConvParams p) {
       }
       const int cm = 0;             // (6 * c) % 3 = 0 always: the chunk's first step sits in ring slot 0 (kept for clarity)
       if (role) {
-        stamp();                        // ev 1: prologue done, waiting at the first barrier
         SDM_WAIT_LGKMCNT0();
+        stamp();                        // prologue done, arriving at the first barrier
         SDM_RAW_BARRIER();
-        stamp();                        // ev 2: past the first barrier
+        stamp();                        // past the first barrier
         for (int c = 0; c < nch; ++c) {
           const bool more = c + 1 < nch;
           const bool morex = more || has_next;             // the chunk staged during this one: c + 1, or chunk 0 of the next tile
@@ -931,31 +1000,37 @@ conv_mfma_kernel(ConvParams p) {
             // chunk c+1's raw values arrived during chunk c-1 (every earlier step ended with vmcnt(0) or left only them in flight)
             if (k == 0 && morex) take_nx();
             SDM_SCHED_FENCE();
+            if (!(lab_nodma && t >= 2)) {
             if (t + 2 < nsteps) dma_step(t + 2, mod3(cm + k + 2));
             else if (has_next) dma_step_v(t + 2 - nsteps, mod3(cm + k + 2), n_dma_voff);      // the next tile's first two weight steps (nsteps % 3 == 0: same slots)
+            }
             SDM_SCHED_FENCE();
-            // chunk c+2 - of this tile, or chunk 0 / 1 of the next one: loaded now, transformed one chunk later
+            // chunk c+2 - of this tile, or chunk 0 / 1 of the next one: loaded now, transformed one chunk later.  ALL of a chunk's loads at its
+            // first step: vector-memory operations retire in order and every step waits for its weight DMAs, so whatever is loaded has to land
+            // within two steps wherever it is issued - one load per step (tried: profiles/r04_conv_f8_step_trace.txt) stretches EVERY step to half
+            // the HBM latency (~4.5 k cycles under this load) instead of one step per chunk
             const bool fly_cur = (k == 0) && (c + 2 < nch), fly_nxt = (k == 0) && !fly_cur && has_next;
-            const bool fly = fly_cur || fly_nxt;
-            if (fly_cur) issue_loads_nx((c + 2) * 32);
-            if (fly_nxt) issue_loads_nx((c + 2 - nch) * 32, true);
+            const bool fly = (fly_cur || fly_nxt) && !lab_nold;
+            if (fly_cur && !lab_nold) issue_loads_nx((c + 2) * 32);
+            if (fly_nxt && !lab_nold) issue_loads_nx((c + 2 - nch) * 32, true);
             SDM_SCHED_FENCE();
             // the other A buffer was last read in chunk c-1: one vector of the next chunk's transform (GroupNorm, SiLU, hi / fp8
             // split) per step, so that no step's barrier waits for the producers
-            if (morex) write_lds_a_f8(Aring + ((c + 1) & 1) * 2 * C::A_BYTES, k, k + 1, !more, n_pix);
+            if (morex && !lab_nowr) write_lds_a_f8(false, Aring + ((c + 1) & 1) * 2 * C::A_BYTES, k, k + 1, !more, n_pix);
             if (fly) { if (AFLY == 12) SDM_WAIT_VMCNT(12); else SDM_WAIT_VMCNT(16); }
             else SDM_WAIT_VMCNT0();
             SDM_WAIT_LGKMCNT0();
+            stamp();                    // step t: arriving at its barrier
             SDM_RAW_BARRIER();
+            stamp();                    // step t: released
           }
-          if (c < 4 || c == nch - 1) stamp();            // ev 3..: end of chunks 0-3 and of the last chunk
         }
         pre_done = has_next ? 1 : 0;
       } else {
         acc_init_residual();
-        stamp();                        // ev 1: accumulators initialised, waiting at the first barrier
+        stamp();                        // accumulators initialised, arriving at the first barrier
         SDM_RAW_BARRIER();              // the producers' prologue (same barrier as in their branch)
-        stamp();                        // ev 2: past the first barrier
+        stamp();                        // past the first barrier
         const int sa8 = p.f8_sa, sb8 = p.f8_sb;
         f16x8 fbh[2][3][NTL];         // w_hi fragments of the two 16-channel halves
         i32x8 fb8[3][NTL];            // [w8 | w_lo8] fragments
@@ -993,6 +1068,8 @@ conv_mfma_kernel(ConvParams p) {
             const unsigned char* B2 = Bring + mod3(cm + dx * 2 + 1) * STEP;       // S2 of this column
             // ---- S1: A_hi . w_hi, channels 0-15 then 16-31; the second half's and the fp8 step's B fragments are read underneath ----
             f16x8 fa[2];
+            i32x8 f8a[2];
+            if (!lab_nomm) {
             fa[0] = ld_ah(Ab, 0, 0, dx);
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
@@ -1009,7 +1086,6 @@ conv_mfma_kernel(ConvParams p) {
               }
               SDM_SCHED_FENCE();
             }
-            i32x8 f8a[2];
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
               if (r + 1 < NR) fa[(NR + r + 1) & 1] = ld_ah(Ab, 1, r + 1, dx);
@@ -1026,10 +1102,12 @@ conv_mfma_kernel(ConvParams p) {
               }
               SDM_SCHED_FENCE();
             }
+            }
             SDM_RAW_BARRIER();
             // ---- S2: [x_lo8 | x8] . [w8 | w_lo8]; the w_hi fragments of the next column (or chunk) are read underneath ----
             const bool last = (dx == 2) && !more;
             const unsigned char* Bn = Bring + mod3(cm + dx * 2 + 2) * STEP;
+            if (!lab_nomm) {
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
               if (r + 1 < NR) f8a[(r + 1) & 1] = ld_a8(Ab, r + 1, dx);
@@ -1045,9 +1123,9 @@ conv_mfma_kernel(ConvParams p) {
               }
               SDM_SCHED_FENCE();
             }
+            }
             SDM_RAW_BARRIER();
           }
-          if (c < 4 || c == nch - 1) stamp();            // ev 3..: end of chunks 0-3 and of the last chunk
         }
       }
       }   // NTAPS == 9
@@ -1274,20 +1352,23 @@ conv_mfma_kernel(ConvParams p) {
     const sdm_rsrc rso = sdm_make_rsrc((unsigned char*)p.out + px_tile0 * cs4, (unsigned int)(span * cs4));
     const unsigned int vo = (unsigned int)l31 * cs4 + (unsigned int)(p.out_ch_off + ch_lane) * 4u;
     f32x4 b4[NTL][4];
-    bool okq[NTL][4];
 #pragma unroll
     for (int j = 0; j < NTL; ++j)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        b4[j][g] = *(const f32x4*)(bias_tab + wn * WTN + j * 32 + 8 * g + 4 * hi);
-        okq[j][g] = (ch_lane + j * 32 + 8 * g) < p.Cout_valid;
-      }
+      for (int g = 0; g < 4; ++g) b4[j][g] = *(const f32x4*)(bias_tab + wn * WTN + j * 32 + 8 * g + 4 * hi);
     float s1[NTL][16], s2[NTL][16];
 #pragma unroll
     for (int j = 0; j < NTL; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s1[j][r] = 0.0f; s2[j][r] = 0.0f; }
-    const bool do_store = !(p.ablate & 8), do_stats = p.stats != nullptr;
+#if defined(SDM_CONV_LAB) && !defined(SDM_EMU)
+    const bool do_store = !(p.ablate & 8);
+#else
+    constexpr bool do_store = true;
+#endif
+    const bool do_stats = p.stats != nullptr;
+    // (fast_epi: acc_scale == 1 - F8 layers accumulate in the output's unit -, out_scale == 1, every channel of the tile valid: no
+    // predicates, no scaling, no vector-memory wait)
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const unsigned int so = sub_px(i) * cs4;
@@ -1295,21 +1376,28 @@ conv_mfma_kernel(ConvParams p) {
       for (int j = 0; j < NTL; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+          // the bias is added in place and the quad stored from the accumulator registers themselves (no temporary quad whose rewrite could
+          // run into the store-data hazard below; timing is unchanged: the 32 stores issue at the CU's store rate either way)
           f32x4 v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = ((SPLIT ? acc[i][j][4 * g + e] * p.acc_scale : acc[i][j][4 * g + e]) + b4[j][g][e]) * p.out_scale;
-          if (okq[j][g]) {
-            if (do_store) sdm_buffer_store16(__builtin_bit_cast(u32x4, v), rso, vo + (unsigned int)((j * 32 + 8 * g) * 4), so);
-            if (do_stats) {
+          for (int e = 0; e < 4; ++e) { acc[i][j][4 * g + e] += b4[j][g][e]; v[e] = acc[i][j][4 * g + e]; }
+          if (do_store) sdm_buffer_store16(__builtin_bit_cast(u32x4, v), rso, vo + (unsigned int)((j * 32 + 8 * g) * 4), so);
+          if (do_stats) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) { s1[j][4 * g + e] += v[e]; s2[j][4 * g + e] += v[e] * v[e]; }
-            }
-            // the store's data registers stay untouched until here: on gfx950 a v_pk_* that rewrites them two instructions behind a
-            // buffer_store_dwordx4 changes what lanes 12-15 of each 16 store (profiles/r03_conv_epilogue_branchfree_ab.txt)
-            SDM_PIN_STORE_DATA(v);
+            for (int e = 0; e < 4; ++e) { s1[j][4 * g + e] += v[e]; s2[j][4 * g + e] += v[e] * v[e]; }
           }
+          // the store's data registers stay untouched until here: on gfx950 a v_pk_* that rewrites them two instructions behind a
+          // buffer_store_dwordx4 changes what lanes 12-15 of each 16 store (profiles/r03_conv_epilogue_branchfree_ab.txt)
+          SDM_PIN_STORE_DATA(v);
         }
+      stamp();                   // (traced builds) sub-tile i issued
     }
+#if !defined(SDM_EMU) && defined(__HIP_DEVICE_COMPILE__)      // (device pass only: a 512-bit "v" operand is not valid x86 inline asm)
+    // the biased accumulators stay live to this point, so that hipcc really keeps every store's data in its own registers
+    asm volatile("" :: "v"(acc[0][0]), "v"(acc[0][NTL - 1]), "v"(acc[MT > 1 ? 1 : 0][0]), "v"(acc[MT > 1 ? 1 : 0][NTL - 1]),
+                 "v"(acc[MT > 2 ? 2 : 0][0]), "v"(acc[MT > 2 ? 2 : 0][NTL - 1]), "v"(acc[MT > 3 ? 3 : 0][0]), "v"(acc[MT > 3 ? 3 : 0][NTL - 1]));
+    static_assert(!FASTEPI || (MT <= 4 && NTL <= 2), "operand list above");
+#endif
     if (do_stats) {
       // per-channel sums over this wave's 128 pixels: in-lane over the 4 sub-tiles (above), then over the 16 lanes of each DPP row;
       // the two rows of a lane half meet in a wave-private LDS scratch (the second A buffer is free during the epilogue), from which
@@ -1327,7 +1415,7 @@ conv_mfma_kernel(ConvParams p) {
           }
         }
       SDM_WAVE_SYNC();
-      if (lane < WTN && (n0 + wn * WTN + lane) < p.Cout_valid) {
+      if (lane < WTN) {
         const f32x2 a = *(const f32x2*)(sc + lane * 2), b = *(const f32x2*)(sc + (WTN + lane) * 2);
         f32x2 o2;
         o2[0] = a[0] + b[0]; o2[1] = a[1] + b[1];
@@ -1556,6 +1644,15 @@ conv_mfma_kernel(ConvParams p) {
         if (v < p.vgrid) run_tile(std::integral_constant<int, 0>{}, v, k & 1, (k + 1 < p.tpb) && (v + (int)gridDim.x < p.vgrid));
       }
     }
+#if defined(SDM_CONV_TRACE) && !defined(SDM_EMU)
+    if (NTAPS == 9 && p.trace && (int)blockIdx.x >= p.trace_b0 && (int)blockIdx.x < p.trace_b0 + 16 && (threadIdx.x & (NT - 1)) == 0) {      // the parked stamps of this role -> global memory, once
+      const int r = (int)threadIdx.x / NT;
+      const unsigned int* tb = (const unsigned int*)(smem + C::TILE_BYTES + 2 * BN * 4) + r * 64;
+      unsigned int* dst = p.trace + ((size_t)((int)blockIdx.x - p.trace_b0) * 2 + r) * 384;
+      for (int i = 0; i < tr_n && i < 383; ++i) dst[i] = tb[i];
+      dst[383] = (unsigned int)tr_n;
+    }
+#endif
   } else {
     run_tile(std::integral_constant<int, -1>{}, (int)blockIdx.x, 0, false);
   }

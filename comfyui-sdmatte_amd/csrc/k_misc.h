@@ -148,7 +148,9 @@ __global__ void refine_compose_kernel(const float* __restrict__ img, const float
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npix) return;
   float a = alpha[i];
-  const float t = tri[i];
+  // the trimap may be smaller than the image when nothing below reads it (mask_refine off, alpha_only / matted_rgba: the reference
+  // indexes the alpha with the trimap only in mask_refine and matted_rgb, sdmatte_nodes.py:365-394) - then it is not loaded at all
+  const float t = (refine || mode == 2) ? tri[i] : 0.0f;
   if (refine) {
     const bool fg = t > c, bg = t < one_minus_c, unk = !(fg || bg);
     if (bg) a = 0.0f;

@@ -83,6 +83,43 @@ static inline void dev_use(int device) {
 static inline size_t rupz(size_t a, size_t b) { return ((a + b - 1) / b) * b; }
 
 // ------------------------------------------------------------------------------------------------
+// kernel-selection options.  The product reads NO environment variable on any path: every choice below has ONE default, and the only
+// way to change one is the C ABI (sdm_set_option; tests and the A/B tools under tools/ use it).  sdm_kernel_counts reports which
+// variants actually ran, so that a test can assert the kernel it meant to check.
+// ------------------------------------------------------------------------------------------------
+struct OptEntry { const char* name; int value; int def; const char* what; };
+static OptEntry g_opts[] = {
+  {"conv_f8", 1, 1, "residual terms of the wide split-precision 3x3 convs on fp8 MFMAs (read when a model is built)"},
+  {"gemm_f8", 1, 1, "the same for Linear / 1x1 layers with K >= gemm_f8_min_k (read when a model is built)"},
+  {"gemm_f8_min_k", 1024, 1024, "smallest K of a GEMM that takes the 8-wave fp8-residual kernel"},
+  {"conv_epi", 4, 4, "F8 kernels' epilogue: 4 register-direct stores + residual as accumulator init, 3 residual init only, 0 LDS-staged"},
+  {"conv_xtile", 1, 1, "F8 3x3: cross-tile prefetch by the producer waves"},
+  {"conv_f8_tpb", 0, 0, "F8: tiles per block (0 = by queue depth)"},
+  {"conv_dma", 1, 1, "3x3 stride-1 256x128 tile: weights by LDS-DMA"},
+  {"conv_dma_all", 0, 0, "keep a stage-ordered weight copy for every wide 3x3 layer, not only the split-precision ones (read when a model is built)"},
+  {"conv_pc", -1, -1, "producer / consumer form of the split-precision DMA kernel: -1 by channel count, 0 off, 1 on"},
+  {"conv_pc_min_cin", 256, 256, "conv_pc = -1: smallest Cin that takes the producer / consumer form"},
+  {"conv_db", 0, 0, "512x128 double-buffered tile where the queue is deep"},
+  {"force_cfg0", 0, 0, "always the 256x128 tile for 3x3 stride 1 (tests: fused GroupNorm at tiny sizes)"},
+  {"no_gn_fuse", 0, 0, "never fuse the GroupNorm apply into the consuming conv"},
+  {"split_lds_pad", 0, 0, "extra dynamic LDS of the register-staged split kernels (forces one block per CU)"},
+  {"attn_f8", 1, 1, "Q.K^T residual terms of the d=64 split-precision attention on fp8 MFMAs"},
+  {"attn_dense", 0, 0, "walk every key tile of the trimap-biased self-attention"},
+  {"attn_pv_split", 0, 0, "residual terms of P.V too (fully split attention; tests)"},
+  {"attn_nw", 0, 0, "waves per d=64 attention block: 0 by launch size, 4, 8"},
+  {"attn_pipe", 1, 1, "8-wave split-precision d=64 attention: two-tile software pipeline"},
+  {"attn_pipe4", 1, 1, "the same pipeline for the 4-wave launches (two K / three V^T buffers)"},
+  {"precise_mask", -1, -1, "stages in split precision (-1 = the config's own mask; per-stage attribution experiments; read at sdm_create)"},
+};
+static OptEntry* opt_find(const char* name) {
+  for (auto& o : g_opts) if (name && strcmp(o.name, name) == 0) return &o;
+  return nullptr;
+}
+static int opt(const char* name) { OptEntry* o = opt_find(name); return o ? o->value : 0; }
+static std::map<std::string, long> g_kernel_counts;
+static void count_kernel(const char* name) { g_kernel_counts[name] += 1; }
+
+// ------------------------------------------------------------------------------------------------
 // conv tile configurations
 // ------------------------------------------------------------------------------------------------
 template <int NTAPS, int STRIDE, int TH, int TW, int BN, int KC, int WM, int WN, int DB = 0, int GNOK = 0>
@@ -99,7 +136,7 @@ static void launch_conv_t(const ConvParams& p_in, void* stream) {
   if constexpr (!DB) {
     if (p.w_lo) {                  // precise mode: split-fp16 operands (fp32 activations only)
       using CS = ConvCfg<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN, 0, 1>;
-      static const size_t lds_pad = getenv("SDM_SPLIT_LDS_PAD") ? (size_t)atoi(getenv("SDM_SPLIT_LDS_PAD")) : 0;   // experiment hook: extra dynamic LDS (forces 1 block per CU)
+      const size_t lds_pad = (size_t)opt("split_lds_pad");   // experiment option: extra dynamic LDS (forces 1 block per CU)
       if (GNOK && p.gn_scale) {
         auto k = conv_mfma_kernel<NTAPS, STRIDE, TH, TW, BN, KC, WM, WN, 1, 0, GNOK, 1>;
         SDM_SET_SMEM(k, 160 * 1024);
@@ -156,8 +193,8 @@ static int conv_pick_cfg(int ntaps, int stride, const ConvParams& p) {
   const int n = conv_num_cfgs(ntaps, stride);
   long best_blocks = -1;
   int best = -1;
-  if (ntaps == 9 && stride == 1 && getenv("SDM_FORCE_CFG0") && conv_cfg_ok(t[0], p)) return 0;   // test hook: exercise the 256x128 tile (+ fused GroupNorm) at tiny sizes
-  static const bool use_db = getenv("SDM_CONV_DB") && getenv("SDM_CONV_DB")[0] == '1';   // A/B hook for the 512x128 double-buffered tile
+  if (ntaps == 9 && stride == 1 && opt("force_cfg0") && conv_cfg_ok(t[0], p)) return 0;   // test option: exercise the 256x128 tile (+ fused GroupNorm) at tiny sizes
+  const bool use_db = opt("conv_db") != 0;   // A/B option for the 512x128 double-buffered tile
   for (int i = 0; i < n; ++i) {
     if (!conv_cfg_ok(t[i], p)) continue;
     if (ntaps == 9 && stride == 1 && i >= 3) continue;          // cfg 3 / 4: variants of cfg 0, substituted below
@@ -206,8 +243,7 @@ static int conv_f8_tiles_per_block(long tiles) {
 #ifdef SDM_EMU
   return tiles >= 6 ? 3 : (tiles >= 2 ? 2 : 1);
 #else
-  const char* o = getenv("SDM_CONV_F8_TPB");
-  if (o && o[0] >= '1' && o[0] <= '8') return o[0] - '0';
+  if (opt("conv_f8_tpb") >= 1 && opt("conv_f8_tpb") <= 8) return opt("conv_f8_tpb");
   static int cus = 0;
   if (!cus) {
     int dev = 0;
@@ -249,12 +285,13 @@ static void launch_conv_dma(const ConvParams& p_in, void* stream) {
     p.tpb = conv_f8_tiles_per_block((long)grid.x);                                                           \
     unsigned pg = (grid.x + p.tpb - 1) / p.tpb;                                                              \
     pg = (pg + 7) & ~7u;              /* block id % 8 = XCD: the stride between a block's tiles stays a multiple of 8 */ \
-    SDM_LAUNCH(k, dim3(pg, 1, 1), dim3(CD::LAUNCH_THREADS), (size_t)CD::SMEM + 2 * 128 * 4, stream, p);     /* + two bias tables */ \
+    SDM_LAUNCH(k, dim3(pg, 1, 1), dim3(CD::LAUNCH_THREADS), (size_t)CD::SMEM + CD::F8_EXTRA, stream, p);     /* + two bias tables (k_conv.h) */ \
   } while (0)
+    count_kernel(gn ? "conv3x3_f8<gn>" : "conv3x3_f8");
     if (gn) SDM_F8_CASE(1); else SDM_F8_CASE(0);
 #undef SDM_F8_CASE
   }
-  else if (split && p.pc) { if (gn) SDM_DMA_CASE(1, 1, 1, 1); else SDM_DMA_CASE(1, 0, 1, 1); }
+  else if (split && p.pc) { count_kernel("conv3x3_pc"); if (gn) SDM_DMA_CASE(1, 1, 1, 1); else SDM_DMA_CASE(1, 0, 1, 1); }
   else if (split) { if (gn) SDM_DMA_CASE(1, 1, 1, 0); else SDM_DMA_CASE(1, 0, 1, 0); }
   else if (p.in_f32) { if (gn) SDM_DMA_CASE(1, 1, 0, 0); else SDM_DMA_CASE(1, 0, 0, 0); }
   else { if (gn) SDM_DMA_CASE(0, 1, 0, 0); else SDM_DMA_CASE(0, 0, 0, 0); }
@@ -274,9 +311,10 @@ static void launch_gemm_f8(const ConvParams& p_in, void* stream) {
   p.tpb = conv_f8_tiles_per_block((long)vg);
   unsigned pg = (vg + p.tpb - 1) / p.tpb;
   pg = (pg + 7) & ~7u;
+  count_kernel("gemm_f8");
   auto k = conv_mfma_kernel<1, 1, 8, 32, 128, 32, 2, 2, 1, 0, 0, 1, 1, 1, 1>;
   SDM_SET_SMEM(k, 160 * 1024);
-  SDM_LAUNCH(k, dim3(pg, 1, 1), dim3(CD::LAUNCH_THREADS), (size_t)CD::SMEM + 2 * 128 * 4, stream, p);      // + two bias tables
+  SDM_LAUNCH(k, dim3(pg, 1, 1), dim3(CD::LAUNCH_THREADS), (size_t)CD::SMEM + CD::F8_EXTRA, stream, p);      // + two bias tables
 }
 
 static int launch_conv(int ntaps, int stride, int cfg, const ConvParams& p, void* stream) {
@@ -317,41 +355,26 @@ static int launch_conv(int ntaps, int stride, int cfg, const ConvParams& p, void
 // ------------------------------------------------------------------------------------------------
 // Residual terms of the split-precision 3x3 convs on fp8 operands (k_conv.h, F8): default on; SDM_CONV_F8=0 keeps them on fp16
 // (the round-2 "fp16x3" arithmetic everywhere).  Read when a model is built: the weight copy is packed for one of the two.
-static bool conv_f8_enabled() {
-  const char* v = getenv("SDM_CONV_F8");
-  return !(v && v[0] == '0');
-}
+static bool conv_f8_enabled() { return opt("conv_f8") != 0; }
 
-static bool gemm_f8_enabled() {
-  const char* v = getenv("SDM_GEMM_F8");
-  return !(v && v[0] == '0');
-}
+static bool gemm_f8_enabled() { return opt("gemm_f8") != 0; }
 
 // epilogue of the F8 kernels (ConvParams::epi_mode): 4 = register-direct 16-byte stores + residual as the accumulators' initial value
 // (default), 3 = LDS-staged stores + residual as initial value, 0 = LDS-staged stores, residual added in the epilogue.  Read per launch:
 // A/B hook.
 static int conv_epi_mode() {
-  const char* v = getenv("SDM_CONV_EPI");
-  return (v && (v[0] == '0' || v[0] == '3' || v[0] == '4')) ? v[0] - '0' : 4;
+  const int v = opt("conv_epi");
+  return (v == 0 || v == 3 || v == 4) ? v : 4;
 }
 
 // Residual terms of Q.K^T in the split-precision attention cores on fp8 MFMAs (k_attn.h, PREC = 3; q / k arrive as fp16 + e5m2 pair planes):
 // default on; SDM_ATTN_F8=0 keeps them on fp16 MFMAs (PREC = 2, fp16 hi | lo planes).  Read per forward: A/B hook.
-static bool attn_f8_enabled() {
-  const char* v = getenv("SDM_ATTN_F8");
-  return !(v && v[0] == '0');
-}
+static bool attn_f8_enabled() { return opt("attn_f8") != 0; }
 
 // F8 3x3 kernels: cross-tile prefetch by the producer waves (k_conv.h); SDM_CONV_XTILE=0 disables.  Read per launch: A/B hook.
-static bool conv_xtile_enabled() {
-  const char* v = getenv("SDM_CONV_XTILE");
-  return !(v && v[0] == '0');
-}
+static bool conv_xtile_enabled() { return opt("conv_xtile") != 0; }
 
-static int gemm_f8_min_k() {
-  const char* v = getenv("SDM_GEMM_F8_MIN_K");
-  return v ? atoi(v) : 1024;
-}
+static int gemm_f8_min_k() { return opt("gemm_f8_min_k"); }
 
 struct ConvL {
   std::string name;
@@ -531,7 +554,7 @@ struct Builder {
     if (L.split) { L.w_exp = kSplitWeightExp; L.wlo_off = woff; woff += rupz((size_t)L.Cin_pad * ntaps * L.Cout_pad * 2, 256); }
     // stage-ordered copy for the DMA-weight kernel: split-precision layers only (measured +4..6 % there; neutral with fp16 operands,
     // where the register-staged kernel stays; SDM_CONV_DMA_ALL=1 builds the copy for every wide 3x3 layer)
-    static const bool dma_all = getenv("SDM_CONV_DMA_ALL") != nullptr;
+    const bool dma_all = opt("conv_dma_all") != 0;
     if (ntaps == 9 && L.Cout_pad >= 128 && !geglu && (L.split || dma_all)) {
       L.wdma_bytes = (size_t)L.Cin_pad * 9 * L.Cout_pad * 2 * (L.split ? 2 : 1);
       L.wdma_off = doff; doff += rupz(L.wdma_bytes, 256);
@@ -892,12 +915,11 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
     p.stats = a.out->stats;
   }
   // weights by LDS-DMA (256x128 tile, 3x3 stride 1): the layer keeps a stage-ordered copy of its weights for that kernel
-  static const bool dma_off = getenv("SDM_CONV_DMA") && getenv("SDM_CONV_DMA")[0] == '0';      // A/B hook
+  const bool dma_off = opt("conv_dma") == 0;      // A/B option
   if (!dma_off && L.ntaps == 9 && a.stride == 1 && cfg == 0 && L.w_dma && (!L.split || p.in_f32)) p.w_dma = L.w_dma;
   {   // producer / consumer form of the split-precision DMA kernel (k_conv.h, PC): SDM_CONV_PC=0 / 1 forces it off / on
-    const char* pc_env = getenv("SDM_CONV_PC");                  // read per launch: tests toggle it
-    const int pc_min_cin = getenv("SDM_CONV_PC_MIN_CIN") ? atoi(getenv("SDM_CONV_PC_MIN_CIN")) : 256;
-    if (p.w_dma && L.split) p.pc = pc_env ? (pc_env[0] == '1') : (L.Cin_pad >= pc_min_cin);
+    const int pc_opt = opt("conv_pc"), pc_min_cin = opt("conv_pc_min_cin");
+    if (p.w_dma && L.split) p.pc = pc_opt >= 0 ? (pc_opt == 1) : (L.Cin_pad >= pc_min_cin);
     if (p.w_dma && L.f8) {
       // the fp8-residual kernel stages 32-channel chunks: a channel concat that does not split on a chunk boundary takes the
       // register-staged split kernel (K16 weights) instead
@@ -1029,11 +1051,13 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
   if (!(D == 64 || (D == 512 && heads == 1))) SDM_FAIL(e, SDM_ERR_INVALID, "attention: unsupported head dim %d x %d heads", D, heads);
   if ((ldq | ldk | ldv | ldo) % 8) SDM_FAIL(e, SDM_ERR_INVALID, "attention: row strides must be multiples of 8");
   if (ap.prec && D != 64) SDM_FAIL(e, SDM_ERR_INVALID, "attention: the split-precision variant exists for head dim 64 only");
+  // the fp8-pair form cannot rescale Q inside the kernel (its pair plane is produced pre-scaled, as the engine always does)
+  if (ap.prec == 2 && !q_prescaled) SDM_FAIL(e, SDM_ERR_INVALID, "attention: the fp8-residual form takes pre-scaled queries");
   const int ldvt = rup(Lk, 64);
   T vt = talloc(e, (ap.prec ? 2 : 1) * B, heads, D, ldvt, 0);      // precise: V^T_hi planes of all images, then V^T_lo
   // key tiles whose bias underflows the softmax are skipped (exact, AttnParams::tiles); the engine passes one list per U-Net
   // level, the stand-alone operator entry builds it here.  SDM_ATTN_DENSE=1 walks every tile (A/B hook).
-  const bool dense_attn = getenv("SDM_ATTN_DENSE") != nullptr;
+  const bool dense_attn = opt("attn_dense") != 0;
   const int ntiles64 = sdm_cdiv(Lk, 64);
   T tl_own;
   const bool own_list = (D == 64) && bias_l2 && !tiles && !dense_attn;
@@ -1050,8 +1074,7 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
                vt_hs, ldvt, Lk, D);
     // split-precision variant: Q.K^T on split operands, P.V on plain fp16 (k_attn.h, PREC = 2) unless SDM_ATTN_PV_SPLIT=1 asks for
     // the residual terms of P.V too (PREC = 1: then V^T_lo is needed as well)
-    const char* pvs_env = getenv("SDM_ATTN_PV_SPLIT");
-    const bool pv_split = ap.prec == 1 && pvs_env && pvs_env[0] == '1';
+    const bool pv_split = ap.prec == 1 && opt("attn_pv_split") != 0;
     if (pv_split)
       SDM_LAUNCH(transpose_v_kernel, dim3(ldvt / 64, heads * (D / 64), B), dim3(256), 0, e->stream, v + ap.v_lo, (long)Lk * ldv, ldv,
                  (half_t*)vt.p + (size_t)B * vt_bs, vt_bs, vt_hs, ldvt, Lk, D);
@@ -1088,30 +1111,29 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
       // 8-wave blocks (256 queries share every K / V^T tile: half the L2 / Infinity-Cache traffic and LDS staging per MFMA) only
       // where they measured faster: the split-precision variant with >= 4 such blocks per CU (B=4 h=5 L=16384: 4.01 vs 4.25 ms;
       // h=10 Lq=4096: 2.39 vs 2.24 ms, i.e. slower; the fp16 variant is neutral to -10 %) - profiles/r02_ablate_attn_nw8.txt
-      const char* force_nw = getenv("SDM_ATTN_NW");                 // A/B / test hook: "4" or "8" (read per launch)
-      const bool nw8 = force_nw ? (force_nw[0] == '8') : (ap.prec && (long)B * heads * sdm_cdiv(Lq, 256) >= 1024);
+      const int force_nw = opt("attn_nw");                          // A/B / test option: 4 or 8
+      const bool nw8 = force_nw ? (force_nw == 8) : (ap.prec && (long)B * heads * sdm_cdiv(Lq, 256) >= 1024);
       const int qrows = nw8 ? 256 : 128;
       p.batch = B; p.heads = heads; p.nq_blocks = sdm_cdiv(Lq, qrows); p.q_chunks = 8;     // B*heads*8 units: always a multiple of 8
       const int qb = sdm_cdiv(p.nq_blocks, p.q_chunks);
       const unsigned nblk = (unsigned)(B * heads * p.q_chunks * qb);                         // 1-D grid, XCD-aware mapping in the kernel
       if (ap.prec == 2) {
         // 8-wave blocks with fp32 output (the engine's level-0 attentions): the two-tile software pipeline of the kernel (k_attn.h,
-        // attn_d64_pipe_kernel: same arithmetic, bit-identical results, -9 % kernel time); SDM_ATTN_PIPE=0 selects the plain form.  A/B hook.
-        const char* pipe_env = getenv("SDM_ATTN_PIPE");
-        const char* pipe4_env = getenv("SDM_ATTN_PIPE4");      // the same pipeline for the 4-wave launches: built, emulator-checked, not yet measured (off)
-        if (nw8 && !(pipe_env && pipe_env[0] == '0') && p.o_f32) { auto kp = attn_d64_pipe_kernel<8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(512), ATTN64PIPE_SMEM, e->stream, p); }
-        else if (!nw8 && pipe4_env && pipe4_env[0] == '1' && p.o_f32) { auto kp = attn_d64_pipe_kernel<4>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(256), ATTN64PIPE4_SMEM, e->stream, p); }
-        else if (nw8) { auto kp = attn_d64_kernel<1, 3, 8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(512), ATTN64P_SMEM, e->stream, p); }
-        else { auto kp = attn_d64_kernel<1, 3, 4>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(256), ATTN64P_SMEM, e->stream, p); }
+        // attn_d64_pipe_kernel: same arithmetic, bit-identical results, -9 % kernel time); option attn_pipe = 0 selects the plain form.
+        const bool pipe8 = opt("attn_pipe") != 0, pipe4 = opt("attn_pipe4") != 0;
+        if (nw8 && pipe8 && p.o_f32) { count_kernel("attn_d64_pipe<8>"); auto kp = attn_d64_pipe_kernel<8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(512), ATTN64PIPE_SMEM, e->stream, p); }
+        else if (!nw8 && pipe4 && p.o_f32) { count_kernel("attn_d64_pipe<4>"); auto kp = attn_d64_pipe_kernel<4>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(256), ATTN64PIPE4_SMEM, e->stream, p); }
+        else if (nw8) { count_kernel("attn_d64<prec3,8>"); auto kp = attn_d64_kernel<1, 3, 8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(512), ATTN64P_SMEM, e->stream, p); }
+        else { count_kernel("attn_d64<prec3,4>"); auto kp = attn_d64_kernel<1, 3, 4>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(256), ATTN64P_SMEM, e->stream, p); }
       } else if (ap.prec && pv_split) {
-        if (nw8) { auto kp = attn_d64_kernel<1, 1, 8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(512), ATTN64P_SMEM, e->stream, p); }
-        else { auto kp = attn_d64_kernel<1, 1, 4>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(256), ATTN64P_SMEM, e->stream, p); }
+        if (nw8) { count_kernel("attn_d64<prec1,8>"); auto kp = attn_d64_kernel<1, 1, 8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(512), ATTN64P_SMEM, e->stream, p); }
+        else { count_kernel("attn_d64<prec1,4>"); auto kp = attn_d64_kernel<1, 1, 4>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(256), ATTN64P_SMEM, e->stream, p); }
       } else if (ap.prec) {
-        if (nw8) { auto kp = attn_d64_kernel<1, 2, 8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(512), ATTN64P_SMEM, e->stream, p); }
-        else { auto kp = attn_d64_kernel<1, 2, 4>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(256), ATTN64P_SMEM, e->stream, p); }
+        if (nw8) { count_kernel("attn_d64<prec2,8>"); auto kp = attn_d64_kernel<1, 2, 8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(512), ATTN64P_SMEM, e->stream, p); }
+        else { count_kernel("attn_d64<prec2,4>"); auto kp = attn_d64_kernel<1, 2, 4>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(256), ATTN64P_SMEM, e->stream, p); }
       } else {
-        if (nw8) { auto kf = attn_d64_kernel<1, 0, 8>; SDM_SET_SMEM(kf, 160 * 1024); SDM_LAUNCH(kf, dim3(nblk, 1, 1), dim3(512), ATTN64P_SMEM, e->stream, p); }
-        else { SDM_LAUNCH((attn_d64_kernel<1, 0, 4>), dim3(nblk, 1, 1), dim3(256), ATTN64_SMEM, e->stream, p); }
+        if (nw8) { count_kernel("attn_d64<fp16,8>"); auto kf = attn_d64_kernel<1, 0, 8>; SDM_SET_SMEM(kf, 160 * 1024); SDM_LAUNCH(kf, dim3(nblk, 1, 1), dim3(512), ATTN64P_SMEM, e->stream, p); }
+        else { count_kernel("attn_d64<fp16,4>"); SDM_LAUNCH((attn_d64_kernel<1, 0, 4>), dim3(nblk, 1, 1), dim3(256), ATTN64_SMEM, e->stream, p); }
       }
       prof_end(e);
     } else {
@@ -1145,7 +1167,7 @@ static int conv_simple(sdm_ctx* e, int layer, const T& in, T* out, int Cout_stor
 
 // Would op_conv pick tile cfg 0 (the one that has the fused-GroupNorm variant) for this 3x3 stride-1 conv?
 static bool conv_can_fuse_gn(sdm_ctx* e, const ConvL& L, const T& x, const T* x2) {
-  static const bool off = getenv("SDM_NO_GN_FUSE") != nullptr;        // A/B hook
+  const bool off = opt("no_gn_fuse") != 0;        // A/B option
   if (off || L.ntaps != 9) return false;
   const int Cin = x.C + (x2 ? x2->C : 0);
   if (Cin > 1024 || Cin != L.Cin_pad) return false;
@@ -1231,7 +1253,7 @@ static int vae_attention(sdm_ctx* e, const VaeAttnB& a, const T& x, T* out) {
   // plane format of q | k | v: fp16 hi | lo (the logit scale is applied to Q inside the kernel here - it is not folded into these
   // weights - which the fp8 pair planes do not allow); V needs no low-part plane unless the fully split P.V form is requested
   const int pf = pa ? 2 : 0;
-  const bool need_vlo = pf == 2 && getenv("SDM_ATTN_PV_SPLIT") && getenv("SDM_ATTN_PV_SPLIT")[0] == '1';
+  const bool need_vlo = pf == 2 && opt("attn_pv_split") != 0;
   TRY(linear(e, a.qkv, hn, &qkv, 3 * a.C, pf, nullptr, false, need_vlo ? -1 : 2 * a.C));
   tfree(e, hn);
   ao = talloc(e, x.N, x.H, x.W, a.C, e->act_f32);
@@ -1259,7 +1281,7 @@ static int transformer(sdm_ctx* e, const TfB& t, const T& x, const T& uin, const
   TRY(op_ln(e, e->norms[t.ln1], h, e->cfg.unet_ln_eps, &n));
   const int pa = (e->cfg.precise_mask & SDM_PRECISE_UNET_ATTN) ? 1 : 0;      // split-precision attention cores: q|k|v as hi|lo planes
   const int pf = pa ? (attn_f8_enabled() ? 3 : 2) : 0;         // plane format of q | k | v; SDM_ATTN_PV_SPLIT=1 (fully split P.V, test hook) needs V_lo too
-  const bool need_vlo = pf == 2 && getenv("SDM_ATTN_PV_SPLIT") && getenv("SDM_ATTN_PV_SPLIT")[0] == '1';
+  const bool need_vlo = pf == 2 && opt("attn_pv_split") != 0;
   TRY(linear(e, t.qkv1, n, &qkv, 3 * C, pf, nullptr, false, need_vlo ? -1 : 2 * C));
   tfree(e, n);
   ao = talloc(e, x.N, x.H, x.W, C, e->act_f32);
@@ -1748,7 +1770,7 @@ int sdm_create(sdm_ctx** out, int device_id, const sdm_config* cfg) {
   if (cfg) e->cfg = *cfg; else sdm_default_config(&e->cfg);
   if (e->cfg.point_embeddings_input_dim <= 0) e->cfg.point_embeddings_input_dim = 1680;
   e->cfg.precise_mask &= SDM_PRECISE_ALL;
-  if (const char* pm = getenv("SDM_PRECISE_MASK")) e->cfg.precise_mask = atoi(pm) & SDM_PRECISE_ALL;      // experiment hook (per-stage attribution)
+  if (opt("precise_mask") >= 0) e->cfg.precise_mask = opt("precise_mask") & SDM_PRECISE_ALL;      // experiment option (per-stage attribution)
   e->act_f32 = e->cfg.precise_mask ? 1 : 0;
   if (e->act_f32) e->cfg.stream_f32 = 1;
   e->device = device_id;
@@ -2119,6 +2141,43 @@ int sdm_release_memory(sdm_ctx* e) {
   if (e->stage) { dev_free(e->stage); e->stage = nullptr; e->stage_bytes = 0; }
   return SDM_OK;
 }
+int sdm_set_option(const char* name, int value) {
+  OptEntry* o = opt_find(name);
+  if (!o) return SDM_ERR_INVALID;
+  o->value = value;
+  return SDM_OK;
+}
+
+int sdm_get_option(const char* name, int* value) {
+  OptEntry* o = opt_find(name);
+  if (!o || !value) return SDM_ERR_INVALID;
+  *value = o->value;
+  return SDM_OK;
+}
+
+void sdm_reset_options(void) {
+  for (auto& o : g_opts) o.value = o.def;
+}
+
+const char* sdm_option_name(int i) {
+  return (i >= 0 && i < (int)(sizeof(g_opts) / sizeof(g_opts[0]))) ? g_opts[i].name : nullptr;
+}
+
+const char* sdm_option_help(int i) {
+  return (i >= 0 && i < (int)(sizeof(g_opts) / sizeof(g_opts[0]))) ? g_opts[i].what : nullptr;
+}
+
+int sdm_kernel_counts(char* buf, int cap) {
+  std::string out;
+  for (auto& kv : g_kernel_counts) { out += kv.first; out += "="; out += std::to_string(kv.second); out += ";"; }
+  if (buf && cap > 0) { const int n = (int)out.size() < cap - 1 ? (int)out.size() : cap - 1; memcpy(buf, out.data(), (size_t)n); buf[n] = 0; }
+  return (int)out.size();
+}
+
+void sdm_kernel_counts_reset(void) { g_kernel_counts.clear(); }
+
+int64_t sdm_weight_bytes(sdm_ctx* e) { return e ? (int64_t)e->warena_bytes : 0; }
+
 int64_t sdm_resident_bytes(sdm_ctx* e) {
   return e ? (int64_t)(e->warena_bytes + e->arena_bytes + e->io_in_bytes + e->io_out_bytes + e->stage_bytes) : 0;
 }
@@ -2356,7 +2415,7 @@ float sdm_bench_conv(sdm_ctx* e, int N, int H, int W, int Cin, int Cout, int nta
   if (resf) { p.res = resb; p.res_f32 = 1; p.res_C = L.Cout_pad; }
   if (statf) p.stats = (float*)statb;
   void* wdm = nullptr;
-  static const bool bench_dma_off = getenv("SDM_CONV_DMA") && getenv("SDM_CONV_DMA")[0] == '0';
+  const bool bench_dma_off = opt("conv_dma") == 0;
   if (!bench_dma_off && ntaps == 9 && stride == 1 && L.Cout_pad >= 128) {
     const size_t nb = wbytes * (split ? 2 : 1);
     if (dev_malloc(&wdm, nb)) return -2.f;
@@ -2376,25 +2435,25 @@ float sdm_bench_conv(sdm_ctx* e, int N, int H, int W, int Cin, int Cout, int nta
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   launch_conv(ntaps, stride, cfg, p, e->stream);
-  if (ablate & 256) {      // one traced launch of the F8 3x3 kernel: shader-clock stamps of the first blocks (ConvParams::trace) -> stderr
+  if (ablate & 256) {      // one traced launch of the F8 3x3 kernel (-DSDM_CONV_TRACE builds): the LDS-parked shader-clock stamps of the first 16 blocks -> stderr
     void* tr = nullptr;
-    const size_t tb = (size_t)8 * 2 * 8 * 16 * 8;
+    const size_t tb = (size_t)16 * 2 * 384 * 4;
     if (dev_malloc(&tr, tb) == 0) {
       dev_memset(tr, 0, tb, e->stream);
-      ConvParams pt = p; pt.trace = (unsigned long long*)tr; pt.ablate = ablate & 255;
+      ConvParams pt = p; pt.trace = (unsigned int*)tr; pt.ablate = ablate & 255; pt.trace_skip = (ablate >> 9) & 7; pt.trace_b0 = ((ablate >> 12) & 0xFF) * 256;
       launch_conv(ntaps, stride, cfg, pt, e->stream);
-      std::vector<unsigned long long> h(tb / 8);
+      std::vector<unsigned int> h(tb / 4);
       (void)dev_memcpy_d2h(h.data(), tr, tb, e->stream);
       (void)dev_sync(e->stream);
-      for (int b = 0; b < 8; b += 4)
-        for (int k = 0; k < 8; ++k)
-          for (int r = 0; r < 2; ++r) {
-            const unsigned long long* ev = &h[(((size_t)b * 2 + r) * 8 + k) * 16];
-            if (!ev[0]) continue;
-            fprintf(stderr, "[trace] block %d tile %d %s:", b, k, r ? "producer" : "consumer");
-            for (int i = 0; i < 16 && ev[i]; ++i) fprintf(stderr, " %llu", (unsigned long long)(ev[i] - h[(((size_t)b * 2 + 0) * 8 + 0) * 16]));
-            fprintf(stderr, "\n");
-          }
+      for (int b = 0; b < 16; ++b)
+        for (int r = 0; r < 2; ++r) {
+          const unsigned int* ev = &h[((size_t)b * 2 + r) * 384];
+          const int n = (int)ev[383] < 383 ? (int)ev[383] : 383;
+          if (!n) continue;
+          fprintf(stderr, "[trace] block %d %s n=%d:", pt.trace_b0 + b, r ? "producer" : "consumer", n);
+          for (int i = 0; i < n; ++i) fprintf(stderr, " %u", ev[i]);
+          fprintf(stderr, "\n");
+        }
       dev_free(tr);
     }
     p.ablate = ablate & 255;
@@ -2510,8 +2569,7 @@ int sdm_op_attention_split(sdm_ctx* e, const float* q, const float* k, const flo
   if (e) dev_use(e->device);
   if (!e || !q || !k || !v || !out) return SDM_ERR_INVALID;
   const int C = heads * 64;
-  const char* pvs = getenv("SDM_ATTN_PV_SPLIT");
-  const int mode = (attn_f8_enabled() && !(pvs && pvs[0] == '1')) ? 3 : 2;
+  const int mode = (attn_f8_enabled() && !opt("attn_pv_split")) ? 3 : 2;
   return run_two_pass(e, [&]() {
     T b2 = talloc(e, B, 1, 1, Lk, 1);
     T qp = talloc(e, B, 1, Lq, C, mode), kp = talloc(e, B, 1, Lk, C, mode), vp = talloc(e, B, 1, Lk, C, mode);

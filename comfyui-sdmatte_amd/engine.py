@@ -82,9 +82,10 @@ EXPORTS = [
     "sdm_default_config", "sdm_create", "sdm_destroy", "sdm_last_error", "sdm_load_tensor", "sdm_finalize_weights",
     "sdm_weight_stats", "sdm_missing_key", "sdm_weight_blob_bytes", "sdm_export_weight_blob", "sdm_import_weight_blob",
     "sdm_host_blob_bytes", "sdm_export_host_blob", "sdm_import_host_blob", "sdm_forward", "sdm_forward_ex", "sdm_forward_rect", "sdm_apply_matte", "sdm_apply_matte_node",
-    "sdm_synchronize", "sdm_release_memory", "sdm_resident_bytes", "sdm_last_forward_ms", "sdm_profile_enable", "sdm_profile_count", "sdm_profile_get", "sdm_profile_dump",
+    "sdm_synchronize", "sdm_release_memory", "sdm_resident_bytes", "sdm_weight_bytes", "sdm_last_forward_ms", "sdm_profile_enable", "sdm_profile_count", "sdm_profile_get", "sdm_profile_dump",
     "sdm_op_conv", "sdm_op_conv_ex", "sdm_debug_run_layer", "sdm_debug_temb_row", "sdm_conv_num_cfgs", "sdm_bench_conv", "sdm_bench_attn", "sdm_op_groupnorm", "sdm_op_layernorm", "sdm_op_attention", "sdm_op_attention_split", "sdm_op_resize_aa",
     "sdm_op_mask_bias",
+    "sdm_set_option", "sdm_get_option", "sdm_reset_options", "sdm_option_name", "sdm_option_help", "sdm_kernel_counts", "sdm_kernel_counts_reset",
 ]
 
 
@@ -117,6 +118,7 @@ class Bindings:
             "sdm_synchronize": (i32, [vp]),
             "sdm_release_memory": (i32, [vp]),
             "sdm_resident_bytes": (i64, [vp]),
+            "sdm_weight_bytes": (i64, [vp]),
             "sdm_last_forward_ms": (f32, [vp]),
             "sdm_profile_enable": (i32, [vp, i32]),
             "sdm_profile_count": (i32, [vp]),
@@ -138,11 +140,55 @@ class Bindings:
             "sdm_op_attention_split": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
             "sdm_op_resize_aa": (i32, [vp, vp, i32, i32, i32, vp, i32, i32]),
             "sdm_op_mask_bias": (i32, [vp, vp, i32, i32, i32, vp]),
+            "sdm_set_option": (i32, [C.c_char_p, i32]),
+            "sdm_get_option": (i32, [C.c_char_p, C.POINTER(i32)]),
+            "sdm_reset_options": (None, []),
+            "sdm_option_name": (C.c_char_p, [i32]),
+            "sdm_option_help": (C.c_char_p, [i32]),
+            "sdm_kernel_counts": (i32, [C.c_char_p, i32]),
+            "sdm_kernel_counts_reset": (None, []),
         }
         for name in EXPORTS:
             fn = getattr(cdll, name)          # AttributeError = missing export: fail loudly
             fn.restype, fn.argtypes = sig[name]
             setattr(self, name, fn)
+
+    # ---- kernel-selection options (process-wide; tests and tools/ only - the library reads no environment variable) ----
+    def set_option(self, name, value):
+        if self.sdm_set_option(name.encode(), int(value)) != 0:
+            raise KeyError(f"unknown engine option {name!r}; known: {', '.join(self.options())}")
+
+    def get_option(self, name):
+        v = C.c_int(0)
+        if self.sdm_get_option(name.encode(), C.byref(v)) != 0:
+            raise KeyError(name)
+        return v.value
+
+    def options(self):
+        out, i = {}, 0
+        while True:
+            n = self.sdm_option_name(i)
+            if n is None:
+                return out
+            out[n.decode()] = self.sdm_option_help(i).decode()
+            i += 1
+
+    def reset_options(self):
+        self.sdm_reset_options()
+
+    def kernel_counts(self, reset=False):
+        """{kernel variant: launches since the last reset}"""
+        n = self.sdm_kernel_counts(None, 0)
+        buf = C.create_string_buffer(n + 1)
+        self.sdm_kernel_counts(buf, n + 1)
+        out = {}
+        for item in buf.value.decode().split(";"):
+            if item:
+                k, v = item.rsplit("=", 1)
+                out[k] = int(v)
+        if reset:
+            self.sdm_kernel_counts_reset()
+        return out
 
 
 _PRODUCT = None
@@ -338,6 +384,10 @@ class Engine:
     def resident_bytes(self):
         """Device memory held by the engine (weights + activation arena + I/O staging), invisible to torch's allocator."""
         return int(self.lib.sdm_resident_bytes(self.h))
+
+    def weight_bytes(self):
+        """The weight part of resident_bytes(): canonical blob + derived kernel layouts (stays resident across release_memory())."""
+        return int(self.lib.sdm_weight_bytes(self.h))
 
     def release_memory(self):
         """Free the activation arena and staging buffers (weights stay); the next call re-allocates what it needs."""

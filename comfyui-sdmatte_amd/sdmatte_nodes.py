@@ -204,7 +204,7 @@ def _trim_engine_memory(model):
         limit = float(os.environ.get("SDMATTE_KEEP_ARENA_GB", "8")) * 2 ** 30
         engines = [model.engine] + (list(model._fan.engines[1:]) if getattr(model, "_fan", None) is not None else [])
         for eng in engines:
-            if eng.resident_bytes() - eng.weight_blob_bytes() > limit:
+            if eng.resident_bytes() - eng.weight_bytes() > limit:      # arena + I/O staging only: ALL weight layouts stay
                 eng.release_memory()
     except Exception as exc:  # noqa: BLE001 - best effort, like the reference's empty_cache block (sdmatte_nodes.py:399-403)
         print(f"[SDMatte] note: could not trim engine memory ({exc})")

@@ -163,7 +163,24 @@ int sdm_apply_matte_node(sdm_ctx* ctx, const float* image_bhwc, const float* tri
 /* Memory the engine holds outside any framework allocator: packed weights + activation arena (sized by the largest batch /
  * resolution seen) + I/O staging.  sdm_release_memory frees everything but the weights (the next forward re-allocates). */
 int64_t sdm_resident_bytes(sdm_ctx* ctx);
+/* The weight part of it: the canonical blob (sdm_weight_blob_bytes) plus the kernel-specific layouts derived from it.
+ * sdm_resident_bytes - sdm_weight_bytes = what sdm_release_memory gives back. */
+int64_t sdm_weight_bytes(sdm_ctx* ctx);
 int sdm_release_memory(sdm_ctx* ctx);
+
+/* Kernel-selection options.  The library reads NO environment variable: every choice among its kernel variants has one default, and
+ * this is the only way to change one (tests and the A/B tools under tools/ do; the ComfyUI node never does).  Process-wide; names and
+ * meanings: sdm_option_name(i) / sdm_option_help(i) for i = 0 .. until NULL.  Options marked "read when a model is built" / "read at
+ * sdm_create" must be set before that call.  Returns SDM_ERR_INVALID for an unknown name. */
+int sdm_set_option(const char* name, int value);
+int sdm_get_option(const char* name, int* value);
+void sdm_reset_options(void);
+const char* sdm_option_name(int i);
+const char* sdm_option_help(int i);
+/* Which kernel variants were launched since the last reset, as "name=count;..." (returns the full length; truncates to cap).  Lets a
+ * test assert that the variant it means to check is the one that ran. */
+int sdm_kernel_counts(char* buf, int cap);
+void sdm_kernel_counts_reset(void);
 
 /* Block until everything queued on the engine stream has finished. */
 int sdm_synchronize(sdm_ctx* ctx);

@@ -24,3 +24,19 @@ def pkg():
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture
+def engine_option():
+    """Set kernel-selection options of an engine library for one test (sdm_set_option - the library reads no environment variable);
+    everything is back at its default afterwards.  usage: engine_option(engine_or_bindings, "attn_nw", 8)"""
+    touched = []
+
+    def set_option(target, name, value):
+        lib = getattr(target, "lib", target)
+        lib.set_option(name, value)
+        if lib not in touched:
+            touched.append(lib)
+    yield set_option
+    for lib in touched:
+        lib.reset_options()

@@ -30,7 +30,7 @@ def check_conv(eng, dev, N, H, W, Cin, Cout, ntaps=9, stride=1, pad_mode=0, up=0
     """gn = (eps, silu): GroupNorm(32)(+SiLU) of the input fused into the conv's operand staging (the ResBlock path).
     split = True: split-fp16 operands (precise mode) - the reference then sees the un-rounded fp32 operands.
     f8 = True: the residual terms of the split product on fp8 operands (F8 kernel: 3x3 stride 1, Cin % 32 == 0, tile cfg 0);
-    False pins them to fp16 (SDM_CONV_F8=0) so that the 2e-5 checks of the fp16x3 arithmetic keep their meaning.
+    False pins them to fp16 (option conv_f8 = 0) so that the 2e-5 checks of the fp16x3 arithmetic keep their meaning.
     xscale / wscale multiply the N(0,1) activations / the N(0, 1/fan_in) weights (range robustness of the fp8 residual operands);
     rel = True compares max|d| / max|ref| with atol."""
     g = _g(seed)
@@ -80,16 +80,13 @@ def check_conv(eng, dev, N, H, W, Cin, Cout, ntaps=9, stride=1, pad_mode=0, up=0
     if r is not None:
         rr = nhwc(r)
         rr = (rr if res == "f32" else rr.half()).to(dev)
-    prev = os.environ.get("SDM_CONV_F8")
-    os.environ["SDM_CONV_F8"] = "1" if f8 else "0"
+    prev = eng.lib.get_option("conv_f8")      # (the stand-alone operator packs its weights per call: the option is read there)
+    eng.lib.set_option("conv_f8", 1 if f8 else 0)
     try:
         out = eng.op_conv(x0, w.to(dev), b.to(dev), x1=x1, stride=stride, pad_mode=pad_mode, up=up, res=rr, geglu=geglu, out_f32=out_f32,
                           out_scale=out_scale, tile_cfg=tile_cfg, split=split, gn=gn_arg)
     finally:
-        if prev is None:
-            os.environ.pop("SDM_CONV_F8", None)
-        else:
-            os.environ["SDM_CONV_F8"] = prev
+        eng.lib.set_option("conv_f8", prev)
     got = nchw(out.float().cpu())
     err = (got - ref).abs().max().item()
     if rel:

@@ -14,6 +14,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def _emu_lib():
+    from emu.build_emu import build
+    from comfyui_sdmatte_amd.engine import Bindings
+    return Bindings(ctypes.CDLL(build()))      # (dlopen of one path = one library instance: its options are shared)
+
+
 def _emu_engine(cfg, precision="fp16"):
     """Emulator engine; the emulator tests that are about host logic / index math run the fp16-operand graph (3x fewer
     emulated MFMAs), test_emu_precise_mode_meets_parity_bar covers the default split-precision graph."""
@@ -22,7 +28,7 @@ def _emu_engine(cfg, precision="fp16"):
     return Engine(cfg, 0, True, _lib=Bindings(ctypes.CDLL(build())), precision=precision)
 
 
-def test_emu_precise_mode_meets_parity_bar(pkg, monkeypatch):
+def test_emu_precise_mode_meets_parity_bar(pkg, engine_option):
     """The default precision ("fp16x3": split-fp16 operands in every conv / GEMM / attention core, fp32 activations) on the kernel
     emulator: alpha within the north star's 1e-3 of the fp32 oracle (the fp16-operand graph sits at ~4e-3 on the same inputs),
     through the generic tiles AND through the 256x128 fused-GroupNorm tile that carries the real sizes."""
@@ -46,7 +52,7 @@ def test_emu_precise_mode_meets_parity_bar(pkg, monkeypatch):
     a = eng.apply_matte(img, tri, 64)
     d = (a - ref).abs()
     assert d.max().item() <= 1e-3 and d.max().item() < 0.25 * dfast.max().item(), (d.max().item(), dfast.max().item())
-    monkeypatch.setenv("SDM_FORCE_CFG0", "1")
+    engine_option(_emu_lib(), "force_cfg0", 1)
     d0 = (eng.apply_matte(img, tri, 64) - ref).abs()
     assert d0.max().item() <= 1e-3, d0.max().item()
     eng.close()
@@ -83,7 +89,13 @@ def test_emu_gpu_node_tail_bit_exact_vs_reference_fixture(pkg, golden_dir):
     # 349); it only has to match where the reference indexes the alpha with it (mask_refine / matted_rgb), and fails there like it
     from oracle import sdmatte_oracle as O
     tri_small = F.interpolate(tri[:1, None], size=(29, 41), mode="bilinear", align_corners=False)[:, 0].contiguous()
+    # ... and is not READ beyond its own size where nothing uses it: the small trimap sits right in front of an inaccessible page
+    # (an out-of-bounds load of tri[i], i < H*W of the image, would fault here; on a GPU it can fault the process)
+    tri_small = _in_front_of_a_guard_page(tri_small)
     a2, m2 = eng.apply_matte_node(image[:1], tri_small, 64, False, "matted_rgba", False, 0.8)
+    # what release_memory() would give back (activation arena + I/O staging) excludes EVERY weight layout, not only the canonical blob:
+    # the node's trim threshold (SDMATTE_KEEP_ARENA_GB) is compared with this
+    assert 0 < eng.resident_bytes() - eng.weight_bytes() < 2 ** 30 and eng.weight_bytes() >= eng.weight_blob_bytes()
     w = synthetic_state_dict(cfg, 0)
     pred = O.sdmatte_forward(w, cfg.as_dict(), O.preprocess(image[:1], tri_small, 64, False))
     ra, _ = O.postprocess(pred, image[:1], tri_small, "alpha_only", False, 0.8)
@@ -96,6 +108,27 @@ def test_emu_gpu_node_tail_bit_exact_vs_reference_fixture(pkg, golden_dir):
     with pytest.raises(ValueError):
         eng.apply_matte_node(image[:1, :, :, :2], tri[:1], 64, False, "alpha_only", False, 0.8)    # not an RGB image
     eng.close()
+
+
+_GUARDED = []      # keeps the mappings alive
+
+
+def _in_front_of_a_guard_page(t):
+    """A copy of the (contiguous, fp32) tensor whose last byte is the last accessible byte of its mapping."""
+    import ctypes
+    import mmap
+    page = mmap.PAGESIZE
+    nbytes = t.numel() * t.element_size()
+    npages = (nbytes + page - 1) // page
+    m = mmap.mmap(-1, (npages + 1) * page)
+    base = ctypes.addressof(ctypes.c_char.from_buffer(m))
+    libc = ctypes.CDLL(None, use_errno=True)
+    assert libc.mprotect(ctypes.c_void_p(base + npages * page), ctypes.c_size_t(page), 0) == 0      # PROT_NONE
+    off = npages * page - nbytes
+    g = torch.frombuffer(m, dtype=t.dtype, count=t.numel(), offset=off).view(t.shape)
+    g.copy_(t)
+    _GUARDED.append(m)
+    return g
 
 
 def test_emu_single_process_fan_out(pkg):
@@ -170,7 +203,7 @@ def test_emu_full_forward_matches_oracle(pkg):
     eng2.close()
 
 
-def test_emu_fused_groupnorm_path(pkg, monkeypatch):
+def test_emu_fused_groupnorm_path(pkg, engine_option):
     """Force the 256x128 conv tile so that GroupNorm+SiLU is applied inside the conv operand staging (the production path at
     real sizes) and compare with the oracle and with the un-fused path."""
     from comfyui_sdmatte_amd.config import SDMatteConfig
@@ -183,7 +216,7 @@ def test_emu_fused_groupnorm_path(pkg, monkeypatch):
     ref, _ = O.apply_matte(w, cfg.as_dict(), img, tri, 64, mask_refine=False)
     eng = _emu_engine(cfg)
     eng.load_state_dict(w)
-    monkeypatch.setenv("SDM_FORCE_CFG0", "1")
+    engine_option(_emu_lib(), "force_cfg0", 1)
     eng.profile(True)
     a = eng.apply_matte(img, tri, 64)
     d = (a - ref).abs()
@@ -370,3 +403,62 @@ def test_bench_two_ranks_control_flow(pkg):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["steps"] == 1
     assert d["config"]["global_batch"] == 2 and d["config"]["parallelism"] == "dp2"
     assert d["cpu_baseline"] is None
+
+
+def test_checkpoint_variants_load_to_identical_engines(pkg, tmp_path):
+    """What a real `SDMatte*.safetensors` can look like without us ever having seen one (sdmatte_nodes.py:298-323 loads it with
+    strict=False): saved in fp16 or bf16, the VAE attention under diffusers' legacy names (query / key / value / proj_attn), a
+    text_encoder.* subtree the trimap path never touches.  Each variant, streamed through the node's loader (LazyCheckpoint ->
+    sdm_load_tensor), must give bit-identical packed weights to an fp32 file with the modern names holding the same values; and
+    tools/check_checkpoint.py must pass the same files from their headers alone."""
+    import json
+    import subprocess
+    import sys
+    from safetensors.torch import save_file
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    from comfyui_sdmatte_amd.weights import synthetic_state_dict
+    from comfyui_sdmatte_amd.sdmatte_nodes import LazyCheckpoint
+    cfg = SDMatteConfig.tiny()
+    w = synthetic_state_dict(cfg, 3)
+
+    def blob_of(path):
+        eng = _emu_engine(cfg, precision="fp16x3")
+        missing, ignored = eng.load_state_dict(LazyCheckpoint(str(path)), strict=True)
+        dev = torch.empty(eng.weight_blob_bytes(), dtype=torch.uint8)
+        host = torch.empty(eng.host_blob_bytes(), dtype=torch.uint8)
+        eng.export_weights(dev, host)
+        eng.close()
+        return dev, host, ignored
+
+    def legacy_names(sd):
+        out = {}
+        for k, v in sd.items():
+            if k.startswith("vae.") and "mid_block.attentions.0" in k:
+                for a, b in ((".to_q.", ".query."), (".to_k.", ".key."), (".to_v.", ".value."), (".to_out.0.", ".proj_attn.")):
+                    k = k.replace(a, b)
+            out[k] = v
+        return out
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "check_checkpoint.py")
+    for dt in (torch.float16, torch.bfloat16):
+        rounded = {k: v.to(dt).float().contiguous() for k, v in w.items()}                       # the values such a file holds
+        f32 = tmp_path / f"f32_{dt}.safetensors"
+        save_file(rounded, str(f32))
+        low = {k: v.to(dt).contiguous() for k, v in legacy_names(w).items()}
+        low["text_encoder.text_model.embeddings.token_embedding.weight"] = torch.zeros(8, 4, dtype=dt)
+        low["text_encoder.text_model.final_layer_norm.bias"] = torch.zeros(4, dtype=dt)
+        lowf = tmp_path / f"low_{dt}.safetensors"
+        save_file(low, str(lowf))
+        d0, h0, ig0 = blob_of(f32)
+        d1, h1, ig1 = blob_of(lowf)
+        assert torch.equal(d0, d1) and torch.equal(h0, h1), str(dt)
+        assert ig0 == 0 and ig1 == 0                                                              # text_encoder.* never reaches the engine
+        r = subprocess.run([sys.executable, tool, str(lowf), "--config", "tiny", "--write-manifest", str(tmp_path / "m.json")], capture_output=True, text=True)
+        assert r.returncode == 0 and "missing (engine would refuse to load): 0" in r.stdout and "shape mismatches: 0" in r.stdout, r.stdout + r.stderr
+        r = subprocess.run([sys.executable, tool, "--diff", str(tmp_path / "m.json"), "--config", "tiny"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run([sys.executable, tool, "--write-expected", str(tmp_path / "exp.json"), "--config", "full"], capture_output=True, text=True)
+    assert r.returncode == 0
+    exp = json.load(open(tmp_path / "exp.json"))["tensors"]
+    assert exp["unet.conv_in.weight"]["shape"] == [320, 8, 3, 3] and exp["unet.aux_conv_in.weight"]["shape"] == [1024, 4, 3, 3] and len(exp) > 1000

@@ -60,11 +60,11 @@ def test_conv3x3_dma_weight_pipeline(emu_engine):
     S.check_conv(emu_engine, DEV, 1, 6, 20, 32, 128, C1=32, up=1, tile_cfg=0, in_f32=True, out_f32=True, split=True, seed=8, atol=2e-5)
 
 
-def test_conv3x3_producer_consumer_form(emu_engine, monkeypatch):
+def test_conv3x3_producer_consumer_form(emu_engine, engine_option):
     """PC form of the split-precision DMA-weight kernel (8 waves: 4 MFMA-only consumer waves + 4 staging producer waves, A tile
     double-buffered, weights two stages ahead in a ring of 5): 1 / odd / even numbers of K-chunks, ragged output-channel tile, fused
     GroupNorm, upsample + concat, residual; and agreement with the 4-wave form up to the fp32 summation order."""
-    monkeypatch.setenv("SDM_CONV_PC", "1")
+    engine_option(emu_engine, "conv_pc", 1)
     S.check_conv(emu_engine, DEV, 1, 9, 35, 16, 128, tile_cfg=0, in_f32=True, out_f32=True, split=True, seed=6, atol=2e-5)
     S.check_conv(emu_engine, DEV, 2, 9, 35, 96, 160, tile_cfg=0, in_f32=True, out_f32=True, split=True, gn=(1e-6, True), res="f32", seed=7, atol=2e-5)
     S.check_conv(emu_engine, DEV, 1, 6, 20, 32, 128, C1=32, up=1, tile_cfg=0, in_f32=True, out_f32=True, split=True, seed=8, atol=2e-5)
@@ -72,7 +72,7 @@ def test_conv3x3_producer_consumer_form(emu_engine, monkeypatch):
     x = torch.randn(1, 10, 33, 80)
     w = torch.randn(128, 80, 3, 3) / 27.0
     a = emu_engine.op_conv(x, w, None, out_f32=True, split=True, tile_cfg=0)
-    monkeypatch.setenv("SDM_CONV_PC", "0")
+    engine_option(emu_engine, "conv_pc", 0)
     b = emu_engine.op_conv(x, w, None, out_f32=True, split=True, tile_cfg=0)
     assert (a - b).abs().max().item() <= 2e-5
 
@@ -90,12 +90,12 @@ def test_conv3x3_fp8_residual_terms(emu_engine):
 
 
 @pytest.mark.parametrize("mode", ["0", "3", "4"])
-def test_f8_accumulator_layout_epilogue(emu_engine, monkeypatch, mode):
+def test_f8_accumulator_layout_epilogue(emu_engine, engine_option, mode):
     """F8 kernels ([channel][pixel] accumulators), full fp32 tiles: 16-byte stores straight from the MFMA registers + bias from LDS
-    + the residual as the accumulators' initial value (SDM_CONV_EPI=4, the default), the residual init alone (=3) and the LDS-staged
+    + the residual as the accumulators' initial value (option conv_epi = 4, the default), the residual init alone (=3) and the LDS-staged
     epilogue (=0): same results on full tiles (3x3: H % 8 == 0 and W % 32 == 0; GEMM: rows % 256 == 0), a ragged output-channel
     tile, with and without residual, fused GroupNorm; a ragged image mixes both paths in one launch."""
-    monkeypatch.setenv("SDM_CONV_EPI", mode)
+    engine_option(emu_engine, "conv_epi", int(mode))
     S.check_conv(emu_engine, DEV, 1, 16, 64, 64, 160, tile_cfg=0, in_f32=True, out_f32=True, split=True, f8=True, res="f32", seed=71, atol=3e-4)
     S.check_conv(emu_engine, DEV, 2, 8, 32, 32, 128, tile_cfg=0, in_f32=True, out_f32=True, split=True, f8=True, gn=(1e-6, True), seed=72, atol=3e-4)
     S.check_conv(emu_engine, DEV, 1, 12, 40, 32, 128, tile_cfg=0, in_f32=True, out_f32=True, split=True, f8=True, res="f32", seed=73, atol=3e-4)
@@ -172,51 +172,51 @@ def test_attention_d64(emu_engine):
     S.check_attention(emu_engine, DEV, 1, 1, 32, 192, 64, use_bias=False, spike=True, seed=3)
 
 
-def test_attention_d64_split_precision(emu_engine, monkeypatch):
+def test_attention_d64_split_precision(emu_engine, engine_option):
     """The default precision's attention cores: Q.K^T on split operands (the logits feed an exponential), P.V on plain fp16 operands
-    (PREC = 2), fp32 in / out; and the fully split form (PREC = 1, SDM_ATTN_PV_SPLIT=1).  Against un-rounded fp64 attention: the
+    (PREC = 2), fp32 in / out; and the fully split form (PREC = 1, option attn_pv_split).  Against un-rounded fp64 attention: the
     fp16-operand kernel sits at ~2e-3 on these inputs."""
     e2 = S.check_attention(emu_engine, DEV, 1, 2, 70, 100, 64, use_bias=True, split=True, atol=1e-3)
     S.check_attention(emu_engine, DEV, 2, 1, 33, 200, 64, use_bias=False, split=True, seed=4, atol=1e-3)
-    monkeypatch.setenv("SDM_ATTN_PV_SPLIT", "1")
+    engine_option(emu_engine, "attn_pv_split", 1)
     e1 = S.check_attention(emu_engine, DEV, 1, 2, 70, 100, 64, use_bias=True, split=True, atol=3e-5)
     assert e1 < e2
-    monkeypatch.delenv("SDM_ATTN_PV_SPLIT")
-    # the residual terms of Q.K^T on fp8 MFMAs (PREC = 3, the default) against the same kernel with fp16 residual terms (SDM_ATTN_F8=0,
+    engine_option(emu_engine, "attn_pv_split", 0)
+    # the residual terms of Q.K^T on fp8 MFMAs (PREC = 3, the default) against the same kernel with fp16 residual terms (option attn_f8 = 0,
     # PREC = 2): P.V is rounded identically in both, so the difference isolates the logit error of the e5m2 residual pairs
     import torch
     g = torch.Generator().manual_seed(21)
     q, k, v = torch.randn(1, 70, 128, generator=g) * 1.5, torch.randn(1, 130, 128, generator=g) * 1.5, torch.randn(1, 130, 128, generator=g)
     a8 = emu_engine.op_attention_split(q, k, v, 2)
-    monkeypatch.setenv("SDM_ATTN_F8", "0")
+    engine_option(emu_engine, "attn_f8", 0)
     a16 = emu_engine.op_attention_split(q, k, v, 2)
     d = (a8 - a16).abs().max().item()
     assert 0.0 < d < 4e-4, d            # logit spread ~3x that of unit-variance q / k; fp16 operands alone are off by ~1e-2 here
-    monkeypatch.delenv("SDM_ATTN_F8")
+    engine_option(emu_engine, "attn_f8", 1)
     # the 8-wave form of the same kernel (level-0 attentions; global loads two key tiles ahead through two raw-tile register sets): same
     # arithmetic per query row as the 4-wave form -> bit-identical, for 1, 2, 3 and 5 key tiles and the trimap-style tile list
     for lk in (40, 128, 130, 300, 450):
         kk, vv = torch.randn(1, lk, 128, generator=g) * 1.5, torch.randn(1, lk, 128, generator=g)
         bias = torch.where(torch.rand(1, lk, generator=g) < 0.3, torch.tensor(-10000.0), torch.tensor(0.0))
         for bb in (None, bias):
-            monkeypatch.setenv("SDM_ATTN_NW", "4")
+            engine_option(emu_engine, "attn_nw", 4)
             r4 = emu_engine.op_attention_split(q, kk, vv, 2, bias=bb)
-            monkeypatch.setenv("SDM_ATTN_PIPE4", "1")          # the 4-wave pipeline (two K / three V^T buffers; off by default, unmeasured)
+            engine_option(emu_engine, "attn_pipe4", 1)          # the 4-wave pipeline (two K / three V^T buffers; off by default, unmeasured)
             r4p = emu_engine.op_attention_split(q, kk, vv, 2, bias=bb)
-            monkeypatch.delenv("SDM_ATTN_PIPE4")
+            engine_option(emu_engine, "attn_pipe4", 0)
             assert torch.equal(r4p, r4), (lk, bb is not None, (r4p - r4).abs().max().item())
-            monkeypatch.setenv("SDM_ATTN_NW", "8")
-            monkeypatch.setenv("SDM_ATTN_PIPE", "0")
+            engine_option(emu_engine, "attn_nw", 8)
+            engine_option(emu_engine, "attn_pipe", 0)
             r8 = emu_engine.op_attention_split(q, kk, vv, 2, bias=bb)
             assert torch.equal(r4, r8), (lk, bb is not None, (r4 - r8).abs().max().item())
             # the two-tile software pipeline of the 8-wave kernel (the default for 8-wave launches; three LDS buffers): same arithmetic
-            monkeypatch.delenv("SDM_ATTN_PIPE")
+            engine_option(emu_engine, "attn_pipe", 1)
             rp = emu_engine.op_attention_split(q, kk, vv, 2, bias=bb)
             assert torch.equal(rp, r8), (lk, bb is not None, (rp - r8).abs().max().item())
-    monkeypatch.delenv("SDM_ATTN_NW")
+    engine_option(emu_engine, "attn_nw", 0)
 
 
-def test_attention_d64_skips_underflowing_key_tiles(emu_engine, monkeypatch):
+def test_attention_d64_skips_underflowing_key_tiles(emu_engine, engine_option):
     # trimap-like bias with whole key tiles at -5000 / -10000: those tiles are never loaded; the result must equal the fp32
     # reference (where their probabilities underflow to 0) AND be bit-identical to walking every tile
     S.check_attention(emu_engine, DEV, 3, 2, 40, 500, 64, use_bias=True, blocks=True, seed=7)
@@ -228,7 +228,7 @@ def test_attention_d64_skips_underflowing_key_tiles(emu_engine, monkeypatch):
     bias[1, 5:9] = 0.0
     bias[1, 200:] = -5000.0
     sparse = emu_engine.op_attention(q, k, v, 1, bias)
-    monkeypatch.setenv("SDM_ATTN_DENSE", "1")
+    engine_option(emu_engine, "attn_dense", 1)
     dense = emu_engine.op_attention(q, k, v, 1, bias)
     assert torch.equal(sparse, dense)
 

@@ -90,6 +90,33 @@ def test_e2e_tiny_s192_ragged_levels(pkg):
     m.engine.close()
 
 
+@pytest.mark.parametrize("S", [640, 896])
+def test_e2e_tiny_node_sizes_640_896(pkg, S):
+    """The two inference sizes of the node's menu (sdmatte_nodes.py:226-229) that are neither a power of two nor 768: latent 80 / 112,
+    ragged 64-key / 128-query tile counts at every level (6400 / 12544 tokens at level 0)."""
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    m, w, img, tri, data, ref, out, d = _run(pkg, SDMatteConfig.tiny(), S, 1)
+    assert d.max().item() <= TOL
+    m.engine.close()
+
+
+@pytest.mark.parametrize("nw", [8, 4])
+def test_e2e_tiny_through_each_attention_pipeline_kernel(pkg, engine_option, nw):
+    """End to end against the oracle with every d=64 attention launch forced onto one of the two shipped pipeline kernels (8-wave: what
+    the level-0 attentions of the timed B=4 1024^2 step run; 4-wave: everything else), trimap bias and tile lists included."""
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    from comfyui_sdmatte_amd import engine as E
+    lib = E.load_library()
+    engine_option(lib, "attn_nw", nw)
+    lib.kernel_counts(reset=True)
+    m, w, img, tri, data, ref, out, d = _run(pkg, SDMatteConfig.tiny(), 256, 2)
+    counts = lib.kernel_counts()
+    print(counts)
+    assert d.max().item() <= TOL
+    assert counts.get(f"attn_d64_pipe<{nw}>", 0) > 0 and all(c == 0 for n, c in counts.items() if n.startswith("attn_d64") and n != f"attn_d64_pipe<{nw}>"), counts
+    m.engine.close()
+
+
 def test_e2e_tiny_d512_vae_attention(pkg):
     from comfyui_sdmatte_amd.config import SDMatteConfig
     m, w, img, tri, data, ref, out, d = _run(pkg, SDMatteConfig.tiny_d512(), 128, 1)
@@ -361,7 +388,7 @@ def test_e2e_config4_768_sdmatte_plus_node_refine(pkg, tmp_path, monkeypatch):
 
 
 @pytest.mark.slow
-def test_e2e_full_model_1024_properties(pkg, monkeypatch):
+def test_e2e_full_model_1024_properties(pkg, engine_option):
     """BASELINE config #2/#3 size (1024x1024, full architecture, synthetic weights).  The fp32 oracle needs minutes per image at this
     size (bench.py times it; profiles/ holds the comparison), so the test checks size-independent properties instead:
     determinism, batch-position independence (image i of a batch == the same image alone: nothing mixes images), range, and
@@ -390,10 +417,26 @@ def test_e2e_full_model_1024_properties(pkg, monkeypatch):
     ds = (single[0] - a[1]).abs()
     print(f"\n[full 1024 B=1 vs B=2] max|d|={ds.max():.3e} mean|d|={ds.mean():.3e}")
     assert ds.max().item() <= TOL
-    monkeypatch.setenv("SDM_ATTN_DENSE", "1")
+    engine_option(eng, "attn_dense", 1)
     dense = eng.apply_matte(img, tri, S, False).cpu()
     assert torch.equal(dense, a)                                   # exact sparsity: same bits as the dense key walk
     eng.close()
+
+
+def test_e2e_full_model_512_batch4_vs_oracle(pkg):
+    """Full SD-2.1 architecture, B = 4 (the batch size the benchmark times: tile and kernel selection depend on it), every image against
+    the oracle; the launch census shows the kernels of the timed configuration class (F8 3x3 convs, fp8-residual GEMMs, both attention
+    pipelines)."""
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    from comfyui_sdmatte_amd import engine as E
+    lib = E.load_library()
+    lib.kernel_counts(reset=True)
+    m, w, img, tri, data, ref, out, d = _run(pkg, SDMatteConfig.full(), 512, 4, seed=4321)
+    counts = lib.kernel_counts()
+    print(counts)
+    assert d.max().item() <= 4e-4, d.max().item()
+    assert counts.get("conv3x3_f8<gn>", 0) > 0 and counts.get("gemm_f8", 0) > 0 and counts.get("attn_d64_pipe<4>", 0) > 0
+    m.engine.close()
 
 
 @pytest.mark.slow

@@ -108,9 +108,9 @@ def test_attention_d64(eng):
     S.check_attention(eng, DEV, 1, 1, 64, 4096, 64, use_bias=False, spike=True, seed=3)            # forced rescale branch
 
 
-def test_attention_d64_skips_underflowing_key_tiles(eng, monkeypatch):
+def test_attention_d64_skips_underflowing_key_tiles(eng, engine_option):
     # trimap-like bias with whole key tiles at -5000 / -10000: never loaded; equal to the fp32 reference and bit-identical to
-    # walking every tile (SDM_ATTN_DENSE)
+    # walking every tile (option attn_dense)
     S.check_attention(eng, DEV, 3, 5, 1000, 4096, 64, use_bias=True, blocks=True, seed=7)
     import torch
     g = torch.Generator().manual_seed(11)
@@ -121,7 +121,7 @@ def test_attention_d64_skips_underflowing_key_tiles(eng, monkeypatch):
     bias[1, 5:9] = 0.0
     bias[1, 700:] = -5000.0
     sparse = eng.op_attention(q, k, v, 2, bias.to(DEV)).cpu()
-    monkeypatch.setenv("SDM_ATTN_DENSE", "1")
+    engine_option(eng, "attn_dense", 1)
     dense = eng.op_attention(q, k, v, 2, bias.to(DEV)).cpu()
     assert torch.equal(sparse, dense)
 
@@ -219,23 +219,23 @@ def test_f8_residual_operand_ranges(eng, xs, ws):
 
 
 @pytest.mark.parametrize("mode", ["0", "3", "4"])
-def test_f8_epilogue_modes(eng, monkeypatch, mode):
-    """SDM_CONV_EPI: register-direct 16-byte stores + residual as the accumulators' initial value (4, default), residual init alone (3),
+def test_f8_epilogue_modes(eng, engine_option, mode):
+    """Option conv_epi: register-direct 16-byte stores + residual as the accumulators' initial value (4, default), residual init alone (3),
     LDS-staged epilogue (0); full and ragged tiles."""
-    monkeypatch.setenv("SDM_CONV_EPI", mode)
+    engine_option(eng, "conv_epi", int(mode))
     S.check_conv(eng, DEV, 2, 64, 128, 128, 160, tile_cfg=0, in_f32=True, out_f32=True, split=True, f8=True, gn=(1e-6, True), res="f32", seed=71, atol=3e-4)
     S.check_conv(eng, DEV, 1, 44, 72, 64, 128, tile_cfg=0, in_f32=True, out_f32=True, split=True, f8=True, res="f32", seed=73, atol=3e-4)
     S.check_conv(eng, DEV, 1, 64, 64, 1280, 320, ntaps=1, tile_cfg=4, in_f32=True, out_f32=True, split=True, f8=True, res="f32", seed=74, atol=3e-4)
 
 
-def test_attention_d64_split_precision(eng, monkeypatch):
+def test_attention_d64_split_precision(eng, engine_option):
     """Split-precision attention cores as the engine runs them (Q.K^T on hi | lo pairs, P.V on fp16; 4- and 8-wave blocks), and the
     fully split form, against un-rounded fp64 attention."""
     e2 = S.check_attention(eng, DEV, 2, 5, 300, 1000, 64, use_bias=True, split=True, atol=1e-3)
-    monkeypatch.setenv("SDM_ATTN_NW", "8")
+    engine_option(eng, "attn_nw", 8)
     S.check_attention(eng, DEV, 1, 2, 700, 333, 64, use_bias=False, split=True, seed=5, atol=1e-3)
-    monkeypatch.delenv("SDM_ATTN_NW")
-    monkeypatch.setenv("SDM_ATTN_PV_SPLIT", "1")
+    engine_option(eng, "attn_nw", 0)
+    engine_option(eng, "attn_pv_split", 1)
     e1 = S.check_attention(eng, DEV, 2, 5, 300, 1000, 64, use_bias=True, split=True, atol=3e-5)
     print(f"[split attention] P.V fp16: {e2:.2e}  fully split: {e1:.2e}")
 
@@ -248,3 +248,32 @@ def test_gemm_fp8_residual_terms(eng, M_hw, cin, cout, geglu, res):
     err = S.check_conv(eng, DEV, 2, M_hw[0], M_hw[1], cin, cout, ntaps=1, tile_cfg=4, in_f32=True, out_f32=True, split=True, f8=True, geglu=geglu,
                        res=res, seed=cin + cout, atol=3e-4)
     print(f"[F8 gemm {cin}->{cout}] max|d|={err:.2e}")
+
+
+@pytest.mark.parametrize("nw,kern", [(8, "attn_d64_pipe<8>"), (4, "attn_d64_pipe<4>")])
+def test_attention_pipeline_kernels_with_trimap_bias_and_skipped_tiles(eng, engine_option, golden_dir, nw, kern):
+    """The kernels the default precision SHIPS for the d=64 attention cores - the two-tile software pipelines (8-wave: the level-0
+    launches of the timed B=4 step; 4-wave: every other launch) - against un-rounded fp64 attention with what the engine feeds them: a
+    trimap-style key bias whose -10000 / -5000 tiles are skipped (tile lists), ragged query / key counts, >= 5 key tiles; and the
+    reference's own scores fixture G3 through the same kernel.  sdm_kernel_counts proves which variant ran."""
+    import numpy as np
+    engine_option(eng, "attn_nw", nw)
+    eng.lib.kernel_counts(reset=True)
+    e_blocks = S.check_attention(eng, DEV, 2, 5, 700, 333, 64, use_bias=True, split=True, blocks=True, seed=11, atol=1e-3)       # 6 key tiles, ragged
+    e_rand = S.check_attention(eng, DEV, 1, 2, 2100, 1500, 64, use_bias=True, split=True, seed=12, atol=1e-3)                    # 24 key tiles, random -10000 keys
+    e_one = S.check_attention(eng, DEV, 1, 2, 130, 40, 64, use_bias=True, split=True, seed=13, atol=1e-3)                        # a single (ragged) key tile
+    g = np.load(os.path.join(golden_dir, "g3_attention_scores.npz"))
+    q, k, v = (torch.from_numpy(g[n]) for n in ("q", "k", "v"))
+    BH, Lq, d = q.shape
+    heads = 2
+    B = BH // heads
+    tok = lambda x: x.view(B, heads, x.shape[1], d).permute(0, 2, 1, 3).reshape(B, x.shape[1], heads * d)
+    bias = torch.from_numpy(g["key_bias"])[::heads, 0].contiguous()
+    e_g3 = 0.0
+    for use_bias, key in ((True, "out_bias"), (False, "out_nobias")):
+        out = eng.op_attention_split(tok(q).to(DEV), tok(k).to(DEV), tok(v).to(DEV), heads, bias.to(DEV) if use_bias else None)
+        e_g3 = max(e_g3, (out.float().cpu() - tok(torch.from_numpy(g[key]))).abs().max().item())
+    counts = eng.lib.kernel_counts()
+    print(f"[{kern}] blocks {e_blocks:.2e} random {e_rand:.2e} one tile {e_one:.2e} G3 {e_g3:.2e} {counts}")
+    assert e_g3 < 1e-3
+    assert counts.get(kern, 0) >= 5 and all(c == 0 for n, c in counts.items() if n.startswith("attn_d64") and n != kern), counts

@@ -3,6 +3,11 @@ inferred from the reference's module attribute names: SURVEY.md Appendix C - no 
 Reads only the safetensors header (names, dtypes, shapes): no tensor data is loaded, no GPU is needed.
 
   python tools/check_checkpoint.py /path/to/SDMatte.safetensors [--write-manifest out.json] [--config full|tiny]
+  python tools/check_checkpoint.py --write-expected expected.json [--config full|tiny]      # what the engine expects, as a manifest
+  python tools/check_checkpoint.py --diff real_manifest.json [--config full|tiny]            # a manifest written elsewhere vs the schema
+
+A manifest is {tensor name: {"dtype", "shape"}}: `--write-manifest` on the machine that has the real file + `--diff` here (or
+`--write-expected` here + any JSON diff there) answers "will it load" in one command, without moving 4 GB.
 
 Exit code 0 when every tensor the engine consumes is present with the expected shape (extra tensors such as text_encoder.* are
 listed but fine: the engine ignores them, like the reference's load_state_dict(strict=False))."""
@@ -31,7 +36,23 @@ def main():
     load_package()
     from comfyui_sdmatte_amd.config import SDMatteConfig
     from comfyui_sdmatte_amd.weights import weight_schema
-    have = read_header(sys.argv[1])
+    if "--write-expected" in sys.argv:
+        out = sys.argv[sys.argv.index("--write-expected") + 1]
+        cfg_name = sys.argv[sys.argv.index("--config") + 1] if "--config" in sys.argv else "full"
+        want = weight_schema(getattr(SDMatteConfig, cfg_name)())
+        with open(out, "w") as fh:
+            json.dump({"_comment": "tensors the SDMatte engine consumes (any float dtype; legacy VAE attention names query/key/value/proj_attn are "
+                                   "accepted for to_q/to_k/to_v/to_out.0; everything else in a checkpoint, e.g. text_encoder.*, is ignored)",
+                       "tensors": {k: {"dtype": "F32|F16|BF16", "shape": list(v)} for k, v in want.items()}}, fh, indent=0)
+        print(f"expected manifest of {len(want)} tensors ({cfg_name} architecture) written to {out}")
+        return
+    if "--diff" in sys.argv:
+        with open(sys.argv[sys.argv.index("--diff") + 1]) as fh:
+            man = json.load(fh)
+        man = man.get("tensors", man)
+        have = {k: (v["dtype"], tuple(v["shape"])) for k, v in man.items() if isinstance(v, dict)}
+    else:
+        have = read_header(sys.argv[1])
     if "--write-manifest" in sys.argv:
         out = sys.argv[sys.argv.index("--write-manifest") + 1]
         with open(out, "w") as fh:

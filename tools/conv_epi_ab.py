@@ -1,6 +1,6 @@
 """A/B of the F8 conv / GEMM kernel's epilogue on the layer shapes that dominate the step, in the engine's real I/O format
 (fp32 activations in, fp32 out, optional fp32 residual, GroupNorm statistics of the consumer; random operands).
-SDM_CONV_EPI: 0 = LDS-staged epilogue, 3 = 0 + residual as accumulator init, 4 = 3 + register-direct 16-byte stores (default).
+option conv_epi: 0 = LDS-staged epilogue, 3 = 0 + residual as accumulator init, 4 = 3 + register-direct 16-byte stores (default).
 (profiles/r03_conv_epilogue_ab.txt holds the round-3 measurement of the abandoned dword-store variants 1 / 2.)
 Bench helper, not part of the product path.  usage: python tools/conv_epi_ab.py [quick]
 flag bits: 1 fp32 in, 2 split, 4 fused GroupNorm+SiLU, 16 fp8 residual terms, 32 fp32 out, 64 fp32 residual, 128 statistics"""
@@ -26,22 +26,22 @@ for (N, H, W, ci, co, nt) in shapes:
         res = {}
         for rep in range(2):
             for mode in MODES:
-                os.environ["SDM_CONV_EPI"] = mode
+                eng.lib.set_option("conv_epi", int(mode))
                 t = eng.bench_conv(N, H, W, ci, co, ntaps=nt, in_f32=flag, tile_cfg=0 if nt == 9 else 4, iters=6)
                 res[mode] = min(res.get(mode, 1e9), t)
-        os.environ["SDM_CONV_EPI"] = MODES[-1]
+        eng.lib.set_option("conv_epi", int(MODES[-1]))
         tn = eng.bench_conv(N, H, W, ci, co, ntaps=nt, in_f32=flag, tile_cfg=0 if nt == 9 else 4, ablate=8, iters=6)      # no stores at all
         s = " | ".join(f"epi{m} {res[m]:7.3f} ms {fl / res[m] / 1e9:6.1f} TF/s" for m in MODES)
         print(f"N={N} {H}x{W} {ci}->{co} taps={nt} {name:19s} {s} | x{res['0'] / res[MODES[-1]]:5.3f} | no-store {tn:7.3f} ms", flush=True)
 if not quick:
-    print("== tiles per block (SDM_CONV_F8_TPB) with SDM_CONV_EPI=4, conv2 form")
-    os.environ["SDM_CONV_EPI"] = "4"
+    print("== tiles per block (option conv_f8_tpb) with option conv_epi=4, conv2 form")
+    eng.lib.set_option("conv_epi", 4)
     for (N, H, W, ci, co, nt) in shapes[:5]:
         fl = 2.0 * N * H * W * ci * co * nt
         out = []
         for tpb in ("1", "2", "4"):
-            os.environ["SDM_CONV_F8_TPB"] = tpb
+            eng.lib.set_option("conv_f8_tpb", int(tpb))
             t = min(eng.bench_conv(N, H, W, ci, co, ntaps=nt, in_f32=BASE | 4 | 64, tile_cfg=0, iters=6) for _ in range(2))
             out.append(f"tpb{tpb} {t:7.3f} ms {fl / t / 1e9:6.1f}")
-        os.environ.pop("SDM_CONV_F8_TPB")
+        eng.lib.set_option("conv_f8_tpb", 0)
         print(f"N={N} {H}x{W} {ci}->{co}: " + " | ".join(out), flush=True)

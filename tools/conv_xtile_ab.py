@@ -1,4 +1,4 @@
-"""A/B of the cross-tile prefetch of the F8 3x3 conv kernel (SDM_CONV_XTILE=0 / 1) on the layer shapes that dominate the step, in the
+"""A/B of the cross-tile prefetch of the F8 3x3 conv kernel (option conv_xtile = 0 / 1) on the layer shapes that dominate the step, in the
 engine's real I/O format (fp32 in / out, fused GroupNorm, optional residual, statistics; random operands).  Bench helper."""
 import os
 import sys
@@ -17,19 +17,19 @@ for (N, H, W, ci, co) in shapes:
         res = {}
         for rep in range(3):
             for x in ("0", "1"):
-                os.environ["SDM_CONV_XTILE"] = x
+                eng.lib.set_option("conv_xtile", int(x))
                 t = eng.bench_conv(N, H, W, ci, co, ntaps=9, in_f32=flag, tile_cfg=0, iters=6)
                 res[x] = min(res.get(x, 1e9), t)
         print(f"N={N} {H}x{W} {ci}->{co} {name:19s} xtile0 {res['0']:7.3f} ms {fl / res['0'] / 1e9:6.1f} TF/s | xtile1 {res['1']:7.3f} ms {fl / res['1'] / 1e9:6.1f} TF/s | x{res['0'] / res['1']:5.3f}",
               flush=True)
-os.environ["SDM_CONV_XTILE"] = "1"
+eng.lib.set_option("conv_xtile", 1)
 print("== tiles per block with the cross-tile prefetch (conv2 form)")
 for (N, H, W, ci, co) in shapes[:6]:
     fl = 2.0 * N * H * W * ci * co * 9
     out = []
     for tpb in ("2", "4", "8"):
-        os.environ["SDM_CONV_F8_TPB"] = tpb
+        eng.lib.set_option("conv_f8_tpb", int(tpb))
         t = min(eng.bench_conv(N, H, W, ci, co, ntaps=9, in_f32=BASE | 64, tile_cfg=0, iters=6) for _ in range(2))
         out.append(f"tpb{tpb} {t:7.3f} ms {fl / t / 1e9:6.1f}")
-    os.environ.pop("SDM_CONV_F8_TPB")
+    eng.lib.set_option("conv_f8_tpb", 0)
     print(f"N={N} {H}x{W} {ci}->{co}: " + " | ".join(out), flush=True)

@@ -1,0 +1,8 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out/r4
+export TMPDIR=/tmp
+timeout 300 python tools/conv_lib_ab.py _ab/libsdmatte_hip_r3.so > gpurun_out/r4/conv_ab3.txt 2>&1
+timeout 300 python tools/conv_trace.py > gpurun_out/r4/conv_trace3.txt 2>&1
+timeout 300 python tools/conv_lab.py quick > gpurun_out/r4/conv_lab3.txt 2>&1
+cat gpurun_out/r4/conv_ab3.txt

@@ -10,7 +10,7 @@ from comfyui_sdmatte_amd.build import CODEGEN_FLAGS      # the product's own cod
 def main():
     filt = sys.argv[1:] or ["conv_mfma", "attn", "gemm"]
     with tempfile.TemporaryDirectory() as d:
-        r = subprocess.run(["/opt/rocm/bin/hipcc"] + CODEGEN_FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-c", SRC, "-o", os.path.join(d, "e.o")],
+        r = subprocess.run(["/opt/rocm/bin/hipcc"] + CODEGEN_FLAGS + os.environ.get("SDM_EXTRA_FLAGS","").split() + ["-Rpass-analysis=kernel-resource-usage", "-c", SRC, "-o", os.path.join(d, "e.o")],
                            capture_output=True, text=True)
     blocks = re.split(r"remark: [^\n]*Function Name: ", r.stderr)[1:]
     names = [b.split("\n")[0].strip() for b in blocks]
