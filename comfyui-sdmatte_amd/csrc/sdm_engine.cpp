@@ -13,6 +13,7 @@
 //   * the dead CLIP text branch (meta_arch.py:220-234, never consumed: replace.py:414-416) is not built.
 #include "sdm_common.h"
 #include "k_conv.h"
+#include "k_conv_f8s.h"
 #include "k_norm.h"
 #include "k_attn.h"
 #include "k_misc.h"
@@ -94,6 +95,7 @@ static OptEntry g_opts[] = {
   {"gemm_f8_min_k", 1024, 1024, "smallest K of a GEMM that takes the 8-wave fp8-residual kernel"},
   {"conv_epi", 4, 4, "F8 kernels' epilogue: 4 register-direct stores + residual as accumulator init, 3 residual init only, 0 LDS-staged"},
   {"conv_xtile", 1, 1, "F8 3x3: cross-tile prefetch by the producer waves"},
+  {"conv_swap", 0, 0, "F8 3x3: role-swapping wave groups (k_conv_f8s.h) where its restrictions hold - correct, measured slower (DESIGN.md 4): off"},
   {"conv_f8_tpb", 0, 0, "F8: tiles per block (0 = by queue depth)"},
   {"conv_dma", 1, 1, "3x3 stride-1 256x128 tile: weights by LDS-DMA"},
   {"conv_dma_all", 0, 0, "keep a stage-ordered weight copy for every wide 3x3 layer, not only the split-precision ones (read when a model is built)"},
@@ -275,6 +277,29 @@ static void launch_conv_dma(const ConvParams& p_in, void* stream) {
     SDM_SET_SMEM(k, 160 * 1024);                                                                             \
     SDM_LAUNCH(k, grid, dim3(CD::LAUNCH_THREADS), (size_t)CD::SMEM + gn_extra, stream, p);                   \
   } while (0)
+  if (split && p.f8 && opt("conv_swap") && p.in_f32 && p.out_f32 == 1 && p.epi == 0 && p.out_scale == 1.0f && p.Hout % 8 == 0 && p.Wout % 32 == 0 &&
+      p.Cout_valid == p.Cout_pad && p.Cout_pad % 128 == 0 && ((p.C0 + p.C1) / 32) % 2 == 0 && (p.C0 + p.C1) >= 128 && p.C0 % 32 == 0 && (!p.res || p.res_f32) &&
+      (!p.res || p.res_C % 4 == 0)) {
+    // role-swapping wave groups: a block walks its tiles back to back, one group of four waves multiplying a tile while the other drains
+    // the previous one and stages the next (k_conv_f8s.h).  Persistent blocks once there are at least two tiles per CU.
+    p.vgrid = (int)grid.x;
+#ifdef SDM_EMU
+    unsigned pg = (grid.x + 2) / 3;
+#else
+    static int cus = 0;
+    if (!cus) {
+      int dev = 0;
+      hipDeviceProp_t pr;
+      cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+    }
+    unsigned pg = grid.x >= 2u * (unsigned)cus ? (unsigned)cus : grid.x;
+#endif
+    pg = (pg + 7) & ~7u;
+    count_kernel(gn ? "conv3x3_f8_swap<gn>" : "conv3x3_f8_swap");
+    if (gn) { auto k = conv3x3_f8_swap_kernel<1>; SDM_SET_SMEM(k, 160 * 1024); SDM_LAUNCH(k, dim3(pg, 1, 1), dim3(512), (size_t)ConvF8S::SMEM + 2048, stream, p); }
+    else { auto k = conv3x3_f8_swap_kernel<0>; SDM_SET_SMEM(k, 160 * 1024); SDM_LAUNCH(k, dim3(pg, 1, 1), dim3(512), (size_t)ConvF8S::SMEM + 2048, stream, p); }
+    return;
+  }
   if (split && p.f8) {          // fp8-residual producer / consumer kernel (32-channel chunks; no GroupNorm table in LDS)
 #define SDM_F8_CASE(GNF)                                                                                     \
   do {                                                                                                       \

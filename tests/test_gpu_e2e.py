@@ -117,6 +117,21 @@ def test_e2e_tiny_through_each_attention_pipeline_kernel(pkg, engine_option, nw)
     m.engine.close()
 
 
+def test_e2e_tiny_d512_role_swap_convs(pkg, engine_option):
+    """The role-swap conv kernel (option conv_swap = 1) inside the graph: its drain produces the GroupNorm statistics the next layer
+    normalises with, and adds the ResBlock residual."""
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    from comfyui_sdmatte_amd import engine as E
+    lib = E.load_library()
+    engine_option(lib, "conv_swap", 1)
+    lib.kernel_counts(reset=True)
+    m, w, img, tri, data, ref, out, d = _run(pkg, SDMatteConfig.tiny_d512(), 256, 2)
+    counts = lib.kernel_counts()
+    print(counts)
+    assert d.max().item() <= TOL and counts.get("conv3x3_f8_swap<gn>", 0) > 0
+    m.engine.close()
+
+
 def test_e2e_tiny_d512_vae_attention(pkg):
     from comfyui_sdmatte_amd.config import SDMatteConfig
     m, w, img, tri, data, ref, out, d = _run(pkg, SDMatteConfig.tiny_d512(), 128, 1)
