@@ -113,7 +113,9 @@ def test_e2e_tiny_through_each_attention_pipeline_kernel(pkg, engine_option, nw)
     counts = lib.kernel_counts()
     print(counts)
     assert d.max().item() <= TOL
-    assert counts.get(f"attn_d64_pipe<{nw}>", 0) > 0 and all(c == 0 for n, c in counts.items() if n.startswith("attn_d64") and n != f"attn_d64_pipe<{nw}>"), counts
+    # (the cross-attentions keep fp16 hi | lo planes for K | V - their producer is a folded 3x3 conv - and run attn_d64<prec2,*>; every
+    # self-attention, i.e. everything with fp8 pair planes, a trimap bias and tile lists, must have gone through the pipeline kernel)
+    assert counts.get(f"attn_d64_pipe<{nw}>", 0) > 0 and not any(c for n, c in counts.items() if n.startswith("attn_d64<prec3")), counts
     m.engine.close()
 
 
