@@ -51,11 +51,18 @@ def timed_steps(step, steps, world, dev):
         dist.barrier()
     sync()
     elapsed = time.perf_counter() - t0
+    PER_RANK_S[:] = [elapsed]
     if world > 1:
+        # every rank's own time (all_gather: the list's length is the number of ranks the collective REALLY spanned), then the maximum
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        got = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(got, t)
+        PER_RANK_S[:] = [float(x.item()) for x in got]
+        elapsed = max(PER_RANK_S)
     return elapsed
+
+
+PER_RANK_S = []      # seconds of the last timed_steps() per rank (filled on every rank)
 
 
 def main():
@@ -170,6 +177,7 @@ def main():
     for _ in range(args.warmup):
         step()
     elapsed = timed_steps(step, args.steps, world, dev)
+    per_rank_s = list(PER_RANK_S)
     ms_per_step = elapsed * 1e3 / max(args.steps, 1)
     value = world * B * args.steps / elapsed
 
@@ -225,11 +233,18 @@ def main():
         # (profiles/pmc_traffic.json, written by tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE passes, KB units,
         # FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md); null when no matching profile is committed.
         traffic = None
+        pmc_stale = False      # the committed counter files were taken on another build of the library than the one timed here
+        try:
+            from comfyui_sdmatte_amd import build as _build
+            build_stamp = _build._stamp()
+        except Exception:
+            build_stamp = None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
                 pt = json.load(fh)
             if pt.get("batch_per_gpu") == B and pt.get("inference_size") == S and pt.get("precision", "fp16") == precision:
                 traffic = pt.get("conv3x3_bytes_per_launch")
+                pmc_stale = pmc_stale or pt.get("build_stamp") != build_stamp
         except Exception:
             pass
         # matrix-pipe busy fraction of the same kernel from the committed SQ counter pass of `bench.py --timed-only`
@@ -240,6 +255,7 @@ def main():
                 ps = json.load(fh)
             if ps.get("batch_per_gpu") == B and ps.get("inference_size") == S and ps.get("precision", "fp16") == precision:
                 mfma_busy = ps.get("conv3x3_mfma_busy_frac")
+                pmc_stale = pmc_stale or ps.get("build_stamp") != build_stamp
         except Exception:
             pass
         f8_res = precision == "fp16x3" and eng.lib.get_option("conv_f8") != 0      # residual terms of the 3x3 convs on fp8 (engine default)
@@ -256,7 +272,12 @@ def main():
                     "note": f"achieved = ALGORITHMIC flops (2*MAC of the convolution) / time; this precision keeps the matrix pipe busy for "
                             f"{mfma_per_product} fp16-MFMA time(s) per algorithmic product"
                             + (" (x_hi*w_hi on fp16 + the two residual terms on fp8 K=64 MFMAs at twice the rate)" if f8_res else ""),
-                    "mfma_executed_frac": round(mfma_per_product * ach / MFMA_F16_PEAK_TFLOPS, 4), "mfma_busy_frac_pmc": mfma_busy}
+                    "mfma_executed_frac": round(mfma_per_product * ach / MFMA_F16_PEAK_TFLOPS, 4), "mfma_busy_frac_pmc": mfma_busy,
+                    "pmc_source": "profiles/pmc_traffic.json, profiles/pmc_sq.json (rocprofv3 --pmc passes of `bench.py --timed-only`, reduced by tools/pmc_*.py)",
+                    "pmc_stale": pmc_stale}
+            if pmc_stale:      # counters of another build say nothing about this one
+                roof["traffic"] = None
+                roof["mfma_busy_frac_pmc"] = None
         breakdown = {k: {"ms": round(v["ms"], 3), "launches": v["launches"],
                          "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1) if v["flops"] else None,
                          "gbps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1) if v["bytes"] else None}
@@ -317,6 +338,7 @@ def main():
             eng_o.close()
         result = {
             "metric": "alpha mattes/sec at 1024x1024", "value": round(value, 3), "unit": "images/s", "n_gpus": world,
+            "ranks_seen": len(per_rank_s), "per_rank_images_per_s": [round(B * args.steps / max(x, 1e-9), 3) for x in per_rank_s],
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16x3" if precision == "fp16x3" else "f16", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: {S}x{S} image+trimap -> alpha (alpha_only), SD-2.1/SDMatte architecture, "

@@ -402,6 +402,7 @@ def test_bench_two_ranks_control_flow(pkg):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["steps"] == 1
     assert d["config"]["global_batch"] == 2 and d["config"]["parallelism"] == "dp2"
+    assert d["ranks_seen"] == 2 and len(d["per_rank_images_per_s"]) == 2      # the collective really spanned both ranks
     assert d["cpu_baseline"] is None
 
 

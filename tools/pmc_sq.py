@@ -39,7 +39,7 @@ with open(sys.argv[5], "w", newline="") as fh:
         w.writerow([k, n, "" if b is None else f"{b:.4f}", f"{c.get('SQ_BUSY_CYCLES', 0.0) / 32.0 / n:.0f}",
                     f"{c.get('GRBM_GUI_ACTIVE', 0.0) / 8.0 / n:.0f}" if "GRBM_GUI_ACTIVE" in c else ""] + [c.get(x, 0.0) for x in counters])
 
-FAM = {"conv3x3": "conv_mfma_kernel<9", "gemm": "conv_mfma_kernel<1", "attn_d64": "attn_d64_kernel", "attn_d512": "attn_d512_kernel"}
+FAM = {"conv3x3": "conv_mfma_kernel<9", "gemm": "conv_mfma_kernel<1", "attn_d64": "attn_d64_", "attn_d512": "attn_d512_kernel"}
 out = {"batch_per_gpu": int(sys.argv[2]), "inference_size": int(sys.argv[3]), "precision": sys.argv[4],
        "note": "matrix-pipe busy fraction per kernel family = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x SQ_BUSY_CYCLES / 32), summed over every "
                "dispatch of the family in a `bench.py --timed-only` run"}
@@ -56,4 +56,13 @@ for name, key in FAM.items():
     out[f"{name}_mfma_busy_frac"] = None if b is None else round(b, 4)
     if agg.get("SQ_WAVE_CYCLES"):
         out[f"{name}_wait_inst_any_frac_of_wave_cycles"] = round(agg.get("SQ_WAIT_INST_ANY", 0.0) / agg["SQ_WAVE_CYCLES"], 4)
+try:      # the sources + flags the profiled library was built from (bench.py shows these numbers only beside the same build)
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from __graft_entry__ import load_package
+    load_package()
+    from comfyui_sdmatte_amd import build as _B
+    out["build_stamp"] = _B._stamp()
+except Exception:
+    out["build_stamp"] = None
 print(json.dumps(out))

@@ -22,4 +22,13 @@ out = {"batch_per_gpu": int(sys.argv[3]), "inference_size": int(sys.argv[4]), "p
        "fetch_kb_raw_per_launch": f / max(nf, 1), "write_kb_raw_per_launch": w / max(nw, 1),
        "conv3x3_bytes_per_launch": (2.0 * f / max(nf, 1) + w / max(nw, 1)) * 1024.0,
        "note": "HBM-side bytes per conv3x3 launch = (2*FETCH_SIZE + WRITE_SIZE) KB, averaged over all conv3x3 launches of the run"}
+try:      # the sources + flags the profiled library was built from (bench.py shows these numbers only beside the same build)
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from __graft_entry__ import load_package
+    load_package()
+    from comfyui_sdmatte_amd import build as _B
+    out["build_stamp"] = _B._stamp()
+except Exception:
+    out["build_stamp"] = None
 print(json.dumps(out))

@@ -6,7 +6,7 @@ usage: python tools/rocprof_stats_summary.py <kernel_stats.csv> <steps_in_run> >
 import csv, sys, collections
 
 FAMILIES = [("conv3x3 (conv_mfma_kernel<9,...>)", "conv_mfma_kernel<9"), ("gemm / 1x1 (conv_mfma_kernel<1,...>)", "conv_mfma_kernel<1"),
-            ("attn_d64", "attn_d64_kernel"), ("attn_d512", "attn_d512_kernel"), ("transpose_v", "transpose_v_kernel"),
+            ("attn_d64 (incl. the pipeline kernels)", "attn_d64_"), ("attn_d512", "attn_d512_kernel"), ("transpose_v", "transpose_v_kernel"),
             ("gn_stats / partials", "gn_"), ("layernorm", "layernorm_kernel")]
 steps = int(sys.argv[2])
 agg = collections.OrderedDict((f[0], [0, 0.0]) for f in FAMILIES)
