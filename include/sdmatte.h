@@ -234,7 +234,7 @@ int sdm_op_layernorm(sdm_ctx* ctx, const void* x, int in_f32, long rows, int C, 
  * D = 64 (any heads) or 512 (heads = 1).  With a bias (D = 64), 64-key tiles in which every key's bias lies more than
  * 2000*ln(2) below the image's largest bias are not loaded: their probabilities underflow to exactly 0 in fp32, as they do in
  * the reference's softmax (trimap keys carry (1-m)*-10000, replace.py:401-403).  The result is bit-identical to walking
- * every tile; setting the environment variable SDM_ATTN_DENSE disables the skip. */
+ * every tile; the engine option attn_dense = 1 disables the skip. */
 int sdm_op_attention(sdm_ctx* ctx, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* bias,
                      int B, int heads, int Lq, int Lk, int D, void* out, int ldo);
 /* Split-precision attention cores (head dim 64) as the default precision runs them: contiguous fp32 q [B,Lq,heads*64], k / v [B,Lk,heads*64]
