@@ -76,6 +76,9 @@ struct ConvParams {
                                         // 8 skip the epilogue stores -- after the first K-chunk; always 0 in the engine
   int vgrid, tpb;                       // F8 (tpb tiles per block): number of virtual block ids = the grid of the one-tile-per-block forms
   int tiles_m, tiles_n, xcd_chunk;      // 1-D XCD-aware grid (set by launch_conv_t): M tiles per image (9 taps) or in total (1 tap), N tiles, M tiles per XCD
+  int ksplit; size_t ks_stride;         // split-K (register-staged kernels, launch_conv_t): ksplit > 1 -> grid.y = ksplit, block row y multiplies input channels
+                                        // [y, y+1) * Cin / ksplit and stores its fp32 partial sums (acc * acc_scale: no bias / residual / statistics) at
+                                        // (float*)out + y * ks_stride; splitk_reduce_kernel finishes the layer
   float* stats;                         // optional [N][tiles_m*WM][Cout_store][2]: per-(image, wave row-tile, channel) partial
                                         // sum / sum of squares of the stored values = fused GroupNorm statistics of the NEXT
                                         // layer (reduced by gn_partials_scale_shift_kernel); NTAPS==9 or one image per launch
@@ -261,6 +264,8 @@ conv_mfma_kernel(ConvParams p) {
   const long m_end = (NTAPS == 1 && p.rows_per_img) ? (long)(img + 1) * p.rows_per_img : p.M;      // first row beyond this block's row range
   const int Cin = p.C0 + p.C1;
   const int Hl = p.Hin << p.up, Wl = p.Win << p.up;
+  const bool ksp = !DMAB && p.ksplit > 1;
+  const int kb = ksp ? (int)blockIdx.y * (Cin / p.ksplit) : 0, ke = ksp ? kb + Cin / p.ksplit : Cin;      // this block's input-channel range
 
   f32x16 acc[MT][NTL];
 #pragma unroll
@@ -1288,15 +1293,15 @@ conv_mfma_kernel(ConvParams p) {
     }
     }   // !PC
   } else {
-  issue_loads(0);
+  issue_loads(kb);
   if (DB) {                      // double-buffered tiles: chunk 0 is staged up front, ONE barrier per K-chunk afterwards
     if (GN) __syncthreads();     // gn_tab filled
-    write_lds(As, Bs, 0);
+    write_lds(As, Bs, kb);
     __syncthreads();
   }
-  for (int c0 = 0; c0 < Cin; c0 += KC) {
+  for (int c0 = kb; c0 < ke; c0 += KC) {
     if (SPLIT) {
-      const bool abl_ld = (p.ablate & 1) != 0, abl_wr = (p.ablate & 2) && c0 > 0, abl_mm = (p.ablate & 4) && c0 > 0;   // bench only
+      const bool abl_ld = (p.ablate & 1) != 0, abl_wr = (p.ablate & 2) && c0 > kb, abl_mm = (p.ablate & 4) && c0 > kb;   // bench only
       __syncthreads();            // every wave has finished reading the previous chunk from LDS
       if (!abl_wr) {
         write_lds_a(As, c0);      // A_hi and A_lo halo tiles
@@ -1313,26 +1318,26 @@ conv_mfma_kernel(ConvParams p) {
       __syncthreads();
       // next chunk's activations and w_hi taps: in flight during the third pass (issued only now, when the B staging
       // registers are free again: the A + B staging sets together with 128 accumulators are what fits in 256 registers)
-      if (c0 + KC < Cin && !abl_ld) { issue_loads_a(c0 + KC); issue_loads_b(c0 + KC, rsw); }
+      if (c0 + KC < ke && !abl_ld) { issue_loads_a(c0 + KC); issue_loads_b(c0 + KC, rsw); }
       if (!abl_mm) mfma_chunk(As);            // A_hi . w_lo
       continue;
     }
     if (DB) {
-      const int cur = (c0 / KC) & 1;
+      const int cur = ((c0 - kb) / KC) & 1;
       As = smem + cur * C::TILE_BYTES;
       Bs = As + C::A_BYTES;
-      if (c0 + KC < Cin) issue_loads(c0 + KC);       // in flight during the MFMAs below
+      if (c0 + KC < ke) issue_loads(c0 + KC);       // in flight during the MFMAs below
     } else {
       __syncthreads();            // every wave has finished reading the previous chunk from LDS
-      if (!(p.ablate & 2) || c0 == 0) write_lds(As, Bs, c0);
+      if (!(p.ablate & 2) || c0 == kb) write_lds(As, Bs, c0);
       __syncthreads();
-      if (c0 + KC < Cin && !(p.ablate & 1)) issue_loads(c0 + KC);
-      if ((p.ablate & 4) && c0 > 0) continue;
+      if (c0 + KC < ke && !(p.ablate & 1)) issue_loads(c0 + KC);
+      if ((p.ablate & 4) && c0 > kb) continue;
     }
     mfma_chunk(As);
     if (DB) {
-      if (c0 + KC < Cin) {          // the other half was last read one iteration ago, before the previous barrier
-        unsigned char* An = smem + (((c0 / KC) & 1) ^ 1) * C::TILE_BYTES;
+      if (c0 + KC < ke) {          // the other half was last read one iteration ago, before the previous barrier
+        unsigned char* An = smem + ((((c0 - kb) / KC) & 1) ^ 1) * C::TILE_BYTES;
         write_lds(An, An + C::A_BYTES, c0 + KC);
       }
       __syncthreads();
@@ -1535,7 +1540,7 @@ conv_mfma_kernel(ConvParams p) {
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = v[e];
-            *(f32x4*)((float*)p.out + oidx) = o;
+            *(f32x4*)((float*)p.out + (ksp ? (size_t)blockIdx.y * p.ks_stride : (size_t)0) + oidx) = o;
           } else if (p.out_f32 == 2) {                  // hi | lo fp16 planes (operands of the split-precision attention)
             f16x4 oh, ol;
 #pragma unroll
@@ -1655,6 +1660,87 @@ conv_mfma_kernel(ConvParams p) {
 #endif
   } else {
     run_tile(std::integral_constant<int, -1>{}, (int)blockIdx.x, 0, false);
+  }
+}
+
+// ---- split-K epilogue.  The register-staged kernels above, launched with ConvParams::ksplit > 1, leave ksplit slabs of fp32 partial sums
+//      [rows][ws_C]; this kernel finishes the layer exactly as their linear epilogue does: (sum + bias) * out_scale + residual, fp32 / fp16 store,
+//      and the fused GroupNorm statistics of the consumer in the same partial-row layout [N][srows][Cout_store][2] with srows = row blocks per
+//      image.  The slabs are added in slab order: the result does not depend on scheduling.
+//      grid (N * blocks_per_img, ceil(Cout_valid / 64)), 256 threads = 16 rows x 16 lanes of 4 channels; a block walks `rb` rows of ONE image. ----
+struct SplitKReduceParams {
+  const float* ws; int ksplit; size_t ks_stride; int ws_C;
+  int rows_per_img, rb, blocks_per_img;
+  const float* bias; const int* bias_sel; int Cout_pad;
+  const void* res; int res_f32, res_C;
+  float out_scale;
+  void* out; int out_f32, Cout_store, out_ch_off, Cout_valid;
+  float* stats;
+};
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(SplitKReduceParams q) {
+  SDM_SHARED float red[16][64][2];
+  const int tid = threadIdx.x, l16 = tid & 15, rg = tid >> 4;
+  const int img = (int)blockIdx.x / q.blocks_per_img, rbi = (int)blockIdx.x % q.blocks_per_img;
+  const int oc = (int)blockIdx.y * 64 + l16 * 4;
+  const bool cok = oc < q.Cout_valid;
+  const long row0 = (long)img * q.rows_per_img + (long)rbi * q.rb;
+  long row_end = row0 + q.rb;
+  if (row_end > (long)(img + 1) * q.rows_per_img) row_end = (long)(img + 1) * q.rows_per_img;
+  f32x4 b = {0.f, 0.f, 0.f, 0.f};
+  if (q.bias && cok) b = *(const f32x4*)(q.bias + (q.bias_sel ? (size_t)q.bias_sel[img] * q.Cout_pad : (size_t)0) + oc);
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+  if (cok) {
+    for (long r = row0 + rg; r < row_end; r += 16) {
+      const float* src = q.ws + (size_t)r * q.ws_C + oc;
+      f32x4 a = *(const f32x4*)src;
+      for (int s = 1; s < q.ksplit; ++s) {
+        const f32x4 t = *(const f32x4*)(src + (size_t)s * q.ks_stride);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] += t[e];
+      }
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (a[e] + b[e]) * q.out_scale;
+      if (q.res) {
+        if (q.res_f32) {
+          const f32x4 r4 = *(const f32x4*)((const float*)q.res + (size_t)r * q.res_C + oc);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += r4[e];
+        } else {
+          const f16x4 r4 = *(const f16x4*)((const half_t*)q.res + (size_t)r * q.res_C + oc);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
+        }
+      }
+      const size_t oidx = (size_t)r * q.Cout_store + q.out_ch_off + oc;
+      if (q.out_f32) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = v[e];
+        *(f32x4*)((float*)q.out + oidx) = o;
+      } else {
+        f16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] = (half_t)v[e]; v[e] = (float)o[e]; }      // statistics of what the next layer will actually read
+        *(f16x4*)((half_t*)q.out + oidx) = o;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
+    }
+  }
+  if (q.stats) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[rg][l16 * 4 + e][0] = ssum[e]; red[rg][l16 * 4 + e][1] = ssq[e]; }
+    __syncthreads();
+    if (tid < 128) {
+      const int c = tid >> 1, w = tid & 1;
+      float t = 0.0f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) t += red[g][c][w];
+      const int ch = (int)blockIdx.y * 64 + c;
+      if (ch < q.Cout_valid) q.stats[(((size_t)img * q.blocks_per_img + rbi) * q.Cout_store + q.out_ch_off + ch) * 2 + w] = t;
+    }
   }
 }
 

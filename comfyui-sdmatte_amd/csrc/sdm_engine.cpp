@@ -102,6 +102,7 @@ static OptEntry g_opts[] = {
   {"conv_pc", -1, -1, "producer / consumer form of the split-precision DMA kernel: -1 by channel count, 0 off, 1 on"},
   {"conv_pc_min_cin", 256, 256, "conv_pc = -1: smallest Cin that takes the producer / consumer form"},
   {"conv_db", 0, 0, "512x128 double-buffered tile where the queue is deep"},
+  {"conv_splitk", -1, -1, "split-K of the register-staged conv / GEMM kernels: -1 by shape (few tiles, long K), 0 off, n >= 2 forced where the shape allows"},
   {"force_cfg0", 0, 0, "always the 256x128 tile for 3x3 stride 1 (tests: fused GroupNorm at tiny sizes)"},
   {"no_gn_fuse", 0, 0, "never fuse the GroupNorm apply into the consuming conv"},
   {"split_lds_pad", 0, 0, "extra dynamic LDS of the register-staged split kernels (forces one block per CU)"},
@@ -133,7 +134,7 @@ static void launch_conv_t(const ConvParams& p_in, void* stream) {
   p.tiles_n = sdm_cdiv(p.Cout_pad, BN);
   const long total_m = (long)p.tiles_m * ((NTAPS == 9 || p.rows_per_img) ? p.N : 1);
   p.xcd_chunk = (int)((total_m + 7) / 8);
-  const dim3 grid((unsigned)(8L * p.xcd_chunk * p.tiles_n), 1, 1);      // 1-D, XCD-aware mapping in the kernel
+  const dim3 grid((unsigned)(8L * p.xcd_chunk * p.tiles_n), (unsigned)(p.ksplit > 1 ? p.ksplit : 1), 1);      // x: XCD-aware 1-D mapping in the kernel; y: split-K
   const size_t gn_extra = (size_t)(p.C0 + p.C1) * 8;                    // fused GroupNorm apply: the scale|shift table of the image follows the tiles in LDS
   if constexpr (!DB) {
     if (p.w_lo) {                  // precise mode: split-fp16 operands (fp32 activations only)
@@ -236,6 +237,31 @@ static int conv_pick_cfg(int ntaps, int stride, const ConvParams& p) {
     }
     if (blocks > best_blocks) { best = i; best_blocks = blocks; }
   }
+  return best;
+}
+
+// Split-K for the register-staged kernels (k_conv.h, ConvParams::ksplit).  The 16x16 / 32x32 levels of the U-Net have a handful of
+// 64- or 128-pixel tiles and K = 9 x 1280 ... 2560: one block walks up to 160 chunks with a global-load round trip in each, and at
+// one image per call there are fewer blocks than CUs.  Splitting K puts s times the waves in flight; the partial sums (fp32, a few MB)
+// are added by splitk_reduce_kernel, which also applies bias / residual / statistics.  Returns 1 when the layer is not split.
+static int conv_pick_ksplit(int ntaps, int stride, int cfg, const ConvParams& p) {
+  const int o = opt("conv_splitk");
+  if (o == 0 || o == 1) return 1;
+  const ConvCfgInfo& c = conv_cfg_table(ntaps, stride)[cfg];
+  const int Cin = p.C0 + p.C1;
+  auto valid = [&](int s) { return s >= 2 && Cin % (s * c.KC) == 0; };
+  if (o >= 2) return valid(o) ? o : 1;
+  const long blocks = (ntaps == 9) ? (long)p.N * sdm_cdiv(p.Hout, c.TH) * sdm_cdiv(p.Wout, c.TW) * sdm_cdiv(p.Cout_pad, c.BN)
+                                   : ((p.M + c.TH * c.TW - 1) / (c.TH * c.TW)) * sdm_cdiv(p.Cout_pad, c.BN);
+  // measured (tools/conv_splitk_ab.py, profiles/r04_conv_splitk_ab.txt), 1 and 4 images per call: layers with <= 320 blocks gain x1.1-3.0 from as
+  // many splits as keep blocks x splits <= 1280 (3x3 at 16x16: 219 -> 85 us at one image, 253 -> 135 us at four; Linear 5120 -> 1280 at 32x32:
+  // 156 -> 77 us); at 640 blocks and above splitting loses or is neutral
+  const long kdepth = (long)Cin * ntaps;
+  const long min_total = ntaps == 9 ? 2560 : 1280, min_part = ntaps == 9 ? 1152 : 320;
+  if (blocks > 320 || kdepth < min_total) return 1;
+  int best = 1;
+  for (int s = 2; s <= 8; s *= 2)
+    if (valid(s) && blocks * s <= 1280 && kdepth / s >= min_part) best = s;
   return best;
 }
 
@@ -373,6 +399,29 @@ static int launch_conv(int ntaps, int stride, int cfg, const ConvParams& p, void
     }
   }
   return -1;
+}
+
+// split-K launch: the conv kernel with grid.y = ksplit writes fp32 partial sums to the workspace, splitk_reduce_kernel finishes the layer
+// (bias, output scale, residual, store format, statistics with one partial row per kSplitKRows rows of an image)
+static const int kSplitKRows = 64;
+static int launch_conv_splitk(int ntaps, int stride, int cfg, const ConvParams& p, int ksplit, float* ws, void* stream) {
+  ConvParams ps = p;
+  ps.out = ws; ps.out_f32 = 1; ps.Cout_store = p.Cout_pad; ps.out_ch_off = 0; ps.Cout_valid = p.Cout_pad;
+  ps.bias = nullptr; ps.bias_sel = nullptr; ps.res = nullptr; ps.out_scale = 1.0f; ps.stats = nullptr; ps.rows_per_img = 0;
+  ps.ksplit = ksplit; ps.ks_stride = (size_t)p.M * p.Cout_pad;
+  const int rc = launch_conv(ntaps, stride, cfg, ps, stream);
+  if (rc != 0) return rc;
+  const int bpi = sdm_cdiv(p.Hout * p.Wout, kSplitKRows);
+  SplitKReduceParams q;
+  memset(&q, 0, sizeof(q));
+  q.ws = ws; q.ksplit = ksplit; q.ks_stride = ps.ks_stride; q.ws_C = p.Cout_pad;
+  q.rows_per_img = p.Hout * p.Wout; q.rb = kSplitKRows; q.blocks_per_img = bpi;
+  q.bias = p.bias; q.bias_sel = p.bias_sel; q.Cout_pad = p.Cout_pad;
+  q.res = p.res; q.res_f32 = p.res_f32; q.res_C = p.res_C; q.out_scale = p.out_scale;
+  q.out = p.out; q.out_f32 = p.out_f32; q.Cout_store = p.Cout_store; q.out_ch_off = p.out_ch_off; q.Cout_valid = p.Cout_valid;
+  q.stats = p.stats;
+  SDM_LAUNCH(splitk_reduce_kernel, dim3((unsigned)(p.N * bpi), (unsigned)sdm_cdiv(p.Cout_valid, 64), 1), dim3(256), 0, stream, q);
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -929,16 +978,6 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
     SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: no tile configuration for Cin=%d+%d (cfg %d)", L.name.c_str(), p.C0, p.C1, cfg);
   if (a.gn_scale && !(L.ntaps == 9 && a.stride == 1 && (cfg == 0 || cfg == 4 || cfg == 5) && p.C0 + p.C1 <= 1024))
     SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: fused GroupNorm requested for an unsupported tile configuration", L.name.c_str());
-  if (a.out->want_stats) {
-    if (L.geglu || a.out_ch_off || p.out_f32 >= 2) SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: fused statistics unsupported with this epilogue", L.name.c_str());
-    const ConvCfgInfo& ci = conv_cfg_table(L.ntaps, a.stride)[cfg];
-    const long tiles = (L.ntaps == 9) ? (long)sdm_cdiv(p.Hout, ci.TH) * sdm_cdiv(p.Wout, ci.TW)
-                                      : ((long)p.Hout * p.Wout + ci.TH * ci.TW - 1) / (ci.TH * ci.TW);
-    a.out->srows = (int)(tiles * ci.WM);
-    T sb = talloc(e, 1, 1, 1, (int)((size_t)p.N * a.out->srows * a.out->C * 2), 1);
-    a.out->soff = sb.off; a.out->sbytes = sb.bytes; a.out->stats = (float*)sb.p;
-    p.stats = a.out->stats;
-  }
   // weights by LDS-DMA (256x128 tile, 3x3 stride 1): the layer keeps a stage-ordered copy of its weights for that kernel
   const bool dma_off = opt("conv_dma") == 0;      // A/B option
   if (!dma_off && L.ntaps == 9 && a.stride == 1 && cfg == 0 && L.w_dma && (!L.split || p.in_f32)) p.w_dma = L.w_dma;
@@ -957,7 +996,25 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
     // output's unit (acc_scale 1; the K16 hi | lo copy of the same layer, used by the other kernels, keeps 2^-w_exp)
     if (p.f8) { p.f8_sa = 127 - 11; p.f8_sb = 127 - L.f8_exp; p.acc_scale = 1.0f; }
   }
-  if (e->dry) return 0;
+  // split-K (register-staged kernels only): partial sums into an arena workspace, finished by splitk_reduce_kernel
+  int ksplit = 1;
+  if (!p.w_dma && !L.geglu && p.out_f32 <= 1 && (L.ntaps == 9 || p.M == (long)p.N * p.Hout * p.Wout)) ksplit = conv_pick_ksplit(L.ntaps, a.stride, cfg, p);
+  T ws; ws.bytes = 0;
+  const int sk_bpi = sdm_cdiv(p.Hout * p.Wout, kSplitKRows);
+  if (ksplit > 1 && (size_t)ksplit * p.M * p.Cout_pad >= (1ull << 31)) ksplit = 1;
+  if (a.out->want_stats) {
+    if (L.geglu || a.out_ch_off || p.out_f32 >= 2) SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: fused statistics unsupported with this epilogue", L.name.c_str());
+    const ConvCfgInfo& ci = conv_cfg_table(L.ntaps, a.stride)[cfg];
+    const long tiles = (L.ntaps == 9) ? (long)sdm_cdiv(p.Hout, ci.TH) * sdm_cdiv(p.Wout, ci.TW)
+                                      : ((long)p.Hout * p.Wout + ci.TH * ci.TW - 1) / (ci.TH * ci.TW);
+    // split-K: the statistics come from the reduce kernel, one partial row per kSplitKRows rows of an image
+    a.out->srows = ksplit > 1 ? sk_bpi : (int)(tiles * ci.WM);
+    T sb = talloc(e, 1, 1, 1, (int)((size_t)p.N * a.out->srows * a.out->C * 2), 1);
+    a.out->soff = sb.off; a.out->sbytes = sb.bytes; a.out->stats = (float*)sb.p;
+    p.stats = a.out->stats;
+  }
+  if (ksplit > 1) ws = talloc(e, 1, 1, 1, (int)((size_t)ksplit * p.M * p.Cout_pad), 1);
+  if (e->dry) { if (ksplit > 1) tfree(e, ws); return 0; }
   const double flops = 2.0 * (double)p.M * L.O * L.I * L.ntaps;
   const double bytes = (double)a.in0->rows() * L.Cin_pad * (p.in_f32 ? 4 : 2) + (double)p.M * p.Cout_valid * (p.out_f32 ? 4 : 2) +
                        (double)L.Cin_pad * L.ntaps * L.Cout_pad * 2 + (a.res ? (double)p.M * p.Cout_valid * (p.res_f32 ? 4 : 2) : 0.0);
@@ -975,7 +1032,13 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
   int rc = 0;
   // GEMMs that emit per-image GroupNorm statistics for a batch: row tiles aligned to images inside ONE launch
   if (L.ntaps == 1 && p.stats && p.N > 1) p.rows_per_img = p.Hout * p.Wout;
-  rc = launch_conv(L.ntaps, a.stride, cfg, p, e->stream);
+  if (ksplit > 1) {
+    count_kernel(L.ntaps == 9 ? "conv3x3_splitk" : "gemm_splitk");
+    rc = launch_conv_splitk(L.ntaps, a.stride, cfg, p, ksplit, (float*)ws.p, e->stream);
+    tfree(e, ws);
+  } else {
+    rc = launch_conv(L.ntaps, a.stride, cfg, p, e->stream);
+  }
   if (rc != 0) SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: bad cfg", L.name.c_str());
 #ifndef SDM_EMU
   { const hipError_t le = hipGetLastError(); if (le != hipSuccess) SDM_FAIL(e, SDM_ERR_HIP, "conv %s: launch failed: %s", L.name.c_str(), hipGetErrorString(le)); }
@@ -2334,8 +2397,7 @@ int sdm_op_conv_ex(sdm_ctx* e, const void* in0, const void* in1, int C0, int C1,
     });
     e->act_f32 = act_prev;
   } else {
-    e->dry = false;
-    rc = op_conv(e, L, a);
+    rc = run_two_pass(e, [&]() { return op_conv(e, L, a); });      // (the arena holds the split-K workspace, if the layer is split)
   }
   dev_sync(e->stream);
   dev_free(wp); dev_free(bp); if (wl) dev_free(wl);
@@ -2366,8 +2428,7 @@ int sdm_debug_run_layer(sdm_ctx* e, const char* layer_name, const float* x, int 
   tin.p = (void*)x; tin.N = N; tin.H = H; tin.W = W; tin.C = L->Cin_pad; tin.f32 = 1;
   tout.p = out; tout.N = N; tout.H = H; tout.W = W; tout.C = Cout; tout.f32 = 1;
   ConvArgs a; a.in0 = &tin; a.out = &tout; a.cout_valid = Cout;
-  e->dry = false;
-  int rc = op_conv(e, *L, a);
+  int rc = run_two_pass(e, [&]() { return op_conv(e, *L, a); });
   dev_sync(e->stream);
   return rc;
 }
@@ -2459,7 +2520,14 @@ float sdm_bench_conv(sdm_ctx* e, int N, int H, int W, int Cin, int Cout, int nta
   int cfg = tile_cfg >= 0 ? tile_cfg : conv_pick_cfg(ntaps, stride, p);
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  launch_conv(ntaps, stride, cfg, p, e->stream);
+  // split-K as the engine would run it (option conv_splitk: -1 by shape, n forced); the partial sums + the reduce kernel are inside the timed loop
+  int ksplit = 1;
+  void* wsb = nullptr;
+  if (!(p.w_dma && ((ntaps == 9 && stride == 1 && cfg == 0) || (ntaps == 1 && cfg == 4)))) ksplit = conv_pick_ksplit(ntaps, stride, cfg, p);      // register-staged kernels only
+  if (ksplit > 1 && dev_malloc(&wsb, (size_t)ksplit * p.M * p.Cout_pad * 4)) return -2.f;
+  if (ksplit > 1) fprintf(stderr, "[bench_conv] split-K %d\n", ksplit);
+  auto run = [&](const ConvParams& pp) { if (ksplit > 1) launch_conv_splitk(ntaps, stride, cfg, pp, ksplit, (float*)wsb, e->stream); else launch_conv(ntaps, stride, cfg, pp, e->stream); };
+  run(p);
   if (ablate & 256) {      // one traced launch of the F8 3x3 kernel (-DSDM_CONV_TRACE builds): the LDS-parked shader-clock stamps of the first 16 blocks -> stderr
     void* tr = nullptr;
     const size_t tb = (size_t)16 * 2 * 384 * 4;
@@ -2484,7 +2552,7 @@ float sdm_bench_conv(sdm_ctx* e, int N, int H, int W, int Cin, int Cout, int nta
     p.ablate = ablate & 255;
   }
   (void)hipEventRecord(e0, (hipStream_t)e->stream);
-  for (int i = 0; i < iters; ++i) launch_conv(ntaps, stride, cfg, p, e->stream);
+  for (int i = 0; i < iters; ++i) run(p);
   (void)hipEventRecord(e1, (hipStream_t)e->stream);
   (void)hipStreamSynchronize((hipStream_t)e->stream);
   float ms = 0.f;
@@ -2496,6 +2564,7 @@ float sdm_bench_conv(sdm_ctx* e, int N, int H, int W, int Cin, int Cout, int nta
   if (wdm) dev_free(wdm);
   if (resb) dev_free(resb);
   if (statb) dev_free(statb);
+  if (wsb) dev_free(wsb);
   return ms / (float)iters;
 #endif
 }

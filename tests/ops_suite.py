@@ -96,6 +96,35 @@ def check_conv(eng, dev, N, H, W, Cin, Cout, ntaps=9, stride=1, pad_mode=0, up=0
     return err
 
 
+def check_conv_splitk(eng, dev, set_option):
+    """Split-K of the register-staged conv / GEMM kernels (engine option conv_splitk forced): partial sums + splitk_reduce_kernel against the same
+    references and tolerances as the unsplit kernels, for every register-staged tile configuration that takes the split, with concat inputs,
+    fp32 / fp16 residuals, fp16 / fp32 outputs and the split-precision operands.  The launch counters prove that the split path ran."""
+    cases = [
+        # 3x3 stride 1: cfg 2 (64 px x 64 co, KC 16), cfg 1 (128 x 64, KC 32), split precision on both
+        dict(N=2, H=16, W=16, Cin=128, Cout=64, tile_cfg=2, ks=4),
+        dict(N=1, H=8, W=8, Cin=64, C1=64, Cout=96, tile_cfg=2, ks=2, res="f16"),
+        dict(N=1, H=16, W=16, Cin=128, Cout=64, tile_cfg=2, ks=2, in_f32=True, split=True, out_f32=True, res="f32", atol=3e-5),
+        dict(N=1, H=8, W=32, Cin=128, Cout=64, tile_cfg=1, ks=2, in_f32=True, split=True, out_f32=True, atol=3e-5),
+        dict(N=1, H=8, W=32, Cin=256, Cout=64, tile_cfg=1, ks=4, out_scale=0.5, res="f16"),
+        # 3x3 stride 2
+        dict(N=1, H=16, W=16, Cin=128, Cout=64, stride=2, tile_cfg=1, ks=2),
+        # 1x1 / Linear: cfg 2 (64 rows x 64 co, KC 64), cfg 1 (128 x 64), cfg 4 (256 x 128, KC 32: the fp32-input form)
+        dict(N=1, H=8, W=8, Cin=512, Cout=128, ntaps=1, tile_cfg=2, ks=4, res="f16"),
+        dict(N=2, H=8, W=16, Cin=256, Cout=64, ntaps=1, tile_cfg=1, ks=2, in_f32=True, split=True, out_f32=True, res="f32", atol=3e-5),
+        dict(N=1, H=16, W=16, Cin=256, Cout=128, ntaps=1, tile_cfg=4, ks=2, in_f32=True, split=True, out_f32=True, atol=3e-5),
+    ]
+    for c in cases:
+        c = dict(c)
+        ks = c.pop("ks")
+        set_option(eng, "conv_splitk", ks)
+        eng.lib.kernel_counts(reset=True)
+        check_conv(eng, dev, **c)
+        counts = eng.lib.kernel_counts()
+        assert counts.get("conv3x3_splitk", 0) + counts.get("gemm_splitk", 0) == 1, (c, counts)
+    set_option(eng, "conv_splitk", -1)
+
+
 def check_groupnorm(eng, dev, N, H, W, C, C1=0, in_f32=True, silu=True, eps=1e-6, seed=0, atol=4e-3):
     g = _g(seed)
     x = torch.randn(N, C + C1, H, W, generator=g) * 1.7 + 0.3

@@ -462,4 +462,4 @@ def test_checkpoint_variants_load_to_identical_engines(pkg, tmp_path):
     r = subprocess.run([sys.executable, tool, "--write-expected", str(tmp_path / "exp.json"), "--config", "full"], capture_output=True, text=True)
     assert r.returncode == 0
     exp = json.load(open(tmp_path / "exp.json"))["tensors"]
-    assert exp["unet.conv_in.weight"]["shape"] == [320, 8, 3, 3] and exp["unet.aux_conv_in.weight"]["shape"] == [1024, 4, 3, 3] and len(exp) > 1000
+    assert exp["unet.conv_in.weight"]["shape"] == [320, 8, 3, 3] and exp["unet.aux_conv_in.weight"]["shape"] == [1024, 4, 3, 3] and len(exp) > 900

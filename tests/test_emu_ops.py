@@ -309,3 +309,8 @@ def test_conv3x3_role_swap_kernel(emu_engine, engine_option):
         engine_option(emu_engine, "conv_swap", sw)
         outs.append(emu_engine.op_conv(x, w, b, out_f32=True, split=True, tile_cfg=0))
     assert torch.equal(outs[0], outs[1])
+
+
+def test_conv_split_k(emu_engine, engine_option):
+    """ConvParams::ksplit + splitk_reduce_kernel on the emulator (ops_suite.check_conv_splitk)."""
+    S.check_conv_splitk(emu_engine, DEV, engine_option)

@@ -289,3 +289,13 @@ def test_conv3x3_role_swap_kernel(eng, engine_option):
     S.check_conv(eng, DEV, 1, 32, 64, 512, 384, tile_cfg=0, in_f32=True, out_f32=True, split=True, f8=True, res="f32", seed=83, atol=3e-4)
     counts = eng.lib.kernel_counts()
     assert counts.get("conv3x3_f8_swap<gn>", 0) >= 2 and counts.get("conv3x3_f8_swap", 0) >= 1, counts
+
+
+def test_conv_split_k(eng, engine_option):
+    """ConvParams::ksplit + splitk_reduce_kernel on hardware (ops_suite.check_conv_splitk), plus the shapes the engine splits by itself:
+    the 16x16 U-Net level at one and four images per call."""
+    S.check_conv_splitk(eng, DEV, engine_option)
+    eng.lib.kernel_counts(reset=True)
+    S.check_conv(eng, DEV, 1, 16, 16, 1280, 1280, in_f32=True, out_f32=True, split=True, res="f32", seed=91, atol=3e-5)
+    S.check_conv(eng, DEV, 4, 16, 16, 1280, 640, C1=1280, in_f32=True, out_f32=True, split=True, seed=92, atol=3e-5)
+    assert eng.lib.kernel_counts().get("conv3x3_splitk", 0) == 2, eng.lib.kernel_counts()
