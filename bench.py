@@ -220,6 +220,19 @@ def main():
                          "note": "engine option attn_dense = 1: every key tile of the trimap-biased self-attention is loaded and multiplied"}
             finally:
                 eng.lib.set_option("attn_dense", 0)
+        # ---- the same step with every tile of the VAE encoder's trimap images multiplied (the headline fills the output tiles that lie inside
+        #      a constant region of the trimap from one representative tile - exact, but trimap-dependent): reported next to `value` ----
+        all_tiles = None
+        if world == 1 and not args.timed_only and eng.lib.get_option("trimap_skip") != 0:
+            eng.lib.set_option("trimap_skip", 0)
+            try:
+                step()
+                nd = max(2, args.steps // 2)
+                el_d = timed_steps(step, nd, 1, dev)
+                all_tiles = {"images_per_s": round(B * nd / el_d, 3), "ms_per_step": round(el_d * 1e3 / nd, 3),
+                             "note": "engine option trimap_skip = 0: every output tile of the encoder convs is multiplied, whatever the trimap"}
+            finally:
+                eng.lib.set_option("trimap_skip", 1)
         # ---- roofline of the dominant kernel: per-launch HIP events on the engine stream (separate pass, 1 step) ----
         eng.profile(True)
         eng.apply_matte(img_d, tri_d, S, False, out=alpha, sync=True)
@@ -354,9 +367,12 @@ def main():
                                        "split-fp16 MFMA operands (hi+lo, 3 MFMAs per product), fp32 accumulate, fp32 activations")
                                       if precision == "fp16x3" else "fp16 MFMA operands, fp32 accumulate, fp32 residual stream"),
                        "trimap": "synthetic disc/annulus (28 % foreground / 22 % unknown / 50 % background, SURVEY.md 8d)",
+                       "trimap_encoder_tiles": ("output tiles of the VAE encoder's wide 3x3 convs that lie inside a constant region of the trimap image are filled from "
+                                                "one multiplied tile per (image, region value) - exact; engine option trimap_skip = 0 multiplies all")
+                       if eng.lib.get_option("trimap_skip") != 0 and precision == "fp16x3" else "every tile multiplied",
                        "self_attention_keys": "all key tiles" if args.dense_attention else
                        "key tiles whose (1-m)*-10000 bias underflows the fp32 softmax are not loaded (exact; --dense-attention disables)"},
-            "parity": parity, "modes": modes, "dense_attention": dense, "single_image": b1, "including_host_transfers": incl,
+            "parity": parity, "modes": modes, "dense_attention": dense, "every_trimap_tile_multiplied": all_tiles, "single_image": b1, "including_host_transfers": incl,
             # dense-equivalent algorithmic rate (28.89 TFLOP per 1024^2 image); the self-attention skips the key tiles
             # whose bias underflows the softmax, so the executed attention work depends on the trimap (kernel_breakdown_ms has
             # executed rates per kernel)

@@ -83,4 +83,20 @@ class SDMatteConfig:
         )
 
 
+# (tests) tiny U-Net behind a VAE of 128 | 128 | 512 | 512 channels: the encoder's 3x3 convs then run on the fp8-residual producer / consumer
+# kernel, the one that leaves the constant tiles of the trimap images to a fill kernel
+def _tiny_wide_vae() -> "SDMatteConfig":
+    return SDMatteConfig(
+        vae_channels=(128, 128, 512, 512),
+        unet_channels=(64, 128, 128, 128),
+        unet_heads=(1, 2, 2, 2),
+        cross_attention_dim=64,
+        point_embeddings_input_dim=64,
+        bbox_embeddings_input_dim=256,
+        name="tiny_wide_vae",
+    )
+
+
+SDMatteConfig.tiny_wide_vae = staticmethod(_tiny_wide_vae)
+
 INFERENCE_SIZES = [512, 640, 768, 896, 1024]   # sdmatte_nodes.py:226

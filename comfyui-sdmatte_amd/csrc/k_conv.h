@@ -76,6 +76,12 @@ struct ConvParams {
                                         // 8 skip the epilogue stores -- after the first K-chunk; always 0 in the engine
   int vgrid, tpb;                       // F8 (tpb tiles per block): number of virtual block ids = the grid of the one-tile-per-block forms
   int tiles_m, tiles_n, xcd_chunk;      // 1-D XCD-aware grid (set by launch_conv_t): M tiles per image (9 taps) or in total (1 tap), N tiles, M tiles per XCD
+  int band, img_chunk;                  // optional M-tile order of the 3x3 kernels (band > 0): bands of `band` consecutive M tiles of every image go round-robin over the
+                                        // 8 XCDs (XCD x owns img_chunk tiles of each image) instead of one contiguous 1/8 of the whole batch per XCD - used with
+                                        // tile_flag, whose skipped tiles would otherwise leave the XCDs that own the trimap images idle
+  const unsigned char* tile_flag;       // F8 3x3 kernels, optional [N][tiles_m]: != 0 -> every output pixel of that M tile lies in a region where the layer's input is
+  const int* tile_rep;                  // constant (class id 1..7, k_misc.h cmask_conv_kernel) and the tile's result is the broadcast of one pixel of the class's
+                                        // representative tile tile_rep[img * 8 + class]: such tiles are not computed here (const_tile_fill_kernel writes them)
   int ksplit; size_t ks_stride;         // split-K (register-staged kernels, launch_conv_t): ksplit > 1 -> grid.y = ksplit, block row y multiplies input channels
                                         // [y, y+1) * Cin / ksplit and stores its fp32 partial sums (acc * acc_scale: no bias / residual / statistics) at
                                         // (float*)out + y * ks_stride; splitk_reduce_kernel finishes the layer
@@ -192,6 +198,19 @@ conv_mfma_kernel(ConvParams p) {
 #if defined(SDM_CONV_TRACE) && !defined(SDM_EMU)
   int tr_n = 0;
 #endif
+  // virtual block id -> (linear M tile = image * tiles_m + tile, N tile); false: padding block
+  auto tile_decode = [&](int bid, int& mlin, int& nt) -> bool {
+    const int j = bid >> 3, ml = j / p.tiles_n;
+    nt = j - ml * p.tiles_n;
+    if (NTAPS == 9 && p.band > 0) {
+      const int im = ml / p.img_chunk, r = ml - im * p.img_chunk;
+      const int mt = ((r / p.band) * 8 + (bid & 7)) * p.band + r % p.band;
+      mlin = im * p.tiles_m + mt;
+      return im < p.N && mt < p.tiles_m;
+    }
+    mlin = (bid & 7) * p.xcd_chunk + ml;
+    return mlin < p.tiles_m * (((NTAPS == 9) || p.rows_per_img != 0) ? p.N : 1);
+  };
   u32x4 a_nx[A_PER][IN_F32 ? 2 : 1];
   f32x4 gqn[4];
   // role_c: std::integral_constant<int, R>.  R = 0 / 1: this copy of the tile body is executed by consumer / producer waves only (the F8
@@ -243,15 +262,11 @@ conv_mfma_kernel(ConvParams p) {
   int mt, n0, img = 0, oy0 = 0, ox0 = 0;
   long m0 = 0;
   {
-    const int bid = vbid;
-    const int j = bid >> 3;
-    const int ml = j / p.tiles_n;
-    const int mlin = (bid & 7) * p.xcd_chunk + ml;
+    int mlin, nt;
     const bool per_img = (NTAPS == 9) || p.rows_per_img != 0;
-    if (mlin >= p.tiles_m * (per_img ? p.N : 1)) return;      // padding block of the last XCD range
+    if (!tile_decode(vbid, mlin, nt)) return;      // padding block of the last XCD range
     mt = mlin;
     if (per_img) { img = mlin / p.tiles_m; mt = mlin - img * p.tiles_m; }
-    const int nt = j - ml * p.tiles_n;
     if (NTAPS == 9) {
       const int npx = (p.Wout + TW - 1) / TW;
       oy0 = (mt / npx) * TH;
@@ -809,15 +824,12 @@ conv_mfma_kernel(ConvParams p) {
 #pragma unroll
       for (int i = 0; i < A_PER; ++i) n_pix[i] = -1;
       if (NTAPS == 9 && role && more_tiles && p.xtile && (nch & 1) == 0) {
-        const int bid = vbid + (int)gridDim.x;
-        const int j = bid >> 3;
-        const int ml = j / p.tiles_n;
-        const int mlin = (bid & 7) * p.xcd_chunk + ml;
-        if (mlin < p.tiles_m * p.N) {
+        int mlin, nnt;
+        if (tile_decode(vbid + (int)gridDim.x, mlin, nnt)) {
           has_next = true;
           n_img = mlin / p.tiles_m;
           const int nmt = mlin - n_img * p.tiles_m;
-          n_n0 = (j - ml * p.tiles_n) * BN;
+          n_n0 = nnt * BN;
           const int npx = (p.Wout + TW - 1) / TW;
           const int noy0 = (nmt / npx) * TH, nox0 = (nmt % npx) * TW;
           const int nband0 = ((noy0 * STRIDE - p.pad_t) > 0 ? ((noy0 * STRIDE - p.pad_t) >> p.up) : 0);
@@ -1638,15 +1650,43 @@ conv_mfma_kernel(ConvParams p) {
   }
   };   // run_tile
   if (F8) {
+    // tiles of a constant-input region (ConvParams::tile_flag) are left to const_tile_fill_kernel.  Block-uniform, evaluated identically by both
+    // roles; a tile in front of a skipped one does not prefetch across it, and the bias-table parity counts the tiles that actually ran
+    // bit k of `skip`: the block's k-th tile is left out.  All flags are fetched up front (independent scalar loads: one round trip per block)
+    unsigned int skip = 0;
+    if (NTAPS == 9 && p.tile_flag) {
+      int fl[9], ml9[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) { fl[k] = 0; ml9[k] = 0; }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        if (k >= p.tpb) continue;
+        const int v = (int)blockIdx.x + k * (int)gridDim.x;
+        int nt;
+        if (v < p.vgrid && tile_decode(v, ml9[k], nt)) fl[k] = p.tile_flag[ml9[k]];
+      }
+#pragma unroll
+      for (int k = 0; k < 9; ++k)
+        if (fl[k]) { const int im = ml9[k] / p.tiles_m; if (p.tile_rep[im * 8 + fl[k]] != ml9[k] - im * p.tiles_m) skip |= 1u << k; }
+    }
+    skip = (unsigned int)SDM_UNIFORM_I((int)skip);
     if (SDM_UNIFORM_I((int)threadIdx.x / NT)) {
+      int par = 0;
       for (int k = 0; k < p.tpb; ++k) {
         const int v = (int)blockIdx.x + k * (int)gridDim.x;
-        if (v < p.vgrid) run_tile(std::integral_constant<int, 1>{}, v, k & 1, (k + 1 < p.tpb) && (v + (int)gridDim.x < p.vgrid));
+        if (v < p.vgrid && !((skip >> k) & 1u)) {
+          run_tile(std::integral_constant<int, 1>{}, v, par, (k + 1 < p.tpb) && (v + (int)gridDim.x < p.vgrid) && !((skip >> (k + 1)) & 1u));
+          par ^= 1;
+        }
       }
     } else {
+      int par = 0;
       for (int k = 0; k < p.tpb; ++k) {
         const int v = (int)blockIdx.x + k * (int)gridDim.x;
-        if (v < p.vgrid) run_tile(std::integral_constant<int, 0>{}, v, k & 1, (k + 1 < p.tpb) && (v + (int)gridDim.x < p.vgrid));
+        if (v < p.vgrid && !((skip >> k) & 1u)) {
+          run_tile(std::integral_constant<int, 0>{}, v, par, (k + 1 < p.tpb) && (v + (int)gridDim.x < p.vgrid) && !((skip >> (k + 1)) & 1u));
+          par ^= 1;
+        }
       }
     }
 #if defined(SDM_CONV_TRACE) && !defined(SDM_EMU)

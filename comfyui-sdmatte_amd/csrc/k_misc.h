@@ -219,3 +219,117 @@ __global__ void fill_random_f32_kernel(float* __restrict__ p, long n, unsigned i
     p[i] = ((float)(h & 0xFFFF) * (1.0f / 32768.0f) - 1.0f) * amp;
   }
 }
+
+// ---- piecewise-constant inputs: the trimap half of the VAE encoder's batch.  A trimap is constant over large regions (background, sure
+//      foreground, the inside of the unknown band), and a convolution of a constant region is a constant: every output pixel whose 3x3 window
+//      lies inside one region has the same value, channel by channel - GroupNorm / SiLU / residual adds keep that (per-image, per-channel
+//      maps).  The engine tracks, per activation tensor of that batch, a byte plane [N][H][W]: 0 = nothing known, c = 1..4 = "this pixel is
+//      the image of a region of trimap value class c" (classes = the distinct values of the image's trimap, up to 4; rgb images are all 0).
+//      A conv layer erodes the plane by its window; output TILES whose pixels are all of one class are not multiplied: ONE such tile per
+//      (image, class) is computed by the conv kernel as usual, and const_tile_fill_kernel copies one of its pixels into the others - the
+//      value every one of those pixels would have received (each output pixel is the same chain of operations on the same operands,
+//      independent of its position), and the statistics they would have contributed (count x value, count x value^2).  Exact: nothing
+//      is approximated; the engine option trimap_skip = 0 computes every tile. ----
+#define SDM_CMASK_EMPTY 0xFFFFFFFFu
+
+// class table of one trimap image: up to 4 distinct values among 64 x 64 sample points of the plane (a value that none of the samples hits gets
+// no class - its pixels are simply multiplied).  One block per image; the table is built in LDS and written once: no global atomics.
+__global__ __launch_bounds__(256) void cmask_table_kernel(const float* __restrict__ plane, unsigned int* __restrict__ table, int n0, int H, int W) {
+  SDM_SHARED unsigned int tb[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid < 4) tb[tid] = SDM_CMASK_EMPTY;
+  __syncthreads();
+  const float* pl = plane + (size_t)b * H * W;
+  for (int i = tid; i < 64 * 64; i += 256) {
+    const int y = (int)(((long)(i >> 6) * H) >> 6), x = (int)(((long)(i & 63) * W) >> 6);
+    const unsigned int bits = __builtin_bit_cast(unsigned int, pl[(size_t)y * W + x]);
+    for (int k = 0; k < 4; ++k) {
+      unsigned int cur = tb[k];
+      if (cur == SDM_CMASK_EMPTY) cur = atomicCAS(&tb[k], SDM_CMASK_EMPTY, bits);      // returns the old value: EMPTY = this thread inserted
+      if (cur == SDM_CMASK_EMPTY || cur == bits) break;
+    }
+  }
+  __syncthreads();
+  if (tid < 4) table[(size_t)(n0 + b) * 4 + tid] = tb[tid];
+}
+
+// class plane of the trimap images at the network's input: mask[(n0 + b)][y][x] = 1 + index of the pixel's value in the image's class table, 0 if absent
+__global__ void cmask_init_kernel(const float* __restrict__ plane, unsigned char* __restrict__ mask, const unsigned int* __restrict__ table, int n0, int B, long HW) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * HW) return;
+  const int b = (int)(i / HW);
+  const unsigned int bits = __builtin_bit_cast(unsigned int, plane[i]);
+  const unsigned int* tb = table + (size_t)(n0 + b) * 4;
+  int cls = 0;
+#pragma unroll
+  for (int k = 3; k >= 0; --k)
+    if (tb[k] == bits && bits != SDM_CMASK_EMPTY) cls = k + 1;
+  mask[(size_t)n0 * HW + i] = (unsigned char)cls;
+}
+
+// class plane through a 3x3 conv (stride 1 / 2, the conv's own padding: anything outside the image is padding, i.e. NOT the region's value):
+// mout = c where all nine window pixels are c.  One block = one 8 x 32 output tile (256 threads); tile_flag (optional, [N][tiles]) = c when
+// every pixel of the tile is c; tile_rep[n * 8 + c] = the smallest such tile index (atomicMin; preset to INT_MAX).  grid (tiles, N - n0).
+__global__ __launch_bounds__(256) void cmask_conv_kernel(const unsigned char* __restrict__ min_, int Hin, int Win, unsigned char* __restrict__ mout, int Hout, int Wout,
+                                                         int stride, int pad_t, int pad_l, unsigned char* __restrict__ tile_flag, int* __restrict__ tile_rep, int n0) {
+  SDM_SHARED int red[8];
+  const int tid = threadIdx.x, n = n0 + (int)blockIdx.y;      // images below n0 carry no classes: their planes are never read, their tile flags are preset to 0
+  const int npx = (Wout + 31) / 32;
+  const int mt = blockIdx.x, oy = (mt / npx) * 8 + (tid >> 5), ox = (mt % npx) * 32 + (tid & 31);
+  int c = -1;                                    // -1: pixel outside the image (does not vote)
+  if (oy < Hout && ox < Wout) {
+    const unsigned char* mi = min_ + (size_t)n * Hin * Win;
+    const int iy0 = oy * stride - pad_t, ix0 = ox * stride - pad_l;
+    c = 0;
+    if (iy0 >= 0 && ix0 >= 0 && iy0 + 2 < Hin && ix0 + 2 < Win) {
+      c = mi[(size_t)iy0 * Win + ix0];
+      for (int dy = 0; dy < 3; ++dy)
+        for (int dx = 0; dx < 3; ++dx)
+          if (mi[(size_t)(iy0 + dy) * Win + ix0 + dx] != c) c = 0;
+    }
+    mout[((size_t)n * Hout + oy) * Wout + ox] = (unsigned char)c;
+  }
+  if (!tile_flag) return;
+  // all voting pixels equal and non-zero?  (min == max over the votes; non-voting pixels are neutral)
+  int lo = c < 0 ? 255 : c, hi = c < 0 ? 0 : c;
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) { lo = min(lo, __shfl_xor(lo, s)); hi = max(hi, __shfl_xor(hi, s)); }
+  if ((tid & 63) == 0) { red[tid >> 6] = lo; red[4 + (tid >> 6)] = hi; }
+  __syncthreads();
+  if (tid == 0) {
+    lo = min(min(red[0], red[1]), min(red[2], red[3]));
+    hi = max(max(red[4], red[5]), max(red[6], red[7]));
+    const int f = (lo == hi && lo > 0 && lo < 8) ? lo : 0;
+    tile_flag[(size_t)n * gridDim.x + mt] = (unsigned char)f;
+    if (f) atomicMin(&tile_rep[n * 8 + f], mt);
+  }
+}
+
+// the tiles the F8 conv kernel left out (ConvParams::tile_flag): every pixel = pixel (0, 0) of the class's representative tile (fp32 NHWC, full
+// 8 x 32 tiles), and the two partial statistics rows of the tile (one per 128-pixel wave row, the conv kernel's layout) = 128 x v, 128 x v^2.
+// grid (tiles per image, N - n0), 256 threads.
+__global__ __launch_bounds__(256) void const_tile_fill_kernel(float* __restrict__ out, int C, int Hout, int Wout, const unsigned char* __restrict__ tile_flag,
+                                                              const int* __restrict__ tile_rep, float* __restrict__ stats, int wm_rows, int n0) {
+  const int tid = threadIdx.x, n = n0 + (int)blockIdx.y, mt = blockIdx.x, tiles = gridDim.x;
+  const int f = tile_flag[(size_t)n * tiles + mt];
+  if (!f) return;
+  const int rep = tile_rep[n * 8 + f];
+  if (rep == mt) return;
+  const int npx = Wout / 32, C4 = C / 4;
+  const f32x4* src = (const f32x4*)(out + (((size_t)n * Hout + (size_t)(rep / npx) * 8) * Wout + (size_t)(rep % npx) * 32) * C);
+  const int oy0 = (mt / npx) * 8, ox0 = (mt % npx) * 32;
+  for (int r = 0; r < 8; ++r) {
+    f32x4* dst = (f32x4*)(out + (((size_t)n * Hout + oy0 + r) * Wout + ox0) * C);
+    for (int i = tid; i < 32 * C4; i += 256) dst[i] = src[i % C4];
+  }
+  if (stats) {
+    const float cnt = (float)(256 / wm_rows);
+    for (int ch = tid; ch < C; ch += 256) {
+      const float v = ((const float*)src)[ch];
+      for (int w = 0; w < wm_rows; ++w) {
+        float* st = stats + ((((size_t)n * tiles + mt) * wm_rows + w) * C + ch) * 2;
+        st[0] = cnt * v; st[1] = cnt * (v * v);
+      }
+    }
+  }
+}

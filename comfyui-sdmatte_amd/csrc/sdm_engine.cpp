@@ -102,6 +102,9 @@ static OptEntry g_opts[] = {
   {"conv_pc", -1, -1, "producer / consumer form of the split-precision DMA kernel: -1 by channel count, 0 off, 1 on"},
   {"conv_pc_min_cin", 256, 256, "conv_pc = -1: smallest Cin that takes the producer / consumer form"},
   {"conv_db", 0, 0, "512x128 double-buffered tile where the queue is deep"},
+  {"trimap_skip", 1, 1, "VAE encoder, trimap images: output tiles inside a constant region of the trimap are not multiplied (k_misc.h cmask_*; exact). 0 = every tile"},
+  {"conv_band_rows", 0, 0, "tile rows per XCD band of the convs that leave constant tiles out (0 = by image height)"},
+  {"trimap_skip_min_rows", 256, 256, "smallest output height at which constant tiles are left out (below it nearly every tile touches a region border)"},
   {"conv_splitk", -1, -1, "split-K of the register-staged conv / GEMM kernels: -1 by shape (few tiles, long K), 0 off, n >= 2 forced where the shape allows"},
   {"force_cfg0", 0, 0, "always the 256x128 tile for 3x3 stride 1 (tests: fused GroupNorm at tiny sizes)"},
   {"no_gn_fuse", 0, 0, "never fuse the GroupNorm apply into the consuming conv"},
@@ -293,6 +296,15 @@ static void launch_conv_dma(const ConvParams& p_in, void* stream) {
   p.tiles_n = sdm_cdiv(p.Cout_pad, 128);
   const long total_m = (long)p.tiles_m * p.N;
   p.xcd_chunk = (int)((total_m + 7) / 8);
+  if (p.tile_flag) {
+    // some tiles of some images will be left out (ConvParams::tile_flag): bands of a few tile rows of EVERY image go round-robin over the XCDs, so
+    // that no XCD owns only the images (or only the image regions) that are skipped
+    const int npx = sdm_cdiv(p.Wout, 32), rows = sdm_cdiv(p.Hout, 8);
+    const int br = opt("conv_band_rows") > 0 ? opt("conv_band_rows") : std::max(1, std::min(4, rows / 16));
+    p.band = br * npx;
+    p.img_chunk = sdm_cdiv(p.tiles_m, 8 * p.band) * p.band;
+    p.xcd_chunk = p.N * p.img_chunk;
+  }
   const dim3 grid((unsigned)(8L * p.xcd_chunk * p.tiles_n), 1, 1);
   const bool gn = p.gn_scale != nullptr, split = p.w_lo != nullptr;
   const size_t gn_extra = gn ? (size_t)(p.C0 + p.C1) * 8 : 0;
@@ -494,6 +506,9 @@ struct T {  // NHWC activation tensor living in the arena
   float* stats = nullptr;       // [N][srows][C][2] partial {sum, sumsq} rows written by the producing conv epilogue
   int srows = 0;
   size_t soff = 0, sbytes = 0;
+  unsigned char* cmask = nullptr;   // optional class plane [N][H][W] of a piecewise-constant batch (k_misc.h cmask_*): set by vae_encode on the encoder input,
+  size_t cm_off = 0, cm_bytes = 0;  // propagated by op_conv through 3x3 convs; owned by the tensor (freed with it)
+  int cm_n0 = 0;                    // first image of the batch that carries classes (the rgb images in front of it have none)
   long rows() const { return (long)N * H * W; }
 };
 
@@ -518,6 +533,7 @@ struct ProfRec { std::string name, desc; double flops, bytes;
 struct sdm_ctx {
   sdm_config cfg;
   int device = 0;
+  const unsigned char* dbg_cmask = nullptr;      // test hook (sdm_debug_set_input_cmask): class plane of the next sdm_op_conv_ex input
   void* stream = nullptr;
   bool own_stream = false;
   std::string err;
@@ -880,6 +896,7 @@ static void tfree_raw(sdm_ctx* e, size_t off, size_t sz);
 static void tfree(sdm_ctx* e, T& t) {
   if (!t.bytes) return;
   if (t.sbytes) { tfree_raw(e, t.soff, t.sbytes); t.sbytes = 0; t.stats = nullptr; }
+  if (t.cm_bytes) { tfree_raw(e, t.cm_off, t.cm_bytes); t.cm_bytes = 0; t.cmask = nullptr; }
   tfree_raw(e, t.off, t.bytes);
   t.bytes = 0; t.p = nullptr;
 }
@@ -1014,7 +1031,27 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
     p.stats = a.out->stats;
   }
   if (ksplit > 1) ws = talloc(e, 1, 1, 1, (int)((size_t)ksplit * p.M * p.Cout_pad), 1);
-  if (e->dry) { if (ksplit > 1) tfree(e, ws); return 0; }
+  // class plane of a piecewise-constant batch (the trimap images of the VAE encoder, k_misc.h cmask_*): eroded through this conv's window; on the
+  // F8 kernel's full-tile fp32 path the output tiles that lie inside one region are not multiplied - one representative per (image, class) is,
+  // and const_tile_fill_kernel copies it (and its statistics) into the others.  (cm_bytes, not the pointer, drives every decision: the dry pass
+  // has no pointers and must allocate the same way.)
+  const bool cm_prop = a.in0->cm_bytes != 0 && !a.in1 && L.ntaps == 9 && !a.up && opt("trimap_skip") != 0;
+  bool cm_skip = false;
+  T cm_flag, cm_rep;
+  const int cm_tiles = sdm_cdiv(p.Hout, 8) * sdm_cdiv(p.Wout, 32);
+  if (cm_prop) {
+    T mb = talloc(e, 1, 1, 1, (int)(((size_t)p.N * p.Hout * p.Wout + 3) / 4), 1);
+    a.out->cmask = (unsigned char*)mb.p; a.out->cm_off = mb.off; a.out->cm_bytes = mb.bytes; a.out->cm_n0 = a.in0->cm_n0;
+    cm_skip = p.f8 && p.w_dma && cfg == 0 && a.stride == 1 && p.Hout % 8 == 0 && p.Wout % 32 == 0 && p.out_f32 == 1 && !L.geglu && p.out_scale == 1.0f &&
+              p.Cout_valid == p.Cout_pad && p.Cout_pad % 128 == 0 && p.Cout_store == p.Cout_pad && p.out_ch_off == 0 && (!p.res || p.res_f32) && ksplit == 1 &&
+              !opt("conv_swap") && p.Hout >= opt("trimap_skip_min_rows");
+    if (cm_skip) {
+      cm_flag = talloc(e, 1, 1, 1, (p.N * cm_tiles + 3) / 4, 1);
+      cm_rep = talloc(e, 1, 1, 1, p.N * 8, 1);
+      p.tile_flag = (const unsigned char*)cm_flag.p; p.tile_rep = (const int*)cm_rep.p;
+    }
+  }
+  if (e->dry) { if (ksplit > 1) tfree(e, ws); if (cm_skip) { tfree(e, cm_rep); tfree(e, cm_flag); } return 0; }
   const double flops = 2.0 * (double)p.M * L.O * L.I * L.ntaps;
   const double bytes = (double)a.in0->rows() * L.Cin_pad * (p.in_f32 ? 4 : 2) + (double)p.M * p.Cout_valid * (p.out_f32 ? 4 : 2) +
                        (double)L.Cin_pad * L.ntaps * L.Cout_pad * 2 + (a.res ? (double)p.M * p.Cout_valid * (p.res_f32 ? 4 : 2) : 0.0);
@@ -1032,12 +1069,27 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
   int rc = 0;
   // GEMMs that emit per-image GroupNorm statistics for a batch: row tiles aligned to images inside ONE launch
   if (L.ntaps == 1 && p.stats && p.N > 1) p.rows_per_img = p.Hout * p.Wout;
+  if (cm_prop) {
+    const int n0 = a.in0->cm_n0;
+    if (cm_skip) {
+      SDM_CHECK_DEV(e, dev_memset(cm_rep.p, 0x7f, (size_t)p.N * 8 * 4, e->stream));
+      if (n0 > 0) SDM_CHECK_DEV(e, dev_memset(cm_flag.p, 0, (size_t)n0 * cm_tiles, e->stream));
+    }
+    SDM_LAUNCH(cmask_conv_kernel, dim3((unsigned)cm_tiles, (unsigned)(p.N - n0), 1), dim3(256), 0, e->stream, (const unsigned char*)a.in0->cmask, a.in0->H, a.in0->W, a.out->cmask,
+               p.Hout, p.Wout, a.stride, p.pad_t, p.pad_l, cm_skip ? (unsigned char*)cm_flag.p : (unsigned char*)nullptr, cm_skip ? (int*)cm_rep.p : (int*)nullptr, n0);
+    if (cm_skip) count_kernel("conv3x3_f8_const_tiles");
+  }
   if (ksplit > 1) {
     count_kernel(L.ntaps == 9 ? "conv3x3_splitk" : "gemm_splitk");
     rc = launch_conv_splitk(L.ntaps, a.stride, cfg, p, ksplit, (float*)ws.p, e->stream);
     tfree(e, ws);
   } else {
     rc = launch_conv(L.ntaps, a.stride, cfg, p, e->stream);
+  }
+  if (cm_skip) {
+    if (rc == 0) SDM_LAUNCH(const_tile_fill_kernel, dim3((unsigned)cm_tiles, (unsigned)(p.N - a.in0->cm_n0), 1), dim3(256), 0, e->stream, (float*)p.out, p.Cout_store, p.Hout, p.Wout,
+                            p.tile_flag, p.tile_rep, p.stats, 2, a.in0->cm_n0);
+    tfree(e, cm_rep); tfree(e, cm_flag);
   }
   if (rc != 0) SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: bad cfg", L.name.c_str());
 #ifndef SDM_EMU
@@ -1548,10 +1600,28 @@ static int prepare_variants(sdm_ctx* e, int B, const int32_t* is_trans, const fl
 // ------------------------------------------------------------------------------------------------
 // the model: x16 [2B,SH,SW,16] fp16 (rgb images then trimaps), plane [B,SH,SW] fp32 (trimap in [-1,1]) -> alpha [B,SH,SW]
 // ------------------------------------------------------------------------------------------------
-static int vae_encode(sdm_ctx* e, const T& x16, T* moments) {
+// plane (optional): the trimap plane [B][H][W] behind images B .. 2B-1 of x16 - those images are piecewise constant, and the encoder's wide convs do
+// not multiply the output tiles that lie inside one region (k_misc.h cmask_*, op_conv; engine option trimap_skip; split-precision mode only: the F8
+// kernel is the one that knows how to leave tiles out)
+static int vae_encode(sdm_ctx* e, const T& x16, T* moments, const T* plane = nullptr) {
   const float eps = e->cfg.vae_eps;
   T h, t;
-  TRY(conv_simple(e, e->enc_conv_in, x16, &h, e->cfg.vae_channels[0], e->cfg.stream_f32, 1, 0, 0, nullptr, 1.0f, true));
+  T xin = x16;
+  const bool cm = plane && opt("trimap_skip") != 0 && e->act_f32 && x16.N == 2 * plane->N && plane->H == x16.H && plane->W == x16.W;
+  if (cm) {
+    const long hw = (long)x16.H * x16.W;
+    T mb = talloc(e, 1, 1, 1, (int)(((size_t)x16.N * hw + 3) / 4), 1);
+    xin.cmask = (unsigned char*)mb.p; xin.cm_off = mb.off; xin.cm_bytes = mb.bytes; xin.cm_n0 = plane->N;
+    T tab = talloc(e, 1, 1, 1, x16.N * 4, 1);
+    if (!e->dry) {
+      SDM_LAUNCH(cmask_table_kernel, dim3((unsigned)plane->N), dim3(256), 0, e->stream, (const float*)plane->p, (unsigned int*)tab.p, plane->N, x16.H, x16.W);
+      SDM_LAUNCH(cmask_init_kernel, dim3((unsigned)((plane->N * hw + 255) / 256)), dim3(256), 0, e->stream, (const float*)plane->p, xin.cmask, (const unsigned int*)tab.p,
+                 plane->N, plane->N, hw);
+    }
+    tfree(e, tab);
+  }
+  TRY(conv_simple(e, e->enc_conv_in, xin, &h, e->cfg.vae_channels[0], e->cfg.stream_f32, 1, 0, 0, nullptr, 1.0f, true));
+  if (cm) tfree_raw(e, xin.cm_off, xin.cm_bytes);
   for (int i = 0; i < 4; ++i) {
     for (auto& r : e->enc_res[i]) { TRY(resblock(e, r, h, nullptr, eps, &t)); tfree(e, h); h = t; }
     if (i < 3) { TRY(conv_simple(e, e->enc_down[i], h, &t, e->cfg.vae_channels[i], e->cfg.stream_f32, 2, 1, 0, nullptr, 1.0f, true)); tfree(e, h); h = t; }
@@ -1654,7 +1724,7 @@ static int run_model(sdm_ctx* e, const T& x16, const T& plane, int B, int SH, in
   }
   // VAE encode of rgb and trimap as one batch (meta_arch.py:139-145, 209-212)
   T moments;
-  TRY(vae_encode(e, x16, &moments));
+  TRY(vae_encode(e, x16, &moments, &plane));
   // quant_conv -> mean half * scaling_factor, written straight into the 8(+8 pad)-channel U-Net input:
   // channels 0..3 = rgb latent, 4..7 = trimap latent (torch.cat order of meta_arch.py:244)
   T uin = talloc(e, B, lh, lw, 16, e->act_f32);
@@ -2376,6 +2446,7 @@ int sdm_op_conv_ex(sdm_ctx* e, const void* in0, const void* in1, int C0, int C1,
   tin1 = tin0; tin1.p = (void*)in1; tin1.C = C1;
   tout.p = out; tout.N = N; tout.H = Ho; tout.W = Wo; tout.C = Cst; tout.f32 = out_f32;
   tres = tout; tres.p = (void*)res; tres.f32 = res_f32;
+  if (e->dbg_cmask) { tin0.cmask = const_cast<unsigned char*>(e->dbg_cmask); tin0.cm_bytes = 1; e->dbg_cmask = nullptr; }      // (borrowed: tin0 is never tfree'd)
   ConvArgs a; a.in0 = &tin0; a.in1 = in1 ? &tin1 : nullptr; a.out = &tout; a.stride = stride; a.pad_mode = pad_mode; a.up = up;
   a.res = res ? &tres : nullptr; a.out_scale = out_scale; a.force_cfg = tile_cfg; a.cout_valid = Cst;
   int rc;
@@ -2403,6 +2474,14 @@ int sdm_op_conv_ex(sdm_ctx* e, const void* in0, const void* in1, int C0, int C1,
   dev_free(wp); dev_free(bp); if (wl) dev_free(wl);
   if (wd) dev_free(wd);
   return rc;
+}
+
+/* Test hook: `mask` (device, [N][Hin][Win] bytes, class ids 0..4; k_misc.h cmask_*) is the class plane of the input of the NEXT sdm_op_conv_ex call -
+ * the conv then leaves the output tiles of constant regions to const_tile_fill_kernel, as the VAE encoder does for the trimap images. */
+int sdm_debug_set_input_cmask(sdm_ctx* e, const unsigned char* mask) {
+  if (!e) return SDM_ERR_INVALID;
+  e->dbg_cmask = mask;
+  return SDM_OK;
 }
 
 int sdm_op_conv(sdm_ctx* e, const void* in0, const void* in1, int C0, int C1, int in_f32, int N, int Hin, int Win, int up, int stride,

@@ -83,7 +83,7 @@ EXPORTS = [
     "sdm_weight_stats", "sdm_missing_key", "sdm_weight_blob_bytes", "sdm_export_weight_blob", "sdm_import_weight_blob",
     "sdm_host_blob_bytes", "sdm_export_host_blob", "sdm_import_host_blob", "sdm_forward", "sdm_forward_ex", "sdm_forward_rect", "sdm_apply_matte", "sdm_apply_matte_node",
     "sdm_synchronize", "sdm_release_memory", "sdm_resident_bytes", "sdm_weight_bytes", "sdm_last_forward_ms", "sdm_profile_enable", "sdm_profile_count", "sdm_profile_get", "sdm_profile_dump",
-    "sdm_op_conv", "sdm_op_conv_ex", "sdm_debug_run_layer", "sdm_debug_temb_row", "sdm_conv_num_cfgs", "sdm_bench_conv", "sdm_bench_attn", "sdm_op_groupnorm", "sdm_op_layernorm", "sdm_op_attention", "sdm_op_attention_split", "sdm_op_resize_aa",
+    "sdm_op_conv", "sdm_op_conv_ex", "sdm_debug_run_layer", "sdm_debug_set_input_cmask", "sdm_debug_temb_row", "sdm_conv_num_cfgs", "sdm_bench_conv", "sdm_bench_attn", "sdm_op_groupnorm", "sdm_op_layernorm", "sdm_op_attention", "sdm_op_attention_split", "sdm_op_resize_aa",
     "sdm_op_mask_bias",
     "sdm_set_option", "sdm_get_option", "sdm_reset_options", "sdm_option_name", "sdm_option_help", "sdm_kernel_counts", "sdm_kernel_counts_reset",
 ]
@@ -130,6 +130,7 @@ class Bindings:
             "sdm_op_conv_ex": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, i32,
                                      f32, i32, i32, vp, vp, f32, i32, i32]),
             "sdm_debug_run_layer": (i32, [vp, C.c_char_p, vp, i32, i32, i32, vp, i32]),
+            "sdm_debug_set_input_cmask": (i32, [vp, vp]),
             "sdm_debug_temb_row": (i32, [vp, i32, i32, vp, vp, i32]),
             "sdm_conv_num_cfgs": (i32, [i32, i32]),
             "sdm_bench_conv": (f32, [vp] + [i32] * 11),
@@ -409,9 +410,10 @@ class Engine:
 
     # ---- single operators (parity tests) ---------------------------------------------------------
     def op_conv(self, x0, w, bias=None, x1=None, stride=1, pad_mode=0, up=0, res=None, geglu=False, out_f32=False, out_scale=1.0,
-                tile_cfg=-1, split=False, gn=None):
+                tile_cfg=-1, split=False, gn=None, cmask=None):
         """x0/x1: NHWC fp16|fp32 tensors; w: fp32 OIHW or [O,I]; returns NHWC.  split=True: split-fp16 operands (fp32 inputs);
-        gn=(gamma, beta, eps, groups, silu): GroupNorm(+SiLU) of the input fused into the conv's operand staging."""
+        gn=(gamma, beta, eps, groups, silu): GroupNorm(+SiLU) of the input fused into the conv's operand staging.
+        cmask (test hook): uint8 [N,H,W] class plane of x0 (0 = nothing known, 1..4 = pixels of one constant region class)."""
         N, H, W_, C0 = x0.shape
         C1 = x1.shape[-1] if x1 is not None else 0
         ntaps = 9 if (w.dim() == 4 and w.shape[-1] == 3) else 1
@@ -426,6 +428,9 @@ class Engine:
         b = bias.float().contiguous() if bias is not None else None
         gam = gn[0].float().contiguous() if gn is not None else None
         bet = gn[1].float().contiguous() if gn is not None else None
+        if cmask is not None:
+            cmask = cmask.to(torch.uint8).contiguous()
+            self._check(self.lib.sdm_debug_set_input_cmask(self.h, _ptr(cmask)), "sdm_debug_set_input_cmask")
         self._check(self.lib.sdm_op_conv_ex(self.h, _ptr(x0), _ptr(x1), C0, C1, int(x0.dtype == torch.float32), N, H, W_, up, stride,
                                             pad_mode, ntaps, _ptr(w), _ptr(b), O, _ptr(out), int(out_f32), _ptr(res),
                                             int(res is not None and res.dtype == torch.float32), int(geglu), float(out_scale), tile_cfg,

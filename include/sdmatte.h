@@ -218,6 +218,9 @@ int sdm_op_conv_ex(sdm_ctx* ctx, const void* in0, const void* in1, int C0, int C
 /* Test hooks for the exact algebraic folds done at load time (cross-attention K|V fold of aux_conv_in, logit scale in to_q,
  * time/opacity/bbox embedding constants in the conv1 bias tables): run one packed layer by name on an fp32 NHWC input
  * (DEVICE pointers; channel count = the layer's padded input channels), and read one folded bias row (HOST output). */
+/* Test hook: class plane ([N][Hin][Win] bytes on the device; 0 = nothing known, 1..4 = region class) of the input of the NEXT sdm_op_conv_ex call.  The conv
+ * then treats its input as the VAE encoder treats the trimap images ("constant tiles"): output tiles inside one region are filled, not multiplied. */
+int sdm_debug_set_input_cmask(sdm_ctx* ctx, const unsigned char* mask);
 int sdm_debug_run_layer(sdm_ctx* ctx, const char* layer_name, const float* x_nhwc, int N, int H, int W, float* out_nhwc, int Cout);
 int sdm_debug_temb_row(sdm_ctx* ctx, int temb_index, int is_trans, const float* coords4, float* out_host, int cout);
 /* Bench/ablation helper: ms per launch of one conv (random-ish data), HIP-event timed on the engine stream. */

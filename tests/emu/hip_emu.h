@@ -90,6 +90,8 @@ static inline int __any(int pred) {
 static inline float atomicAdd(float* p, float v) { std::lock_guard<std::mutex> g(emu::g_atomic_mu); float o = *p; *p = o + v; return o; }
 static inline double atomicAdd(double* p, double v) { std::lock_guard<std::mutex> g(emu::g_atomic_mu); double o = *p; *p = o + v; return o; }
 static inline unsigned int atomicMax(unsigned int* p, unsigned int v) { std::lock_guard<std::mutex> g(emu::g_atomic_mu); unsigned int o = *p; if (v > o) *p = v; return o; }
+static inline int atomicMin(int* p, int v) { std::lock_guard<std::mutex> g(emu::g_atomic_mu); int o = *p; if (v < o) *p = v; return o; }
+static inline unsigned int atomicCAS(unsigned int* p, unsigned int cmp, unsigned int v) { std::lock_guard<std::mutex> g(emu::g_atomic_mu); unsigned int o = *p; if (o == cmp) *p = v; return o; }
 static inline int atomicAdd(int* p, int v) { std::lock_guard<std::mutex> g(emu::g_atomic_mu); int o = *p; *p = o + v; return o; }
 
 // ---- MFMA 32x32x16 f16 (gfx950): A[i][k]: lane l holds i=l&31, k=8*(l>>5)+j; B[k][n]: n=l&31, same k;

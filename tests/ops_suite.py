@@ -125,6 +125,81 @@ def check_conv_splitk(eng, dev, set_option):
     set_option(eng, "conv_splitk", -1)
 
 
+def check_conv_const_tiles(eng, dev, N=2, H=48, W=160, Cin=128, Cout=128, gn=True, res=True, seed=7):
+    """The F8 3x3 kernel on a piecewise-constant input with a class plane (what the VAE encoder sees for the trimap images): output tiles inside
+    one region are filled from the region's representative tile instead of being multiplied (k_misc.h cmask_*, ConvParams::tile_flag).  The
+    result has to be BIT-IDENTICAL to the same launch without the class plane - every output pixel of a region is the same chain of operations
+    on the same operands - and the launch counter proves that the skipping path ran."""
+    g = _g(seed)
+    cls = torch.zeros(N, H, W, dtype=torch.uint8)
+    # image 0: class 1 everywhere except a noisy blob in a corner and a class-2 band; image 1: nothing known (an "rgb" image)
+    cls[0] = 1
+    cls[0, :14, :40] = 0
+    cls[0, 30:, 100:] = 2
+    vec = torch.randn(3, Cin, generator=g)
+    x = torch.randn(N, H, W, Cin, generator=g)
+    for c in (1, 2):
+        x[cls == c] = vec[c]
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = 0.1 * torch.randn(Cout, generator=g)
+    gn_arg = (1 + 0.2 * torch.randn(Cin, generator=g), 0.1 * torch.randn(Cin, generator=g), 1e-6, 32, True) if gn else None
+    r = None
+    if res:                  # the residual of a ResBlock is constant wherever the block's input was
+        rv = torch.randn(3, Cout, generator=g)
+        r = torch.randn(N, H, W, Cout, generator=g)
+        for c in (1, 2):
+            r[cls == c] = rv[c]
+    kw = dict(tile_cfg=0, split=True, out_f32=True, gn=tuple(t.to(dev) if torch.is_tensor(t) else t for t in gn_arg) if gn else None,
+              res=r.to(dev) if res else None)
+    prev = eng.lib.get_option("conv_f8")
+    eng.lib.set_option("conv_f8", 1)
+    eng.lib.set_option("trimap_skip_min_rows", 8)          # (the engine leaves tiles out from 256 output rows on)
+    try:
+        full = eng.op_conv(x.to(dev), w.to(dev), b.to(dev), **kw).float().cpu()
+        eng.lib.kernel_counts(reset=True)
+        skip = eng.op_conv(x.to(dev), w.to(dev), b.to(dev), cmask=cls.to(dev), **kw).float().cpu()
+        counts = eng.lib.kernel_counts()
+    finally:
+        eng.lib.set_option("conv_f8", prev)
+        eng.lib.set_option("trimap_skip_min_rows", 256)
+    assert counts.get("conv3x3_f8_const_tiles", 0) == 1, counts
+    if gn:      # the stand-alone GroupNorm statistics of this test helper are summed with atomics on hardware: two launches differ in the last bits
+        assert (full - skip).abs().max().item() <= 2e-5 * full.abs().max().item()
+    else:
+        assert torch.equal(full, skip), f"constant-tile fill differs from the multiplied tiles: max|d| = {(full - skip).abs().max().item():.3g}"
+    # and the region really is constant in the output (away from its border), i.e. there was something to skip
+    assert (full[0, 20:28, 48:80] - full[0, 20, 48]).abs().max().item() == 0.0
+
+
+def check_conv_const_tiles_are_really_left_out(eng, dev, N=2, H=40, W=128, Cin=64, Cout=128, seed=11):
+    """The converse of check_conv_const_tiles: a class plane that CLAIMS one constant region over a noise input.  Interior tiles are then filled from
+    the representative tile (the first interior tile) and must differ from the multiplied result - proof that the kernel did not multiply them -
+    while the border tiles (the zero padding breaks the claim there) and the representative are computed as usual."""
+    g = _g(seed)
+    x = torch.randn(N, H, W, Cin, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = 0.1 * torch.randn(Cout, generator=g)
+    cls = torch.ones(N, H, W, dtype=torch.uint8)
+    prev = eng.lib.get_option("conv_f8")
+    eng.lib.set_option("conv_f8", 1)
+    eng.lib.set_option("trimap_skip_min_rows", 8)
+    try:
+        full = eng.op_conv(x.to(dev), w.to(dev), b.to(dev), tile_cfg=0, split=True, out_f32=True).float().cpu()
+        skip = eng.op_conv(x.to(dev), w.to(dev), b.to(dev), tile_cfg=0, split=True, out_f32=True, cmask=cls.to(dev)).float().cpu()
+    finally:
+        eng.lib.set_option("conv_f8", prev)
+        eng.lib.set_option("trimap_skip_min_rows", 256)
+    ty, tx = H // 8, W // 32
+    differs = ((full - skip).abs().amax(dim=3) > 0).reshape(N, ty, 8, tx, 32).permute(0, 1, 3, 2, 4).reshape(N, ty, tx, 256).any(dim=3)
+    expect = torch.zeros(N, ty, tx, dtype=torch.bool)
+    expect[:, 1:ty - 1, 1:tx - 1] = True           # interior tiles: every window inside the image
+    expect[:, 1, 1] = False                        # the representative of (image, class 1): the smallest interior tile index
+    assert torch.equal(differs, expect), (differs, expect)
+    for n in range(N):                             # filled tiles hold ONE pixel of the representative, everywhere
+        rep = skip[n, 8, 32]
+        assert torch.equal(skip[n, 16:24, 32:64], rep.expand(8, 32, -1))
+
+
 def check_groupnorm(eng, dev, N, H, W, C, C1=0, in_f32=True, silu=True, eps=1e-6, seed=0, atol=4e-3):
     g = _g(seed)
     x = torch.randn(N, C + C1, H, W, generator=g) * 1.7 + 0.3

@@ -314,3 +314,10 @@ def test_conv3x3_role_swap_kernel(emu_engine, engine_option):
 def test_conv_split_k(emu_engine, engine_option):
     """ConvParams::ksplit + splitk_reduce_kernel on the emulator (ops_suite.check_conv_splitk)."""
     S.check_conv_splitk(emu_engine, DEV, engine_option)
+
+
+def test_conv_const_tiles_are_filled_not_multiplied(emu_engine):
+    """Piecewise-constant input + class plane through the F8 3x3 kernel: bit-identical to multiplying every tile (ops_suite.check_conv_const_tiles)."""
+    S.check_conv_const_tiles_are_really_left_out(emu_engine, DEV)
+    S.check_conv_const_tiles(emu_engine, DEV)
+    S.check_conv_const_tiles(emu_engine, DEV, N=1, H=40, W=96, Cin=64, Cout=128, gn=False, res=False, seed=8)

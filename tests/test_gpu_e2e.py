@@ -681,3 +681,40 @@ def test_e2e_rectangular_inference(pkg):
         print(f"\n[rect {H}x{W}] max|d|={d.max():.3e} mean|d|={d.mean():.3e}")
         assert out.shape == (2, 1, H, W) and d.max().item() <= TOL
     eng.close()
+
+
+def test_e2e_trimap_constant_tiles_are_filled_not_multiplied(pkg, engine_option):
+    """The VAE encoder's trimap images are piecewise constant: with the engine option trimap_skip (default on) the wide 3x3 convs fill the output tiles
+    that lie inside one region from a representative tile instead of multiplying them.  Same alpha as with the option off (the tiles are bit-identical;
+    the GroupNorm statistics are summed in a different order), both at the oracle's tolerance, and the launch counter shows the path ran."""
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    from comfyui_sdmatte_amd.weights import synthetic_state_dict
+    from comfyui_sdmatte_amd.synth import synthetic_inputs
+    from comfyui_sdmatte_amd import engine as E
+    from oracle import sdmatte_oracle as O
+    cfg = SDMatteConfig.tiny_wide_vae()
+    S_, B = 256, 2
+    w = synthetic_state_dict(cfg, 0)
+    img, tri = synthetic_inputs(B, S_, S_, 4321)
+    yy, xx = torch.meshgrid(torch.arange(S_), torch.arange(S_), indexing="ij")
+    r = ((yy - 60.0) ** 2 + (xx - 70.0) ** 2).sqrt()
+    t0 = torch.where(r < 30, 1.0, torch.where(r < 50, 0.5, 0.0))             # a small object in a corner: most of the image is background
+    tri = torch.stack([t0, t0.flip(0).flip(1)]).reshape(tri.shape).to(tri.dtype)
+    data = O.preprocess(img, tri, S_, False)
+    ref = O.sdmatte_forward(w, cfg.as_dict(), data)
+    lib = E.load_library()
+    outs = {}
+    for skip in (1, 0):
+        engine_option(lib, "trimap_skip", skip)
+        lib.kernel_counts(reset=True)
+        m = _model(cfg, w, None)
+        outs[skip] = m({k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data.items()}).cpu()
+        counts = lib.kernel_counts()
+        ms = m.engine.last_forward_ms()
+        m.engine.close()
+        print(f"trimap_skip={skip}: gpu_ms={ms:.2f} const-tile convs {counts.get('conv3x3_f8_const_tiles', 0)} max|d| vs oracle {(outs[skip] - ref).abs().max():.3e}")
+        assert (counts.get("conv3x3_f8_const_tiles", 0) > 0) == bool(skip), counts
+        assert (outs[skip] - ref).abs().max().item() <= TOL
+    # (the tiles are bit-identical; the statistics of the filled tiles are count x value instead of a sum of equal values, and the variance of a nearly
+    #  constant image amplifies that last-bit difference)
+    assert (outs[1] - outs[0]).abs().max().item() <= 0.5 * TOL

@@ -299,3 +299,12 @@ def test_conv_split_k(eng, engine_option):
     S.check_conv(eng, DEV, 1, 16, 16, 1280, 1280, in_f32=True, out_f32=True, split=True, res="f32", seed=91, atol=3e-5)
     S.check_conv(eng, DEV, 4, 16, 16, 1280, 640, C1=1280, in_f32=True, out_f32=True, split=True, seed=92, atol=3e-5)
     assert eng.lib.kernel_counts().get("conv3x3_splitk", 0) == 2, eng.lib.kernel_counts()
+
+
+def test_conv_const_tiles_are_filled_not_multiplied(eng):
+    """Piecewise-constant input + class plane through the F8 3x3 kernel: bit-identical to multiplying every tile (ops_suite.check_conv_const_tiles);
+    several tiles per block on the larger case (the skipped tiles interrupt the cross-tile prefetch chain)."""
+    S.check_conv_const_tiles_are_really_left_out(eng, DEV)
+    S.check_conv_const_tiles(eng, DEV)
+    S.check_conv_const_tiles(eng, DEV, N=1, H=40, W=96, Cin=64, Cout=128, gn=False, res=False, seed=8)
+    S.check_conv_const_tiles(eng, DEV, N=3, H=256, W=512, Cin=128, Cout=256, seed=9)
