@@ -484,7 +484,7 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_kernel(AttnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// The 8-wave fp8-residual kernel above as a TWO-TILE software pipeline (default for the 8-wave launches with fp32 output; SDM_ATTN_PIPE=0
+// The 8-wave fp8-residual kernel above as a TWO-TILE software pipeline (default for the 8-wave launches with fp32 output; engine option attn_pipe = 0
 // selects attn_d64_kernel<1,3,8>; measured -9 % on those launches, bit-identical results on hardware: profiles/r03_attn_pipe_ab.txt): the Q.K^T MFMAs
 // of key tile t+1 and the softmax of key tile t are independent and sit in ONE basic block, so the scheduler can issue the VALU stream
 // (max / sub / exp / pack: ~1000 cycles per tile) underneath the matrix stream instead of after it; both waves of a SIMD are in the
@@ -493,8 +493,8 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_kernel(AttnParams p) {
 // the barrier is the raw s_barrier behind an LDS-only wait, so the global loads of tile t+3 stay in flight across it.
 // Same arithmetic, same order per query row as attn_d64_kernel<1,3,8>: results are bit-identical (tests/test_emu_ops.py).
 // ------------------------------------------------------------------------------------------------
-// NW = 8 (measured, default): three whole tile buffers.  NW = 4 (SDM_ATTN_PIPE4=1, built at the very end of round 3: bit-identical on the
-// emulator, NOT yet run on hardware): K | pair plane | bias of a tile are read one iteration before its V^T, so they rotate through TWO
+// NW = 8 (measured, default): three whole tile buffers.  NW = 4 (engine option attn_pipe4, on since round 4; bit-identical to attn_d64_kernel<1,3,4> on the
+// emulator and on hardware): K | pair plane | bias of a tile are read one iteration before its V^T, so they rotate through TWO
 // buffers and only V^T through three - 63.5 KB per block, two blocks per CU as for attn_d64_kernel<1,3,4>.
 #define ATTN64PIPE_SMEM (3 * ATTN64P_BUF)
 #define ATTN64PIPE4_KB (2 * 64 * ATTN64_PK + 256)

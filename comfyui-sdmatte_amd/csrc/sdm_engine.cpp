@@ -104,7 +104,7 @@ static OptEntry g_opts[] = {
   {"conv_db", 0, 0, "512x128 double-buffered tile where the queue is deep"},
   {"trimap_skip", 1, 1, "VAE encoder, trimap images: output tiles inside a constant region of the trimap are not multiplied (k_misc.h cmask_*; exact). 0 = every tile"},
   {"conv_band_rows", 0, 0, "tile rows per XCD band of the convs that leave constant tiles out (0 = by image height)"},
-  {"trimap_skip_min_rows", 256, 256, "smallest output height at which constant tiles are left out (below it nearly every tile touches a region border)"},
+  {"trimap_skip_min_rows", 512, 512, "smallest output height at which constant tiles are left out (measured at 1024^2: the 1024- and 512-row levels gain 3.7 + 1.6 ms, the 256-row level loses 0.7: too few of its 32 x 128-pixel tiles lie inside one region)"},
   {"conv_splitk", -1, -1, "split-K of the register-staged conv / GEMM kernels: -1 by shape (few tiles, long K), 0 off, n >= 2 forced where the shape allows"},
   {"force_cfg0", 0, 0, "always the 256x128 tile for 3x3 stride 1 (tests: fused GroupNorm at tiny sizes)"},
   {"no_gn_fuse", 0, 0, "never fuse the GroupNorm apply into the consuming conv"},
@@ -269,7 +269,7 @@ static int conv_pick_ksplit(int ntaps, int stride, int cfg, const ConvParams& p)
 }
 
 // F8 conv kernel: tiles a block runs back to back (the producer waves stage tile k+1 under the epilogue of tile k).  Only when
-// every CU still gets a block: 160 tiles as 80 two-tile blocks measured 0.43 vs 0.26 ms.  SDM_CONV_F8_TPB overrides (A/B).
+// every CU still gets a block: 160 tiles as 80 two-tile blocks measured 0.43 vs 0.26 ms.  The option conv_f8_tpb overrides (A/B).
 static int conv_f8_tiles_per_block(long tiles) {
 #ifdef SDM_EMU
   return tiles >= 6 ? 3 : (tiles >= 2 ? 2 : 1);
@@ -439,7 +439,7 @@ static int launch_conv_splitk(int ntaps, int stride, int cfg, const ConvParams& 
 // ------------------------------------------------------------------------------------------------
 // engine data structures
 // ------------------------------------------------------------------------------------------------
-// Residual terms of the split-precision 3x3 convs on fp8 operands (k_conv.h, F8): default on; SDM_CONV_F8=0 keeps them on fp16
+// Residual terms of the split-precision 3x3 convs on fp8 operands (k_conv.h, F8): default on; the option conv_f8 = 0 keeps them on fp16
 // (the round-2 "fp16x3" arithmetic everywhere).  Read when a model is built: the weight copy is packed for one of the two.
 static bool conv_f8_enabled() { return opt("conv_f8") != 0; }
 
@@ -454,10 +454,10 @@ static int conv_epi_mode() {
 }
 
 // Residual terms of Q.K^T in the split-precision attention cores on fp8 MFMAs (k_attn.h, PREC = 3; q / k arrive as fp16 + e5m2 pair planes):
-// default on; SDM_ATTN_F8=0 keeps them on fp16 MFMAs (PREC = 2, fp16 hi | lo planes).  Read per forward: A/B hook.
+// default on; the option attn_f8 = 0 keeps them on fp16 MFMAs (PREC = 2, fp16 hi | lo planes).  Read per forward: A/B hook.
 static bool attn_f8_enabled() { return opt("attn_f8") != 0; }
 
-// F8 3x3 kernels: cross-tile prefetch by the producer waves (k_conv.h); SDM_CONV_XTILE=0 disables.  Read per launch: A/B hook.
+// F8 3x3 kernels: cross-tile prefetch by the producer waves (k_conv.h); the option conv_xtile = 0 disables.  Read per launch: A/B hook.
 static bool conv_xtile_enabled() { return opt("conv_xtile") != 0; }
 
 static int gemm_f8_min_k() { return opt("gemm_f8_min_k"); }
@@ -643,7 +643,7 @@ struct Builder {
     L.split = (e->cfg.precise_mask & stage) ? 1 : 0;
     if (L.split) { L.w_exp = kSplitWeightExp; L.wlo_off = woff; woff += rupz((size_t)L.Cin_pad * ntaps * L.Cout_pad * 2, 256); }
     // stage-ordered copy for the DMA-weight kernel: split-precision layers only (measured +4..6 % there; neutral with fp16 operands,
-    // where the register-staged kernel stays; SDM_CONV_DMA_ALL=1 builds the copy for every wide 3x3 layer)
+    // where the register-staged kernel stays; the option conv_dma_all = 1 builds the copy for every wide 3x3 layer)
     const bool dma_all = opt("conv_dma_all") != 0;
     if (ntaps == 9 && L.Cout_pad >= 128 && !geglu && (L.split || dma_all)) {
       L.wdma_bytes = (size_t)L.Cin_pad * 9 * L.Cout_pad * 2 * (L.split ? 2 : 1);
@@ -998,7 +998,7 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
   // weights by LDS-DMA (256x128 tile, 3x3 stride 1): the layer keeps a stage-ordered copy of its weights for that kernel
   const bool dma_off = opt("conv_dma") == 0;      // A/B option
   if (!dma_off && L.ntaps == 9 && a.stride == 1 && cfg == 0 && L.w_dma && (!L.split || p.in_f32)) p.w_dma = L.w_dma;
-  {   // producer / consumer form of the split-precision DMA kernel (k_conv.h, PC): SDM_CONV_PC=0 / 1 forces it off / on
+  {   // producer / consumer form of the split-precision DMA kernel (k_conv.h, PC): the option conv_pc = 0 / 1 forces it off / on
     const int pc_opt = opt("conv_pc"), pc_min_cin = opt("conv_pc_min_cin");
     if (p.w_dma && L.split) p.pc = pc_opt >= 0 ? (pc_opt == 1) : (L.Cin_pad >= pc_min_cin);
     if (p.w_dma && L.f8) {
@@ -1035,7 +1035,8 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
   // F8 kernel's full-tile fp32 path the output tiles that lie inside one region are not multiplied - one representative per (image, class) is,
   // and const_tile_fill_kernel copies it (and its statistics) into the others.  (cm_bytes, not the pointer, drives every decision: the dry pass
   // has no pointers and must allocate the same way.)
-  const bool cm_prop = a.in0->cm_bytes != 0 && !a.in1 && L.ntaps == 9 && !a.up && opt("trimap_skip") != 0;
+  // (no plane behind the last level that can leave tiles out: resolutions only shrink from here, up-sampling convs do not propagate)
+  const bool cm_prop = a.in0->cm_bytes != 0 && !a.in1 && L.ntaps == 9 && !a.up && opt("trimap_skip") != 0 && p.Hout >= opt("trimap_skip_min_rows");
   bool cm_skip = false;
   T cm_flag, cm_rep;
   const int cm_tiles = sdm_cdiv(p.Hout, 8) * sdm_cdiv(p.Wout, 32);
@@ -1044,7 +1045,7 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
     a.out->cmask = (unsigned char*)mb.p; a.out->cm_off = mb.off; a.out->cm_bytes = mb.bytes; a.out->cm_n0 = a.in0->cm_n0;
     cm_skip = p.f8 && p.w_dma && cfg == 0 && a.stride == 1 && p.Hout % 8 == 0 && p.Wout % 32 == 0 && p.out_f32 == 1 && !L.geglu && p.out_scale == 1.0f &&
               p.Cout_valid == p.Cout_pad && p.Cout_pad % 128 == 0 && p.Cout_store == p.Cout_pad && p.out_ch_off == 0 && (!p.res || p.res_f32) && ksplit == 1 &&
-              !opt("conv_swap") && p.Hout >= opt("trimap_skip_min_rows");
+              !opt("conv_swap");
     if (cm_skip) {
       cm_flag = talloc(e, 1, 1, 1, (p.N * cm_tiles + 3) / 4, 1);
       cm_rep = talloc(e, 1, 1, 1, p.N * 8, 1);
@@ -1196,7 +1197,7 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
   const int ldvt = rup(Lk, 64);
   T vt = talloc(e, (ap.prec ? 2 : 1) * B, heads, D, ldvt, 0);      // precise: V^T_hi planes of all images, then V^T_lo
   // key tiles whose bias underflows the softmax are skipped (exact, AttnParams::tiles); the engine passes one list per U-Net
-  // level, the stand-alone operator entry builds it here.  SDM_ATTN_DENSE=1 walks every tile (A/B hook).
+  // level, the stand-alone operator entry builds it here.  The option attn_dense = 1 walks every tile (A/B hook).
   const bool dense_attn = opt("attn_dense") != 0;
   const int ntiles64 = sdm_cdiv(Lk, 64);
   T tl_own;
@@ -2736,7 +2737,7 @@ int sdm_op_attention(sdm_ctx* e, const void* q, int ldq, const void* k, int ldk,
 
 /* Split-precision d = 64 attention cores as the default precision runs them.  q [B,Lq,heads*64], k / v [B,Lk,heads*64]: contiguous fp32
  * DEVICE tensors.  They are first turned into the operand planes the producing GEMMs write in the engine (split_planes_kernel: fp16 hi plane
- * + fp16 lo plane, or + e5m2 pair plane when the Q.K^T residual terms run on fp8 MFMAs - the default; SDM_ATTN_F8=0 selects the former),
+ * + fp16 lo plane, or + e5m2 pair plane when the Q.K^T residual terms run on fp8 MFMAs - the default; the option attn_f8 = 0 selects the former),
  * with the logit scale d^-1/2 * log2(e) applied to Q as the engine's to_q weights do; fp32 output [B,Lq,heads*64].  Test hook. */
 int sdm_op_attention_split(sdm_ctx* e, const float* q, const float* k, const float* v, const float* bias, int B, int heads, int Lq, int Lk, float* out) {
   if (e) dev_use(e->device);

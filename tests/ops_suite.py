@@ -153,7 +153,7 @@ def check_conv_const_tiles(eng, dev, N=2, H=48, W=160, Cin=128, Cout=128, gn=Tru
               res=r.to(dev) if res else None)
     prev = eng.lib.get_option("conv_f8")
     eng.lib.set_option("conv_f8", 1)
-    eng.lib.set_option("trimap_skip_min_rows", 8)          # (the engine leaves tiles out from 256 output rows on)
+    eng.lib.set_option("trimap_skip_min_rows", 8)          # (the engine leaves tiles out from 512 output rows on)
     try:
         full = eng.op_conv(x.to(dev), w.to(dev), b.to(dev), **kw).float().cpu()
         eng.lib.kernel_counts(reset=True)
@@ -161,7 +161,7 @@ def check_conv_const_tiles(eng, dev, N=2, H=48, W=160, Cin=128, Cout=128, gn=Tru
         counts = eng.lib.kernel_counts()
     finally:
         eng.lib.set_option("conv_f8", prev)
-        eng.lib.set_option("trimap_skip_min_rows", 256)
+        eng.lib.set_option("trimap_skip_min_rows", 512)
     assert counts.get("conv3x3_f8_const_tiles", 0) == 1, counts
     if gn:      # the stand-alone GroupNorm statistics of this test helper are summed with atomics on hardware: two launches differ in the last bits
         assert (full - skip).abs().max().item() <= 2e-5 * full.abs().max().item()
@@ -188,7 +188,7 @@ def check_conv_const_tiles_are_really_left_out(eng, dev, N=2, H=40, W=128, Cin=6
         skip = eng.op_conv(x.to(dev), w.to(dev), b.to(dev), tile_cfg=0, split=True, out_f32=True, cmask=cls.to(dev)).float().cpu()
     finally:
         eng.lib.set_option("conv_f8", prev)
-        eng.lib.set_option("trimap_skip_min_rows", 256)
+        eng.lib.set_option("trimap_skip_min_rows", 512)
     ty, tx = H // 8, W // 32
     differs = ((full - skip).abs().amax(dim=3) > 0).reshape(N, ty, 8, tx, 32).permute(0, 1, 3, 2, 4).reshape(N, ty, tx, 256).any(dim=3)
     expect = torch.zeros(N, ty, tx, dtype=torch.bool)

@@ -704,6 +704,7 @@ def test_e2e_trimap_constant_tiles_are_filled_not_multiplied(pkg, engine_option)
     ref = O.sdmatte_forward(w, cfg.as_dict(), data)
     lib = E.load_library()
     outs = {}
+    engine_option(lib, "trimap_skip_min_rows", 64)          # (by default only layers with >= 512 output rows leave tiles out)
     for skip in (1, 0):
         engine_option(lib, "trimap_skip", skip)
         lib.kernel_counts(reset=True)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-4 evidence on the final tree: PMC traffic + SQ passes, rocprofv3 kernel stats, the default bench line (1024 CPU baseline + parity)
-T=${1:-r4z}
+T=${1:-r4final}
 mkdir -p gpurun_out/$T
 export TMPDIR=/tmp
 R=$PWD
