@@ -107,6 +107,9 @@ def check_conv_splitk(eng, dev, set_option):
         dict(N=1, H=16, W=16, Cin=128, Cout=64, tile_cfg=2, ks=2, in_f32=True, split=True, out_f32=True, res="f32", atol=3e-5),
         dict(N=1, H=8, W=32, Cin=128, Cout=64, tile_cfg=1, ks=2, in_f32=True, split=True, out_f32=True, atol=3e-5),
         dict(N=1, H=8, W=32, Cin=256, Cout=64, tile_cfg=1, ks=4, out_scale=0.5, res="f16"),
+        # fused GroupNorm staging (the scale | shift table of the whole input in LDS) with a channel range per block: 256 x 64 and 256 x 128 tiles
+        dict(N=2, H=8, W=32, Cin=64, Cout=64, tile_cfg=5, ks=2, gn=(1e-6, True)),
+        dict(N=1, H=16, W=32, Cin=128, Cout=96, tile_cfg=0, ks=4, gn=(1e-5, True), in_f32=True, split=True, out_f32=True, res="f32", atol=3e-5),
         # 3x3 stride 2
         dict(N=1, H=16, W=16, Cin=128, Cout=64, stride=2, tile_cfg=1, ks=2),
         # 1x1 / Linear: cfg 2 (64 rows x 64 co, KC 64), cfg 1 (128 x 64), cfg 4 (256 x 128, KC 32: the fp32-input form)
