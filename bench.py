@@ -209,38 +209,53 @@ def main():
                     "note": "inputs handed over as pageable host buffers: 16 MB H2D + 4 MB D2H per image inside the timed region"}
         # ---- the same step with the self-attention walking EVERY key tile (the headline skips the tiles whose trimap bias underflows
         #      the fp32 softmax - exact, but trimap-dependent): reported next to `value`, never instead of it ----
-        dense = None
-        if world == 1 and not args.timed_only and not args.dense_attention:
-            eng.lib.set_option("attn_dense", 1)
-            try:
-                step()
-                el_d = timed_steps(step, max(2, args.steps // 2), 1, dev)
-                nd = max(2, args.steps // 2)
-                dense = {"images_per_s": round(B * nd / el_d, 3), "ms_per_step": round(el_d * 1e3 / nd, 3),
-                         "note": "engine option attn_dense = 1: every key tile of the trimap-biased self-attention is loaded and multiplied"}
-            finally:
-                eng.lib.set_option("attn_dense", 0)
-        # ---- the same step with every tile of the VAE encoder's trimap images multiplied (the headline fills the output tiles that lie inside
-        #      a constant region of the trimap from one representative tile - exact, but trimap-dependent): reported next to `value` ----
-        all_tiles = None
-        if world == 1 and not args.timed_only and eng.lib.get_option("trimap_skip") != 0:
-            eng.lib.set_option("trimap_skip", 0)
+        def companion(opts, note):
+            """the timed step again with some engine options changed; the previous values (possibly the user's --opt) are restored afterwards"""
+            prev = {k: eng.lib.get_option(k) for k in opts}
+            for k, v in opts.items():
+                eng.lib.set_option(k, v)
             try:
                 step()
                 nd = max(2, args.steps // 2)
                 el_d = timed_steps(step, nd, 1, dev)
-                all_tiles = {"images_per_s": round(B * nd / el_d, 3), "ms_per_step": round(el_d * 1e3 / nd, 3),
-                             "note": "engine option trimap_skip = 0: every output tile of the encoder convs is multiplied, whatever the trimap"}
+                return {"images_per_s": round(B * nd / el_d, 3), "ms_per_step": round(el_d * 1e3 / nd, 3), "note": note}
             finally:
-                eng.lib.set_option("trimap_skip", 1)
-        # ---- roofline of the dominant kernel: per-launch HIP events on the engine stream (separate pass, 1 step) ----
-        eng.profile(True)
-        eng.apply_matte(img_d, tri_d, S, False, out=alpha, sync=True)
-        eng.profile(False)
-        prof = eng.profile_results()
+                for k, v in prev.items():
+                    eng.lib.set_option(k, v)
+        dense = None
+        if world == 1 and not args.timed_only and eng.lib.get_option("attn_dense") == 0:
+            dense = companion({"attn_dense": 1}, "engine option attn_dense = 1: every key tile of the trimap-biased self-attention is loaded and multiplied")
+        # ---- the same step with every tile of the VAE encoder's trimap images multiplied (the headline fills the output tiles that lie inside
+        #      a constant region of the trimap from one representative tile - exact, but trimap-dependent): reported next to `value` ----
+        all_tiles = None
+        if world == 1 and not args.timed_only and eng.lib.get_option("trimap_skip") != 0:
+            all_tiles = companion({"trimap_skip": 0}, "engine option trimap_skip = 0: every output tile of the encoder convs is multiplied, whatever the trimap")
+        # ---- neither of the two input-dependent shortcuts: the trimap-independent rate ----
+        no_short = None
+        if world == 1 and not args.timed_only and (eng.lib.get_option("trimap_skip") != 0 or eng.lib.get_option("attn_dense") == 0):
+            no_short = companion({"trimap_skip": 0, "attn_dense": 1},
+                                 "attn_dense = 1 and trimap_skip = 0 together: every key tile loaded, every conv tile multiplied - what the step costs on ANY trimap")
+        # ---- roofline of the dominant kernel: per-launch HIP events on the engine stream (separate passes, 1 step each).  The roofline is taken
+        #      with trimap_skip = 0: every counted FLOP of the conv family is then a multiplied one (SURVEY 8a(vi) / 8d: utilisation from EXECUTED
+        #      flops); the pass with the engine's defaults is what kernel_breakdown_ms describes and gives the dense-equivalent figure beside it ----
+        def profile_pass():
+            eng.profile(True)
+            eng.apply_matte(img_d, tri_d, S, False, out=alpha, sync=True)
+            eng.profile(False)
+            return eng.profile_results()
+        prof = profile_pass()
+        prof_dump = eng.profile_dump() if args.dump_profile else None
+        prof_exec = prof
+        skip_prev = eng.lib.get_option("trimap_skip")
+        if skip_prev != 0 and not args.timed_only:       # (--timed-only: every step of the run stays identical, for the rocprofv3 summaries)
+            eng.lib.set_option("trimap_skip", 0)
+            try:
+                prof_exec = profile_pass()
+            finally:
+                eng.lib.set_option("trimap_skip", skip_prev)
         if args.dump_profile:
             with open(args.dump_profile, "w") as fh:
-                fh.write(eng.profile_dump())
+                fh.write(prof_dump)
         roof = None
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
         # (profiles/pmc_traffic.json, written by tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE passes, KB units,
@@ -275,13 +290,20 @@ def main():
         # matrix-pipe time per algorithmic product in units of one fp16 MFMA: fp16x3 = 3; fp16 + two fp8 residual terms at twice
         # the rate = 2 (a handful of thin / strided launches of the family stay on 3 and are counted as 2: lower bound)
         mfma_per_product = (2 if f8_res else 3) if precision == "fp16x3" else 1
-        if "conv3x3_mfma" in prof:
-            c = prof["conv3x3_mfma"]
+        if "conv3x3_mfma" in prof_exec:
+            c = prof_exec["conv3x3_mfma"]
             ach = c["flops"] / (c["ms"] * 1e-3) / 1e12 if c["ms"] > 0 else 0.0
+            cd = prof.get("conv3x3_mfma", c)
+            ach_d = cd["flops"] / (cd["ms"] * 1e-3) / 1e12 if cd["ms"] > 0 else 0.0
             roof = {"bound": "mfma", "kernel": "conv_mfma_kernel<9,...> (conv3x3 implicit GEMM)", "achieved": round(ach, 2),
                     "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_PEAK_TFLOPS, 4), "traffic": traffic,
                     "launches_per_step": c["launches"], "avg_launch_us": round(c["ms"] * 1e3 / max(c["launches"], 1), 2),
-                    "flops_per_launch": c["flops"] / max(c["launches"], 1),
+                    "flops_per_launch": c["flops"] / max(c["launches"], 1), "family_ms_per_step": round(c["ms"], 3),
+                    "basis": ("EXECUTED flops: this pass runs with trimap_skip = 0, so every tile of every launch is multiplied" if prof_exec is not prof or skip_prev == 0
+                              else "dense-equivalent flops (--timed-only keeps every step identical: filled tiles are counted as multiplied)"),
+                    "with_constant_tiles_filled": {"achieved_dense_equivalent": round(ach_d, 2), "frac_dense_equivalent": round(ach_d / MFMA_F16_PEAK_TFLOPS, 4),
+                                                   "family_ms_per_step": round(cd["ms"], 3),
+                                                   "note": "the engine's default (what `value` runs): filled tiles counted as if multiplied - NOT a utilisation figure"},
                     "note": f"achieved = ALGORITHMIC flops (2*MAC of the convolution) / time; this precision keeps the matrix pipe busy for "
                             f"{mfma_per_product} fp16-MFMA time(s) per algorithmic product"
                             + (" (x_hi*w_hi on fp16 + the two residual terms on fp8 K=64 MFMAs at twice the rate)" if f8_res else ""),
@@ -372,7 +394,8 @@ def main():
                        if eng.lib.get_option("trimap_skip") != 0 and precision == "fp16x3" else "every tile multiplied",
                        "self_attention_keys": "all key tiles" if args.dense_attention else
                        "key tiles whose (1-m)*-10000 bias underflows the fp32 softmax are not loaded (exact; --dense-attention disables)"},
-            "parity": parity, "modes": modes, "dense_attention": dense, "every_trimap_tile_multiplied": all_tiles, "single_image": b1, "including_host_transfers": incl,
+            "parity": parity, "modes": modes, "dense_attention": dense, "every_trimap_tile_multiplied": all_tiles, "no_input_shortcuts": no_short,
+            "launches_per_step": sum(v["launches"] for v in prof.values()), "single_image": b1, "including_host_transfers": incl,
             # dense-equivalent algorithmic rate (28.89 TFLOP per 1024^2 image); the self-attention skips the key tiles
             # whose bias underflows the softmax, so the executed attention work depends on the trimap (kernel_breakdown_ms has
             # executed rates per kernel)

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libsdmatte_hip.so")
 SOURCES = ["sdm_engine.cpp"]
-HEADERS = ["sdm_common.h", "k_conv.h", "k_conv_f8s.h", "k_norm.h", "k_attn.h", "k_misc.h", os.path.join("..", "..", "include", "sdmatte.h")]
+HEADERS = ["sdm_common.h", "k_conv.h", "k_norm.h", "k_attn.h", "k_misc.h", os.path.join("..", "..", "include", "sdmatte.h")]
 # -fno-slp-vectorize: hipcc's SLP pass turns adjacent scalar fp32 adds / multiplies into v_pk_* plus the v_mov that assemble the pairs -
 # more issue slots than the scalar form, beside MFMAs (measured: -0.5 % step time without it, profiles/r03_no_slp_ab.txt)
 # -amdgpu-sched-strategy=max-ilp: the d=512 attention kernel gains 16 % (9.1 -> 7.6 ms / step), the d=64 one 1 %, the conv kernels (whose
@@ -56,8 +56,15 @@ def build_all(verbose=False, force=False, extra_flags=(), out=None):
         print(r.stderr[-4000:])
     # a kernel whose body the HOST pass rejects (e.g. inline asm that is only valid for gfx950) is dropped without a diagnostic and leaves
     # an undefined stub symbol: load the library once so that this fails here, in the build container, and not on the GPU box
-    import ctypes
-    ctypes.CDLL(lib)
+    # (in a child process: the library must not stay mapped in the builder - a later rebuild to the same path would otherwise meet a stale mapping - and a
+    # host without a loadable HIP runtime must not fail an otherwise good build: only an undefined SYMBOL is a build error)
+    chk = subprocess.run([sys.executable, "-c", "import ctypes, sys; ctypes.CDLL(sys.argv[1])", lib], capture_output=True, text=True)
+    if chk.returncode != 0:
+        if "undefined symbol" in chk.stderr:
+            sys.stderr.write(chk.stderr)
+            raise RuntimeError("libsdmatte_hip.so has an undefined symbol: a kernel body was dropped by the host pass")
+        if verbose:
+            print("[sdmatte] note: the built library could not be loaded on this host (no HIP runtime?): " + chk.stderr.strip().splitlines()[-1])
     with open(stamp_file, "w") as f:
         f.write(stamp)
     return lib

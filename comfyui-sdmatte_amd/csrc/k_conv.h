@@ -117,17 +117,29 @@ struct ConvCfg {
   // DMAB (weights by LDS-DMA): two A tiles (fp16: double buffer; SPLIT: hi | lo) + a ring of 4 weight stages, one stage = the 3 taps
   // of one kernel column dx for BN output channels in half-plane layout (2 x 3 x BN rows of 16 B)
   // one weight unit: 2 planes x (3 taps dy | 1) x BN rows of 16 B.  F8 rings: 3x3 = 3 steps x 2 units, 1x1 = 3 steps (chunks) x 4 units
-  static constexpr int DMA_SLOT = (NTAPS == 9 ? 96 : 32) * BN, DMA_SLOTS = F8 ? (NTAPS == 9 ? 6 : 12) : (PC ? 5 : 4);      // PC: weights land TWO stages ahead of their use (fragment prefetch across the barrier)
-  static constexpr int TILE_BYTES = DMAB ? (PC ? 4 : 2) * A_BYTES + DMA_SLOTS * DMA_SLOT
+  // R4 (the F8 3x3 kernel): ONE A buffer (fp16 high planes | fp8 region) - the next chunk waits in the producers' registers and is written when the
+  // region it replaces has been read for the last time - and a ring of FOUR weight steps, so that a step's DMAs have two steps to land
+  static constexpr int R4 = (F8 && NTAPS == 9) ? 1 : 0;
+  static constexpr int DMA_SLOT = (NTAPS == 9 ? 96 : 32) * BN, DMA_SLOTS = F8 ? (NTAPS == 9 ? 8 : 12) : (PC ? 5 : 4);      // PC: weights land TWO stages ahead of their use (fragment prefetch across the barrier)
+  static constexpr int TILE_BYTES = DMAB ? (R4 ? 2 : PC ? 4 : 2) * A_BYTES + DMA_SLOTS * DMA_SLOT
                                          : (SPLIT ? 2 : 1) * A_BYTES + B_BYTES;   // one K-chunk of A halo (SPLIT: high and low parts) + B taps
   static constexpr int SMEM = ((DB ? 2 : 1) * TILE_BYTES) > STG_BYTES ? ((DB ? 2 : 1) * TILE_BYTES) : STG_BYTES;
-  // F8 kernels, behind the tiles: two bias tables (BN floats each) | [traced builds: parked stamps]
+  // F8 kernels: two bias tables (BN floats each) | [traced builds: parked stamps]
 #ifdef SDM_CONV_TRACE
   static constexpr int TRACE_BYTES = 1792;      // 64 consumer + 384 producer stamps
 #else
   static constexpr int TRACE_BYTES = 0;
 #endif
   static constexpr int F8_EXTRA = 2 * BN * 4 + TRACE_BYTES;
+  // LDS map of the F8 kernels.  1x1: A (two buffers) | ring | bias tables | stamps; the epilogue's scratch (statistics / staged stores) is the second A buffer.
+  // 3x3 (R4): A | bias tables | ring of 4 steps | tail; the epilogue's scratch starts at ring step 3 - free from a tile's last barrier until the next
+  // tile's first step (the prologue / cross-tile prefetch fills steps 0 - 2 only) - and runs into the tail
+  static constexpr int BIAS_OFF = R4 ? 2 * A_BYTES : TILE_BYTES;
+  static constexpr int RING_OFF = R4 ? 2 * A_BYTES + 2 * BN * 4 : (PC ? 4 : 2) * A_BYTES;
+  static constexpr int SCR_OFF = R4 ? RING_OFF + 6 * DMA_SLOT : 2 * A_BYTES;
+  static constexpr int TRACE_OFF = R4 ? SCR_OFF + STG_BYTES : TILE_BYTES + 2 * BN * 4;
+  static constexpr int SMEM_F8 = R4 ? SCR_OFF + STG_BYTES + TRACE_BYTES : SMEM + F8_EXTRA;      // dynamic LDS of an F8 launch
+  static_assert(!R4 || SMEM_F8 <= 160 * 1024, "LDS of the F8 3x3 kernel");
   static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of 32x32");
   static_assert(KC % 16 == 0, "KC multiple of the MFMA K (16)");
   static_assert(!DB || KC == 16, "swizzled double-buffered tiles assume 2 halves per row");
@@ -213,6 +225,7 @@ conv_mfma_kernel(ConvParams p) {
   };
   u32x4 a_nx[A_PER][IN_F32 ? 2 : 1];
   f32x4 gqn[4];
+  u32x4 f8h[A_PER];                // F8 3x3 producers: [x_lo8 | x8] image of the chunk whose high planes were written last (crosses the tile boundary like a_nx)
   // role_c: std::integral_constant<int, R>.  R = 0 / 1: this copy of the tile body is executed by consumer / producer waves only (the F8
   // tile loop below branches on the role ONCE and instantiates the body per role, so that neither role's registers - the consumers'
   // accumulators and epilogue, the producers' staging sets and the chunk they carry across tiles - are live inside the other's code:
@@ -237,13 +250,20 @@ conv_mfma_kernel(ConvParams p) {
   auto stamp = [&](int first = 0) {
     if (tr_on && tr_n < (ROLE_C > 0 ? 383 : 63)) {      // wave-uniform: the count stays in an SGPR
       const unsigned int t = (unsigned int)__builtin_amdgcn_s_memtime();
-      unsigned int* tr_buf = (unsigned int*)(smem + C::TILE_BYTES + 2 * BN * 4) + (ROLE_C > 0 ? 64 : 0);
+      unsigned int* tr_buf = (unsigned int*)(smem + C::TRACE_OFF) + (ROLE_C > 0 ? 64 : 0);
       if (tid == 0) tr_buf[tr_n] = first ? (t | 1u) : (t & ~1u);
       ++tr_n;
     }
   };
 #else
   auto stamp = [&](int first = 0) { (void)first; };
+#endif
+  // -DSDM_CONV_TRACE2 (with SDM_CONV_TRACE): four more stamps inside every producer step - after the LDS writes / register hand-over, after the DMA
+  // issue, after the load issue, after the transform - tools/conv_trace.py --fine
+#if defined(SDM_CONV_TRACE2) && defined(SDM_CONV_TRACE) && !defined(SDM_EMU)
+  auto stamp2 = [&]() { stamp(); };
+#else
+  auto stamp2 = [&]() {};
 #endif
   // -DSDM_CONV_LAB builds (tools/conv_lab.py) only - differential timing of the F8 3x3 kernel, results are garbage: ConvParams::ablate bit 0 =
   // activation loads from a 64-pixel window (cache-resident), 1 = no weight DMAs after a tile's first two steps, 2 = no MFMAs, 4 = no
@@ -320,7 +340,7 @@ conv_mfma_kernel(ConvParams p) {
   const int ch_lane = n0 + wn * WTN + 4 * (lane >> 5);        // first output channel of this lane's register quad (j, g) = ch_lane + j * 32 + 8 * g
   // bias of the tile's BN output channels: written by the producer waves in their prologue (two tables: the consumers may still read
   // the previous tile's while the next prologue runs), read by the accumulator-layout epilogue
-  float* bias_tab = (float*)(smem + C::TILE_BYTES) + tile_par * BN;
+  float* bias_tab = (float*)(smem + C::BIAS_OFF) + tile_par * BN;
   auto acc_init_residual = [&]() {
   if (FASTEPI && res_init) {
     // the residual is the accumulators' initial value: out = (acc + bias) + res.  F8 layers carry acc_scale == 1 (their fp16 high parts
@@ -680,7 +700,7 @@ conv_mfma_kernel(ConvParams p) {
   if (DMAB) {
     constexpr int SLOT = C::DMA_SLOT, NPR = SPLIT ? 2 : 1, PLANE = 3 * BN * 16;      // PLANE: one k-half plane of a stage (3 dy x BN rows)
     unsigned char* Aring = smem;
-    unsigned char* Bring = smem + (PC ? 4 : 2) * C::A_BYTES;
+    unsigned char* Bring = smem + C::RING_OFF;
     const int nchunks = Cin / 16, nst = nchunks * 3 * NPR;
     const sdm_rsrc rsd = sdm_make_rsrc(p.w_dma, (unsigned int)((size_t)Cin * 9 * NPR * p.Cout_pad * 2));
     const int wv = SDM_UNIFORM_I(wave);
@@ -817,10 +837,14 @@ conv_mfma_kernel(ConvParams p) {
       // that the transform of the next chunk can be spread evenly over the six steps of the current one (one vector per step)
       // (a_nx / gqn live at kernel scope: they carry the next tile's chunk 1 across the tile boundary)
       // ---- the NEXT tile of this block, as far as the producers need it (3x3 only; even chunk counts keep the A buffer parity) ----
-      bool has_next = false;
+      bool has_next = false, chk_nxt = true;
+      // a halo pixel of this tile lies outside the image (zero padding): only then the staged values need the per-pixel test (xform)
+      const bool chk_cur = (NTAPS == 9) ? (SDM_UNIFORM_I((int)((oy0 * STRIDE - p.pad_t < 0) || (oy0 * STRIDE - p.pad_t + C::HPH > Hl) ||
+                                                            (ox0 * STRIDE - p.pad_l < 0) || (ox0 * STRIDE - p.pad_l + HPW > Wl))) != 0) : true;
       int n_img = 0, n_n0 = 0;
       int n_pix[A_PER];
       sdm_rsrc n_rs0 = rs0, n_rs1 = rs1;
+      sdm_rsrc_raw n_rq0 = rq0, n_rq1 = rq1;      // (3x3: the per-step loads go through inline asm, below)
 #pragma unroll
       for (int i = 0; i < A_PER; ++i) n_pix[i] = -1;
       if (NTAPS == 9 && role && more_tiles && p.xtile && (nch & 1) == 0) {
@@ -832,6 +856,8 @@ conv_mfma_kernel(ConvParams p) {
           n_n0 = nnt * BN;
           const int npx = (p.Wout + TW - 1) / TW;
           const int noy0 = (nmt / npx) * TH, nox0 = (nmt % npx) * TW;
+          chk_nxt = SDM_UNIFORM_I((int)((noy0 * STRIDE - p.pad_t < 0) || (noy0 * STRIDE - p.pad_t + C::HPH > Hl) || (nox0 * STRIDE - p.pad_l < 0) ||
+                                        (nox0 * STRIDE - p.pad_l + HPW > Wl))) != 0;
           const int nband0 = ((noy0 * STRIDE - p.pad_t) > 0 ? ((noy0 * STRIDE - p.pad_t) >> p.up) : 0);
           const int nband_rows = ((p.Hin - nband0) < (C::HPH + 1) ? (p.Hin - nband0) : (C::HPH + 1));
 #pragma unroll
@@ -846,9 +872,23 @@ conv_mfma_kernel(ConvParams p) {
           const size_t base_px = ((size_t)n_img * p.Hin + nband0) * p.Win, npxs = (size_t)nband_rows * p.Win;
           n_rs0 = sdm_make_rsrc((const unsigned char*)p.in0 + base_px * p.C0 * es, (unsigned int)(npxs * p.C0 * es));
           n_rs1 = sdm_make_rsrc(p.in1 ? (const unsigned char*)p.in1 + base_px * p.C1 * es : (const unsigned char*)p.in0, p.in1 ? (unsigned int)(npxs * p.C1 * es) : 0u);
+          n_rq0 = sdm_make_rsrc_raw((const unsigned char*)p.in0 + base_px * p.C0 * es, (unsigned int)(npxs * p.C0 * es));
+          n_rq1 = sdm_make_rsrc_raw(p.in1 ? (const unsigned char*)p.in1 + base_px * p.C1 * es : (const unsigned char*)p.in0, p.in1 ? (unsigned int)(npxs * p.C1 * es) : 0u);
         }
       }
       const unsigned int n_dma_voff = (unsigned int)((n_n0 + lane) * 16);
+      // the same six pieces with the address arithmetic hoisted (3x3 step loop): this wave's pieces are (unit, plane) = (wave >> 1, wave & 1) x
+      // (dy = k >> 1, channel half = k & 1), i.e. consecutive 1 KB blocks in LDS and rows g, g + stage_rows, g + 2 stage_rows of the packed tensor -
+      // two scalar adds per piece instead of the ten the generic index expression compiled to (a producer wave issues one instruction per 4 cycles)
+      const unsigned int g_wave = (unsigned int)((wv >> 1) * 6 + (wv & 1) * 3) * stage_rows, sr12 = 12u * stage_rows;
+      const unsigned int l_wave = (unsigned int)(C::RING_OFF + (wv >> 1) * SLOT + (wv & 1) * PLANE);
+      const unsigned int dv0 = dma_voff, dv1 = dma_voff + 1024u, ndv0 = n_dma_voff, ndv1 = n_dma_voff + 1024u;
+      auto dma_fast = [&](int t, int sl, unsigned int v0, unsigned int v1) {
+        const unsigned int g = (unsigned int)t * sr12 + g_wave;
+        unsigned char* d = smem + l_wave + sl * STEP;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sdm_glds16_buf(rs8, (k & 1) ? v1 : v0, g + (unsigned int)(k >> 1) * stage_rows, d + k * 1024);
+      };
       // nxt: addresses of the next tile (cross-tile prefetch)
       auto issue_loads_nx = [&](int c0, bool nxt = false) {
         const bool second = c0 >= p.C0;
@@ -872,6 +912,58 @@ conv_mfma_kernel(ConvParams p) {
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) { a_raw[i][0] = a_nx[i][0]; if (IN_F32) a_raw[i][IN_F32 ? 1 : 0] = a_nx[i][IN_F32 ? 1 : 0]; }
         if (GN) { gq[0] = gqn[0]; gq[1] = gqn[1]; gq[2] = gqn[2]; gq[3] = gqn[3]; }
+      };
+      // ---- 3x3: the same loads ONE VECTOR PER STEP, through inline asm (the compiler's own wait-count bookkeeping knows nothing of them: a wait it
+      // inserted for one of them would drain the DMA queue) ----
+      // (one descriptor: the launcher guarantees gn_shift = gn_scale + N * Cin - both halves of one scratch tensor, sdm_engine.cpp gn_scale_shift)
+      const sdm_rsrc_raw rq_gs = sdm_make_rsrc_raw(p.gn_scale, GN ? (unsigned int)((size_t)p.N * Cin * 8) : 0u);
+      const unsigned int gh_delta = (unsigned int)((size_t)p.N * Cin * 4);
+      auto issue_nx_vec = [&](int i0, const sdm_rsrc_raw rq, unsigned int Cs, unsigned int cc, bool nxt) {      // vector i0 of a chunk -> a_nx[i0]
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+          if (i != i0) continue;
+          // (both values pinned in registers first: left to itself the optimiser selects between the two ADDRESSES, which keeps both
+          //  arrays in scratch memory - a scratch load and a vmcnt(0) in every step)
+          int pa = a_pix[i], pn = n_pix[i];
+          SDM_OPAQUE_I(pa); SDM_OPAQUE_I(pn);
+          const int px0 = nxt ? pn : pa;
+          const int px = lab_win ? (px0 & 63) : px0;
+          const unsigned int off = px >= 0 ? SDM_UMUL24((unsigned int)px, Cs) + cc : SDM_BUF_INVALID;      // px < 11 rows x Win, Cs <= 10 KB: 24-bit operands
+          SDM_ASM_BUFFER_LOAD16_FIRST(a_nx[i][0], off, rq, 0);
+          if (IN_F32) SDM_ASM_BUFFER_LOAD16(a_nx[i][IN_F32 ? 1 : 0], off, rq, 16);
+        }
+      };
+      auto issue_nx_gn = [&](int c0, bool nxt) {                // GroupNorm scale / shift of this thread's 8 channels in that chunk -> gqn
+        if (GN) {
+          const unsigned int off = (unsigned int)(((nxt ? n_img : img) * Cin + c0 + a_part) * 4), offh = off + gh_delta;
+          u32x4 t0, t1, t2, t3;
+          SDM_ASM_BUFFER_LOAD16_FIRST(t0, off, rq_gs, 0);
+          SDM_ASM_BUFFER_LOAD16(t1, off, rq_gs, 16);
+          SDM_ASM_BUFFER_LOAD16(t2, offh, rq_gs, 0);
+          SDM_ASM_BUFFER_LOAD16(t3, offh, rq_gs, 16);
+          gqn[0] = __builtin_bit_cast(f32x4, t0); gqn[1] = __builtin_bit_cast(f32x4, t1); gqn[2] = __builtin_bit_cast(f32x4, t2); gqn[3] = __builtin_bit_cast(f32x4, t3);
+        }
+      };
+      // a_raw[i0] <- a_nx[i0] (loaded six steps ago: every step's end waits for everything older than the two youngest steps' operations).
+      // The empty asm pins the copy BEHIND the waits and barriers in between: for the compiler an asm load's result exists at once
+      auto take_vec = [&](int i0) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+          if (i != i0) continue;
+#ifndef SDM_EMU
+          asm volatile("" : "+v"(a_nx[i][0]), "+v"(a_nx[i][IN_F32 ? 1 : 0]) :: "memory");
+#endif
+          a_raw[i][0] = a_nx[i][0];
+          if (IN_F32) a_raw[i][IN_F32 ? 1 : 0] = a_nx[i][IN_F32 ? 1 : 0];
+        }
+      };
+      auto take_gn = [&]() {
+        if (GN) {
+#ifndef SDM_EMU
+          asm volatile("" : "+v"(gqn[0]), "+v"(gqn[1]), "+v"(gqn[2]), "+v"(gqn[3]) :: "memory");
+#endif
+          gq[0] = gqn[0]; gq[1] = gqn[1]; gq[2] = gqn[2]; gq[3] = gqn[3];
+        }
       };
       if (NTAPS == 1) {
         // ---- 1x1 / Linear GEMM in the same form.  One step = one 32-channel chunk = four 4 KB weight units (w_hi ch 0-15 | w_hi
@@ -981,66 +1073,203 @@ conv_mfma_kernel(ConvParams p) {
           }
         }
       } else {
-      auto write_bias_tab = [&](float* tab, int im, int nn0) {   // bias of a tile's output channels -> LDS (read by the consumers' accumulator-layout epilogue)
+      // ---- 3x3 (ConvCfg::R4).  ONE A buffer and a ring of FOUR weight steps.  The chunk being staged (c + 1, or chunk 0 of the block's next tile) lives in
+      // the producers' registers while chunk c is multiplied: one vector per step is transformed (GroupNorm, SiLU, fp16 high part, e5m2 pair) into
+      // registers (in place, below); the high planes are written during step 5 of chunk c (S2 of the last kernel column: the consumers read only the fp8 region),
+      // the fp8 region during step 0 of chunk c + 1 (S1: only the high planes are read) - or, for a tile's chunk 0, in front of the tile's first
+      // barrier.  The 43.5 KB this frees hold the fourth weight step: the DMAs of step t + 3 are issued at the start of step t and have to be
+      // visible when the barrier of step t + 1 releases - two steps of landing time.  That matters once per chunk: the activation loads of chunk
+      // c + 2 (first touch of HBM, ~4.5 k cycles under this kernel's traffic) are issued at step 0, vector-memory operations return in order, and
+      // with one step of landing time the DMAs queued behind them stalled every chunk by 1.5 - 1.8 k cycles (profiles/r04_conv_f8_step_trace.txt).
+      // Ring slot of step t = t & 3 = (cm + k) & 3 with cm = (6 c) & 3 = 2 (c & 1), a wave-uniform run-time value: the producers' DMA destinations
+      // are scalar anyway (M0), the consumers add the slot's offset to their fragment bases once per step (a handful of VALU adds beside 48 MFMAs).
+      // The staged chunk is transformed IN PLACE: a_raw[i][0] becomes the vector's fp16 high parts, a_raw[i][1] its [x_lo8 | x8] image. ----
+      static_assert(NTAPS != 9 || !F8 || A_PER == 6, "one vector of the next chunk per step");
+      // bias of a tile's BN output channels -> LDS (read by the consumers' accumulator-layout epilogue, a whole tile later), by LDS-DMA: no register,
+      // no wait - a load + ds_write here made the compiler drain the whole vector-memory queue (every DMA and activation load in flight) once
+      // per tile.  Each wave copies 64 floats (waves 2 / 3 repeat those of waves 0 / 1); channels beyond Cout_pad read 0 (descriptor bounds)
+      auto dma_bias_tab = [&](float* tab, int im, int nn0) {
         const float* bsrc = p.bias;
-        if (bsrc && p.bias_sel) bsrc += (size_t)p.bias_sel[im] * p.Cout_pad;
-        if (tid < BN) tab[tid] = (bsrc && nn0 + tid < p.Cout_pad) ? bsrc[nn0 + tid] : 0.0f;
+        const int sel = (bsrc && p.bias_sel) ? SDM_UNIFORM_I(p.bias_sel[im]) : 0;
+        const sdm_rsrc rb = sdm_make_rsrc(bsrc ? bsrc + (size_t)sel * p.Cout_pad : (const float*)p.w, bsrc ? (unsigned int)p.Cout_pad * 4u : 0u);
+        sdm_glds4_buf(rb, (unsigned int)((nn0 + (wv & 1) * 64 + lane) * 4), 0u, (unsigned char*)tab + (wv & 1) * 256);
+      };
+      // vector i of this thread: raw fp32 (a_raw[i][0 | 1]) -> a_raw[i][0] = high parts, a_raw[i][1] = fp8 image.
+      // A producer wave issues ONE instruction per four cycles at best, and it has to stage a vector per step beside the DMA and load issue: every
+      // instruction here is 1/400 of a step.  Hence: ONE conversion per pair to fp16 (v_cvt_pk_f16_f32) whose halves are converted back for the low
+      // parts, SILU / CHK (zero padding stays zero after the normalisation:
+      // only tiles at the image border have such pixels) as compile-time variants chosen by a wave-uniform branch, no per-lane validity test
+      // (vectors beyond the tile are transformed like the others and dropped by the LDS writes).
+      auto xform = [&](const bool SILU, const bool CHK, int i0, bool nxt) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+          if (i != i0) continue;
+          const f32x4 v0 = __builtin_bit_cast(f32x4, a_raw[i][0]), v1 = __builtin_bit_cast(f32x4, a_raw[i][IN_F32 ? 1 : 0]);
+          float y[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) y[e] = e < 4 ? v0[e & 3] : v1[e & 3];
+          if (GN) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = y[e] * (e < 4 ? gq[0][e & 3] : gq[1][e & 3]) + (e < 4 ? gq[2][e & 3] : gq[3][e & 3]);
+            if (SILU) {
+              // stage by stage over the eight values (not value by value): every transcendental has seven independent instructions behind it
+              float t[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) t[e] = y[e] * (-SDM_LOG2E);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) t[e] = sdm_exp2(t[e]);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) t[e] = t[e] + 1.0f;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) t[e] = sdm_rcp(t[e]);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) y[e] = y[e] * t[e];
+            }
+            if (CHK) {
+              int pa = a_pix[i], pn = n_pix[i];      // (pinned in registers: see issue_nx_vec)
+              SDM_OPAQUE_I(pa); SDM_OPAQUE_I(pn);
+              const bool inside = (nxt ? pn : pa) >= 0;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) y[e] = inside ? y[e] : 0.0f;
+            }
+          }
+          // one clamp keeps hi, x8 and x_lo8 finite (e5m2 has the range of fp16)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) y[e] = SDM_MED3(y[e], -F8_AMAX, F8_AMAX);
+          u32x4 hq, q;
+          float lo[8];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f16x2 h2 = __builtin_convertvector(f32x2{y[2 * j], y[2 * j + 1]}, f16x2);      // ONE v_cvt_pk_f16_f32 per pair
+            hq[j] = __builtin_bit_cast(unsigned int, h2);
+            lo[2 * j] = (y[2 * j] - (float)h2[0]) * F8_LS;
+            lo[2 * j + 1] = (y[2 * j + 1] - (float)h2[1]) * F8_LS;
+          }
+          int l0 = SDM_CVT_PK_BF8(lo[0], lo[1], 0, false), l1 = SDM_CVT_PK_BF8(lo[4], lo[5], 0, false);
+          l0 = SDM_CVT_PK_BF8(lo[2], lo[3], l0, true); l1 = SDM_CVT_PK_BF8(lo[6], lo[7], l1, true);
+          int x0 = SDM_CVT_PK_BF8(y[0], y[1], 0, false), x1 = SDM_CVT_PK_BF8(y[4], y[5], 0, false);
+          x0 = SDM_CVT_PK_BF8(y[2], y[3], x0, true); x1 = SDM_CVT_PK_BF8(y[6], y[7], x1, true);
+          q[0] = (unsigned int)l0; q[1] = (unsigned int)l1; q[2] = (unsigned int)x0; q[3] = (unsigned int)x1;
+          a_raw[i][0] = hq;
+          a_raw[i][IN_F32 ? 1 : 0] = q;
+        }
+      };
+      // the variant of a step: SiLU is a property of the layer; the zero-padding test is needed by tiles that touch the image border only (a halo
+      // pixel outside the image, or - cross-tile staging - outside the next tile's image): wave-uniform, decided once per tile
+      auto xform_sel = [&](bool chk, int i0, bool nxt) {
+        if (!GN) { xform(false, false, i0, nxt); return; }
+        if (p.gn_silu) { if (chk) xform(true, true, i0, nxt); else xform(true, false, i0, nxt); }
+        else xform(false, true, i0, nxt);
+      };
+      // high planes: 4 planes of 16-byte rows (channel group g of the chunk); fp8 region behind: sub-planes [x_lo8 ch 0-15 | x_lo8 ch 16-31 | x8 ch 0-15 | x8 ch 16-31]
+      auto write_hi = [&](int i0, int i1) {
+        const int g = a_part >> 3;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i)
+          if (i >= i0 && i < i1 && tid + i * NT < A_VEC) *(u32x4*)(Aring + g * A_HALF + (a_hp0 + i * (NT / KV)) * 16) = a_raw[i][0];
+      };
+      auto write_f8 = [&](const bool FROM_CARRY) {      // FROM_CARRY (a literal at every call site): the image that crossed the tile boundary in f8h
+        const int g = a_part >> 3;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i)
+          if (tid + i * NT < A_VEC) {
+            unsigned char* a8 = Aring + C::A_BYTES + (g >> 1) * A_HALF + (a_hp0 + i * (NT / KV)) * 16 + (g & 1) * 8;
+            u32x2 wl, wx;
+            const u32x4 q = FROM_CARRY ? f8h[i] : a_raw[i][IN_F32 ? 1 : 0];
+            wl[0] = q[0]; wl[1] = q[1]; wx[0] = q[2]; wx[1] = q[3];
+            *(u32x2*)a8 = wl;
+            *(u32x2*)(a8 + 2 * A_HALF) = wx;
+          }
       };
       stamp(1);                         // tile start (both roles)
-      if (role && !pre_done) {          // (a tile prepared by its predecessor skips all of this)
-        write_bias_tab(bias_tab, img, n0);
-        dma_step(0, 0);
-        if (1 < nsteps) dma_step(1, 1);
-        SDM_SCHED_FENCE();
-        issue_loads_a(0);
-        issue_gn(0);
-        write_lds_a_f8(false, Aring, 0, A_PER);
-        SDM_WAIT_VMCNT0();
-        if (nch > 1) {                  // chunk 1: in flight across the first barrier
-          issue_loads_nx(32);
-          SDM_SCHED_FENCE();
-        }
-      }
-      const int cm = 0;             // (6 * c) % 3 = 0 always: the chunk's first step sits in ring slot 0 (kept for clarity)
       if (role) {
+        const bool pre_at_entry = pre_done != 0;
+        dma_bias_tab(bias_tab, img, n0);      // (needed by the consumers' epilogue; the step loop's waits see it landed long before)
+        if (!pre_done) {                // (a tile prepared by its predecessor has its weights in the ring, its chunk 0 in LDS (high planes) / f8h, its chunk 1 in a_nx)
+          dma_step(0, 0);
+          dma_step(1, 1);
+          dma_step(2, 2);
+          SDM_SCHED_FENCE();
+          issue_loads_a(0);
+          issue_gn(0);
+#pragma unroll
+          for (int i = 0; i < A_PER; ++i) xform_sel(chk_cur, i, false);
+          write_hi(0, A_PER);
+          write_f8(false);
+          SDM_WAIT_VMCNT0();
+          if (nch > 1) {                // chunk 1: in flight across the first barrier (waited for at the first step, below)
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i) issue_nx_vec(i, (32 >= p.C0) ? rq1 : rq0, (unsigned int)((32 >= p.C0) ? p.C1 : p.C0) * es,
+                                                         (unsigned int)(((32 >= p.C0) ? 32 - p.C0 : 32) + a_part) * es, false);
+            issue_nx_gn(32, false);
+            SDM_SCHED_FENCE();
+          }
+        } else {
+          write_f8(true);               // chunk 0's fp8 image: nobody reads that region between a tile's last barrier and the next tile's first
+        }
         SDM_WAIT_LGKMCNT0();
         stamp();                        // prologue done, arriving at the first barrier
         SDM_RAW_BARRIER();
         stamp();                        // past the first barrier
+        int cm = 0;                     // ring slot of the chunk's first step
         for (int c = 0; c < nch; ++c) {
           const bool more = c + 1 < nch;
           const bool morex = more || has_next;             // the chunk staged during this one: c + 1, or chunk 0 of the next tile
-          if (!more && has_next) write_bias_tab((float*)(smem + C::TILE_BYTES) + (tile_par ^ 1) * BN, n_img, n_n0);
+          const bool flyc = ((c + 2 < nch) || has_next) && !lab_nold;      // this chunk's steps issue the loads of the chunk after the staged one
+          // where those loads come from: chunk c + 2 of this tile, or chunk 0 / 1 of the next one (descriptor, row pitch and channel offset per chunk)
+          const bool ld_nxt = !(c + 2 < nch);
+          const int ld_c0 = ld_nxt ? (c + 2 - nch) * 32 : (c + 2) * 32;
+          const bool ld_second = ld_c0 >= p.C0;
+          const sdm_rsrc_raw ld_rq = ld_nxt ? (ld_second ? n_rq1 : n_rq0) : (ld_second ? rq1 : rq0);
+          const unsigned int ld_Cs = (unsigned int)(ld_second ? p.C1 : p.C0) * es, ld_cc = (unsigned int)((ld_second ? ld_c0 - p.C0 : ld_c0) + a_part) * es;
+          const bool x_chk = more ? chk_cur : chk_nxt;
 #pragma unroll
           for (int k = 0; k < 6; ++k) {                  // step t = 6c + k: (dx = k / 2, S1 | S2)
             const int t = c * 6 + k;
-            // chunk c+1's raw values arrived during chunk c-1 (every earlier step ended with vmcnt(0) or left only them in flight)
-            if (k == 0 && morex) take_nx();
+            if (k == 0 && c > 0) write_f8(false);         // the current chunk's fp8 image (its high planes went out during the previous step)
+            if (k == 0 && c == 0 && !pre_at_entry && nch > 1) SDM_WAIT_VMCNT0();      // the prologue's loads of chunk 1 (a block's first tile only)
+            // vector k of the staged chunk: loaded six steps ago (every step's end waits for everything but the two youngest steps' operations)
+            if (morex) { take_vec(k); if (k == 0) take_gn(); }
             SDM_SCHED_FENCE();
+            stamp2();
+            bool d3 = false;                              // this step issues the DMAs of step t + 3 (of this tile, or step 0 - 2 of the next one)
             if (!(lab_nodma && t >= 2)) {
-            if (t + 2 < nsteps) dma_step(t + 2, mod3(cm + k + 2));
-            else if (has_next) dma_step_v(t + 2 - nsteps, mod3(cm + k + 2), n_dma_voff);      // the next tile's first two weight steps (nsteps % 3 == 0: same slots)
+              if (t + 3 < nsteps) { dma_fast(t + 3, (cm + k + 3) & 3, dv0, dv1); d3 = true; }
+              else if (has_next) { dma_fast(t + 3 - nsteps, (cm + k + 3) & 3, ndv0, ndv1); d3 = true; }      // nsteps % 4 == 0 (even chunk counts): same slots
             }
             SDM_SCHED_FENCE();
-            // chunk c+2 - of this tile, or chunk 0 / 1 of the next one: loaded now, transformed one chunk later.  ALL of a chunk's loads at its
-            // first step: vector-memory operations retire in order and every step waits for its weight DMAs, so whatever is loaded has to land
-            // within two steps wherever it is issued - one load per step (tried: profiles/r04_conv_f8_step_trace.txt) stretches EVERY step to half
-            // the HBM latency (~4.5 k cycles under this load) instead of one step per chunk
-            const bool fly_cur = (k == 0) && (c + 2 < nch), fly_nxt = (k == 0) && !fly_cur && has_next;
-            const bool fly = (fly_cur || fly_nxt) && !lab_nold;
-            if (fly_cur && !lab_nold) issue_loads_nx((c + 2) * 32);
-            if (fly_nxt && !lab_nold) issue_loads_nx((c + 2 - nch) * 32, true);
+            stamp2();
+            // vector k of chunk c+2 - of this tile, or of chunk 0 / 1 of the next one - BEHIND this step's DMAs: transformed six steps from now.  ONE vector
+            // (two 16-byte loads) per step: the CU accepts a burst of a whole chunk's 64 load instructions (first touches of HBM) only over ~2 k
+            // cycles, and the producer waves sat in that issue queue at every chunk's first step (profiles/r05_conv_f8_step_trace.txt); with
+            // the ring of four a load has three steps to land before anything queued behind it is waited for
+            if (flyc) {
+              issue_nx_vec(k, ld_rq, ld_Cs, ld_cc, ld_nxt);
+              if (k == 0) issue_nx_gn(ld_c0, ld_nxt);
+            }
             SDM_SCHED_FENCE();
-            // the other A buffer was last read in chunk c-1: one vector of the next chunk's transform (GroupNorm, SiLU, hi / fp8
-            // split) per step, so that no step's barrier waits for the producers
-            if (morex && !lab_nowr) write_lds_a_f8(false, Aring + ((c + 1) & 1) * 2 * C::A_BYTES, k, k + 1, !more, n_pix);
-            if (fly) { if (AFLY == 12) SDM_WAIT_VMCNT(12); else SDM_WAIT_VMCNT(16); }
-            else SDM_WAIT_VMCNT0();
+            stamp2();
+            if (k == 5 && morex && !lab_nowr) write_hi(0, 5);      // (five of the six writes complete under the last vector's transform)
+            if (morex && !lab_nowr) xform_sel(x_chk, k, !more);
+            if (k == 5 && morex && !lab_nowr) write_hi(5, 6);
+            stamp2();
+            // the DMAs of step t + 2 (issued one step ago) are visible behind this barrier; what was issued after them may stay in flight: the previous
+            // step's loads (2, + 4 GroupNorm coefficient loads at step 0), this step's DMAs (6 per wave) and this step's loads
+            if (!d3) SDM_WAIT_VMCNT0();
+            else if (!flyc) SDM_WAIT_VMCNT(6);
+            else if (k == 0 && c == 0) { if (GN) SDM_WAIT_VMCNT(15); else SDM_WAIT_VMCNT(11); }      // + this tile's bias DMA
+            else if (k < 2 && GN) SDM_WAIT_VMCNT(14);
+            else SDM_WAIT_VMCNT(10);
             SDM_WAIT_LGKMCNT0();
             stamp();                    // step t: arriving at its barrier
             SDM_RAW_BARRIER();
             stamp();                    // step t: released
           }
+          cm ^= 2;
+        }
+        if (has_next) {                 // the next tile's chunk 0: its fp8 image crosses the tile boundary in registers
+#pragma unroll
+          for (int i = 0; i < A_PER; ++i) f8h[i] = a_raw[i][IN_F32 ? 1 : 0];
         }
         pre_done = has_next ? 1 : 0;
       } else {
@@ -1076,13 +1305,14 @@ conv_mfma_kernel(ConvParams p) {
 #pragma unroll
           for (int dy = 0; dy < 3; ++dy) ld_bh(0, dy, Bring);
         }
+        int cm = 0;                     // ring slot of the chunk's first step (wave-uniform)
         for (int c = 0; c < nch; ++c) {
           const bool more = c + 1 < nch;
-          const unsigned char* Ab = Aring + (c & 1) * 2 * C::A_BYTES;
+          const unsigned char* Ab = Aring;
 #pragma unroll
           for (int dx = 0; dx < 3; ++dx) {
-            const unsigned char* B1 = Bring + mod3(cm + dx * 2) * STEP;           // S1 of this column
-            const unsigned char* B2 = Bring + mod3(cm + dx * 2 + 1) * STEP;       // S2 of this column
+            const unsigned char* B1 = Bring + ((cm + dx * 2) & 3) * STEP;           // S1 of this column
+            const unsigned char* B2 = Bring + ((cm + dx * 2 + 1) & 3) * STEP;       // S2 of this column
             // ---- S1: A_hi . w_hi, channels 0-15 then 16-31; the second half's and the fp8 step's B fragments are read underneath ----
             f16x8 fa[2];
             i32x8 f8a[2];
@@ -1106,7 +1336,7 @@ conv_mfma_kernel(ConvParams p) {
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
               if (r + 1 < NR) fa[(NR + r + 1) & 1] = ld_ah(Ab, 1, r + 1, dx);
-              else f8a[0] = ld_a8(Ab, 0, dx);
+              else if (dx != 0) f8a[0] = ld_a8(Ab, 0, dx);      // (dx == 0: the producers write this chunk's fp8 region during this very step)
               if (r < 3) ld_b8(r, B2);
               SDM_SCHED_FENCE();
 #pragma unroll
@@ -1123,8 +1353,9 @@ conv_mfma_kernel(ConvParams p) {
             SDM_RAW_BARRIER();
             // ---- S2: [x_lo8 | x8] . [w8 | w_lo8]; the w_hi fragments of the next column (or chunk) are read underneath ----
             const bool last = (dx == 2) && !more;
-            const unsigned char* Bn = Bring + mod3(cm + dx * 2 + 2) * STEP;
+            const unsigned char* Bn = Bring + ((cm + dx * 2 + 2) & 3) * STEP;
             if (!lab_nomm) {
+            if (dx == 0) f8a[0] = ld_a8(Ab, 0, dx);
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
               if (r + 1 < NR) f8a[(r + 1) & 1] = ld_a8(Ab, r + 1, dx);
@@ -1143,6 +1374,7 @@ conv_mfma_kernel(ConvParams p) {
             }
             SDM_RAW_BARRIER();
           }
+          cm ^= 2;
         }
       }
       }   // NTAPS == 9
@@ -1359,7 +1591,7 @@ conv_mfma_kernel(ConvParams p) {
   }   // !DMAB
 
   // ---- epilogue: per-wave PRIVATE fp32 staging tile (32 x WTN) in LDS -> coalesced row stores ----
-  if (!DB) __syncthreads();      // all waves are done with the A/B tiles (DB: the loop ended with a barrier)
+  if (!DB && !C::R4) __syncthreads();      // all waves are done with the A/B tiles (DB, F8 3x3: the loop ended with a barrier)
   stamp();                       // tile-end barrier passed
   if (PC && role) return;        // the accumulators live in the consumer waves; no block-wide barrier below this line
   if (FASTEPI && fast_epi) {
@@ -1419,7 +1651,7 @@ conv_mfma_kernel(ConvParams p) {
       // per-channel sums over this wave's 128 pixels: in-lane over the 4 sub-tiles (above), then over the 16 lanes of each DPP row;
       // the two rows of a lane half meet in a wave-private LDS scratch (the second A buffer is free during the epilogue), from which
       // lane c writes channel c of the partial row - one coalesced store, as the LDS-staged epilogue does
-      float* sc = (float*)(smem + 2 * C::A_BYTES) + wave * 256;            // [2 rows][64 channels][sum, sumsq]
+      float* sc = (float*)(smem + C::SCR_OFF) + wave * 256;            // [2 rows][64 channels][sum, sumsq]
 #pragma unroll
       for (int j = 0; j < NTL; ++j)
 #pragma unroll
@@ -1444,7 +1676,7 @@ conv_mfma_kernel(ConvParams p) {
     stamp();                     // epilogue issued
     return;
   }
-  float* stg = (float*)(smem + (F8 ? 2 * C::A_BYTES : 0)) + wave * (32 * WTN);      // F8: second A buffer (the next tile's prologue fills the first)
+  float* stg = (float*)(smem + (F8 ? C::SCR_OFF : 0)) + wave * (32 * WTN);      // F8: the epilogue scratch (ConvCfg: the next tile's prologue does not touch it)
   // accumulators of sub-tile i -> the wave's [32 pixels][WTN channels] staging tile.  F8 kernels hold [channel][pixel]: a register quad
   // is 4 consecutive channels of pixel (lane & 31) - one ds_write_b128 into 16-byte block ((channel / 4) ^ (pixel & 15)) of the
   // pixel's row (the XOR keeps 8 consecutive lanes = 8 rows on distinct banks without padding the tile; readers apply it again)
@@ -1653,8 +1885,10 @@ conv_mfma_kernel(ConvParams p) {
     // tiles of a constant-input region (ConvParams::tile_flag) are left to const_tile_fill_kernel.  Block-uniform, evaluated identically by both
     // roles; a tile in front of a skipped one does not prefetch across it, and the bias-table parity counts the tiles that actually ran
     // bit k of `skip`: the block's k-th tile is left out.  All flags are fetched up front (independent scalar loads: one round trip per block)
+    // Padding blocks of the grid rounding (tile_decode fails) count as left out as well: a tile's bias-table slot is its rank among the tiles that
+    // really run, so a valid / padding / valid sequence (band order with tiles_m % (8 * band) != 0) keeps alternating slots
     unsigned int skip = 0;
-    if (NTAPS == 9 && p.tile_flag) {
+    {
       int fl[9], ml9[9];
 #pragma unroll
       for (int k = 0; k < 9; ++k) { fl[k] = 0; ml9[k] = 0; }
@@ -1663,7 +1897,8 @@ conv_mfma_kernel(ConvParams p) {
         if (k >= p.tpb) continue;
         const int v = (int)blockIdx.x + k * (int)gridDim.x;
         int nt;
-        if (v < p.vgrid && tile_decode(v, ml9[k], nt)) fl[k] = p.tile_flag[ml9[k]];
+        if (v < p.vgrid && tile_decode(v, ml9[k], nt)) { if (NTAPS == 9 && p.tile_flag) fl[k] = p.tile_flag[ml9[k]]; }
+        else skip |= 1u << k;
       }
 #pragma unroll
       for (int k = 0; k < 9; ++k)
@@ -1692,7 +1927,7 @@ conv_mfma_kernel(ConvParams p) {
 #if defined(SDM_CONV_TRACE) && !defined(SDM_EMU)
     if (NTAPS == 9 && p.trace && (int)blockIdx.x >= p.trace_b0 && (int)blockIdx.x < p.trace_b0 + 16 && (threadIdx.x & (NT - 1)) == 0) {      // the parked stamps of this role -> global memory, once
       const int r = (int)threadIdx.x / NT;
-      const unsigned int* tb = (const unsigned int*)(smem + C::TILE_BYTES + 2 * BN * 4) + r * 64;
+      const unsigned int* tb = (const unsigned int*)(smem + C::TRACE_OFF) + r * 64;
       unsigned int* dst = p.trace + ((size_t)((int)blockIdx.x - p.trace_b0) * 2 + r) * 384;
       for (int i = 0; i < tr_n && i < 383; ++i) dst[i] = tb[i];
       dst[383] = (unsigned int)tr_n;

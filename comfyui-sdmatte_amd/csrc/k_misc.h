@@ -228,7 +228,7 @@ __global__ void fill_random_f32_kernel(float* __restrict__ p, long n, unsigned i
 //      A conv layer erodes the plane by its window; output TILES whose pixels are all of one class are not multiplied: ONE such tile per
 //      (image, class) is computed by the conv kernel as usual, and const_tile_fill_kernel copies one of its pixels into the others - the
 //      value every one of those pixels would have received (each output pixel is the same chain of operations on the same operands,
-//      independent of its position), and the statistics they would have contributed (count x value, count x value^2).  Exact: nothing
+//      independent of its position), and the statistics they would have contributed (the representative tile's own partial sums).  Exact: nothing
 //      is approximated; the engine option trimap_skip = 0 computes every tile. ----
 #define SDM_CMASK_EMPTY 0xFFFFFFFFu
 
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void cmask_conv_kernel(const unsigned char* __
 }
 
 // the tiles the F8 conv kernel left out (ConvParams::tile_flag): every pixel = pixel (0, 0) of the class's representative tile (fp32 NHWC, full
-// 8 x 32 tiles), and the two partial statistics rows of the tile (one per 128-pixel wave row, the conv kernel's layout) = 128 x v, 128 x v^2.
+// 8 x 32 tiles), and the two partial statistics rows of the tile (one per 128-pixel wave row, the conv kernel's layout) = the representative's own rows.
 // grid (tiles per image, N - n0), 256 threads.
 __global__ __launch_bounds__(256) void const_tile_fill_kernel(float* __restrict__ out, int C, int Hout, int Wout, const unsigned char* __restrict__ tile_flag,
                                                               const int* __restrict__ tile_rep, float* __restrict__ stats, int wm_rows, int n0) {
@@ -323,13 +323,12 @@ __global__ __launch_bounds__(256) void const_tile_fill_kernel(float* __restrict_
     for (int i = tid; i < 32 * C4; i += 256) dst[i] = src[i % C4];
   }
   if (stats) {
-    const float cnt = (float)(256 / wm_rows);
-    for (int ch = tid; ch < C; ch += 256) {
-      const float v = ((const float*)src)[ch];
-      for (int w = 0; w < wm_rows; ++w) {
-        float* st = stats + ((((size_t)n * tiles + mt) * wm_rows + w) * C + ch) * 2;
-        st[0] = cnt * v; st[1] = cnt * (v * v);
-      }
+    // the partial statistics rows of the representative tile, as the conv kernel summed them: the left-out tile holds the same values in the same
+    // positions, so the kernel would have produced exactly these sums for it (count x v would differ from the running fp32 sum in the last bits)
+    for (int i = tid; i < wm_rows * C; i += 256) {
+      const int w = i / C, ch = i - w * C;
+      const f32x2 r2 = *(const f32x2*)(stats + ((((size_t)n * tiles + rep) * wm_rows + w) * C + ch) * 2);
+      *(f32x2*)(stats + ((((size_t)n * tiles + mt) * wm_rows + w) * C + ch) * 2) = r2;
     }
   }
 }

@@ -41,6 +41,8 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define SDM_SCHED_GROUP(mask, n, id) ((void)0)
 static inline float sdm_exp2(float x) { return exp2f(x); }
 static inline float sdm_rcp(float x) { return 1.0f / x; }
+#define SDM_MED3(x, lo, hi) fminf(fmaxf((x), (lo)), (hi))
+#define SDM_UMUL24(a, b) ((unsigned int)(a) * (unsigned int)(b))
 #else
 #define SDM_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #define SDM_SHARED __shared__
@@ -77,6 +79,8 @@ static inline float sdm_rcp(float x) { return 1.0f / x; }
 #define SDM_SCHED_GROUP(mask, n, id) __builtin_amdgcn_sched_group_barrier((mask), (n), (id))
 __device__ __forceinline__ float sdm_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float sdm_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#define SDM_MED3(x, lo, hi) __builtin_amdgcn_fmed3f((x), (lo), (hi))      // clamp in one instruction (lo <= hi)
+#define SDM_UMUL24(a, b) __umul24((a), (b))                                // both operands below 2^24: full-rate multiply (v_mul_u32_u24 / v_mad_u32_u24)
 #endif
 
 // ---- raw buffer loads: SGPR resource descriptor + 32-bit byte offset; out-of-range offsets return 0 in hardware
@@ -157,6 +161,13 @@ static inline void sdm_glds16_buf(sdm_rsrc r, unsigned int voff, unsigned int so
   const u32x4 v = sdm_buffer_load16(r, voff, soff);
   memcpy(lds_base + (threadIdx.x & 63) * 16, &v, 16);
 }
+// 4 bytes per lane (a bias table: 64 floats per wave)
+static inline void sdm_glds4_buf(sdm_rsrc r, unsigned int voff, unsigned int soff, unsigned char* lds_base) {
+  unsigned int v = 0u;
+  const unsigned long long o = (unsigned long long)voff + soff;
+  if (o + 4 <= r.bytes) memcpy(&v, r.base + o, 4);
+  memcpy(lds_base + (threadIdx.x & 63) * 4, &v, 4);
+}
 #define SDM_UNIFORM_I(x) (x)
 #define SDM_OPAQUE_I(x) ((void)0)
 #define SDM_PIN_HERE_V4(a, b, c, d) ((void)0)
@@ -172,6 +183,9 @@ __device__ __forceinline__ void sdm_glds16(const void* gsrc, unsigned char* lds_
 // buffer form: SGPR descriptor + 32-bit per-lane byte offset + uniform byte offset (no 64-bit address VGPRs; OOB -> 0)
 __device__ __forceinline__ void sdm_glds16_buf(sdm_rsrc r, unsigned int voff, unsigned int soff, unsigned char* lds_base) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_base, 16, (int)voff, (int)soff, 0, 0);
+}
+__device__ __forceinline__ void sdm_glds4_buf(sdm_rsrc r, unsigned int voff, unsigned int soff, unsigned char* lds_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_base, 4, (int)voff, (int)soff, 0, 0);
 }
 // value known to be wave-uniform (e.g. threadIdx.x >> 6): lets the compiler keep everything derived from it in SGPRs
 #define SDM_UNIFORM_I(x) __builtin_amdgcn_readfirstlane(x)

@@ -13,7 +13,6 @@
 //   * the dead CLIP text branch (meta_arch.py:220-234, never consumed: replace.py:414-416) is not built.
 #include "sdm_common.h"
 #include "k_conv.h"
-#include "k_conv_f8s.h"
 #include "k_norm.h"
 #include "k_attn.h"
 #include "k_misc.h"
@@ -26,6 +25,8 @@
 #include <cstring>
 #include <atomic>
 #include <map>
+#include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -95,7 +96,6 @@ static OptEntry g_opts[] = {
   {"gemm_f8_min_k", 1024, 1024, "smallest K of a GEMM that takes the 8-wave fp8-residual kernel"},
   {"conv_epi", 4, 4, "F8 kernels' epilogue: 4 register-direct stores + residual as accumulator init, 3 residual init only, 0 LDS-staged"},
   {"conv_xtile", 1, 1, "F8 3x3: cross-tile prefetch by the producer waves"},
-  {"conv_swap", 0, 0, "F8 3x3: role-swapping wave groups (k_conv_f8s.h) where its restrictions hold - correct, measured slower (DESIGN.md 4): off"},
   {"conv_f8_tpb", 0, 0, "F8: tiles per block (0 = by queue depth)"},
   {"conv_dma", 1, 1, "3x3 stride-1 256x128 tile: weights by LDS-DMA"},
   {"conv_dma_all", 0, 0, "keep a stage-ordered weight copy for every wide 3x3 layer, not only the split-precision ones (read when a model is built)"},
@@ -122,8 +122,15 @@ static OptEntry* opt_find(const char* name) {
   return nullptr;
 }
 static int opt(const char* name) { OptEntry* o = opt_find(name); return o ? o->value : 0; }
+// One process may run one engine per host thread (parallel.py MultiGpuEngine, ctypes releases the GIL).  Options are process-wide: a forward
+// holds g_opt_mu shared from before its dry pass to the end of its launch pass, sdm_set_option / sdm_reset_options take it exclusively - an option
+// can therefore never change between the pass that sizes the arena and the pass that launches (it waits for the forwards in flight).  The launch
+// counters are a mutex-guarded map: a few hundred increments per step.
+static std::shared_mutex g_opt_mu;
+struct OptReadLock { std::shared_lock<std::shared_mutex> l; OptReadLock() : l(g_opt_mu) {} };
+static std::mutex g_count_mu;
 static std::map<std::string, long> g_kernel_counts;
-static void count_kernel(const char* name) { g_kernel_counts[name] += 1; }
+static void count_kernel(const char* name) { std::lock_guard<std::mutex> g(g_count_mu); g_kernel_counts[name] += 1; }
 
 // ------------------------------------------------------------------------------------------------
 // conv tile configurations
@@ -315,29 +322,6 @@ static void launch_conv_dma(const ConvParams& p_in, void* stream) {
     SDM_SET_SMEM(k, 160 * 1024);                                                                             \
     SDM_LAUNCH(k, grid, dim3(CD::LAUNCH_THREADS), (size_t)CD::SMEM + gn_extra, stream, p);                   \
   } while (0)
-  if (split && p.f8 && opt("conv_swap") && p.in_f32 && p.out_f32 == 1 && p.epi == 0 && p.out_scale == 1.0f && p.Hout % 8 == 0 && p.Wout % 32 == 0 &&
-      p.Cout_valid == p.Cout_pad && p.Cout_pad % 128 == 0 && ((p.C0 + p.C1) / 32) % 2 == 0 && (p.C0 + p.C1) >= 128 && p.C0 % 32 == 0 && (!p.res || p.res_f32) &&
-      (!p.res || p.res_C % 4 == 0)) {
-    // role-swapping wave groups: a block walks its tiles back to back, one group of four waves multiplying a tile while the other drains
-    // the previous one and stages the next (k_conv_f8s.h).  Persistent blocks once there are at least two tiles per CU.
-    p.vgrid = (int)grid.x;
-#ifdef SDM_EMU
-    unsigned pg = (grid.x + 2) / 3;
-#else
-    static int cus = 0;
-    if (!cus) {
-      int dev = 0;
-      hipDeviceProp_t pr;
-      cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
-    }
-    unsigned pg = grid.x >= 2u * (unsigned)cus ? (unsigned)cus : grid.x;
-#endif
-    pg = (pg + 7) & ~7u;
-    count_kernel(gn ? "conv3x3_f8_swap<gn>" : "conv3x3_f8_swap");
-    if (gn) { auto k = conv3x3_f8_swap_kernel<1>; SDM_SET_SMEM(k, 160 * 1024); SDM_LAUNCH(k, dim3(pg, 1, 1), dim3(512), (size_t)ConvF8S::SMEM + 2048, stream, p); }
-    else { auto k = conv3x3_f8_swap_kernel<0>; SDM_SET_SMEM(k, 160 * 1024); SDM_LAUNCH(k, dim3(pg, 1, 1), dim3(512), (size_t)ConvF8S::SMEM + 2048, stream, p); }
-    return;
-  }
   if (split && p.f8) {          // fp8-residual producer / consumer kernel (32-channel chunks; no GroupNorm table in LDS)
 #define SDM_F8_CASE(GNF)                                                                                     \
   do {                                                                                                       \
@@ -348,7 +332,7 @@ static void launch_conv_dma(const ConvParams& p_in, void* stream) {
     p.tpb = conv_f8_tiles_per_block((long)grid.x);                                                           \
     unsigned pg = (grid.x + p.tpb - 1) / p.tpb;                                                              \
     pg = (pg + 7) & ~7u;              /* block id % 8 = XCD: the stride between a block's tiles stays a multiple of 8 */ \
-    SDM_LAUNCH(k, dim3(pg, 1, 1), dim3(CD::LAUNCH_THREADS), (size_t)CD::SMEM + CD::F8_EXTRA, stream, p);     /* + two bias tables (k_conv.h) */ \
+    SDM_LAUNCH(k, dim3(pg, 1, 1), dim3(CD::LAUNCH_THREADS), (size_t)CD::SMEM_F8, stream, p);                 /* LDS map: ConvCfg (k_conv.h) */ \
   } while (0)
     count_kernel(gn ? "conv3x3_f8<gn>" : "conv3x3_f8");
     if (gn) SDM_F8_CASE(1); else SDM_F8_CASE(0);
@@ -377,7 +361,7 @@ static void launch_gemm_f8(const ConvParams& p_in, void* stream) {
   count_kernel("gemm_f8");
   auto k = conv_mfma_kernel<1, 1, 8, 32, 128, 32, 2, 2, 1, 0, 0, 1, 1, 1, 1>;
   SDM_SET_SMEM(k, 160 * 1024);
-  SDM_LAUNCH(k, dim3(pg, 1, 1), dim3(CD::LAUNCH_THREADS), (size_t)CD::SMEM + CD::F8_EXTRA, stream, p);      // + two bias tables
+  SDM_LAUNCH(k, dim3(pg, 1, 1), dim3(CD::LAUNCH_THREADS), (size_t)CD::SMEM_F8, stream, p);      // LDS map: ConvCfg (k_conv.h)
 }
 
 static int launch_conv(int ntaps, int stride, int cfg, const ConvParams& p, void* stream) {
@@ -980,6 +964,9 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
   p.epi_mode = conv_epi_mode();
   p.xtile = conv_xtile_enabled() ? 1 : 0;
   p.gn_scale = a.gn_scale; p.gn_shift = a.gn_shift; p.gn_silu = a.gn_silu;
+  // the F8 3x3 kernel addresses both tables through ONE buffer descriptor: scale | shift are the two halves of one scratch tensor (gn_scale_shift)
+  if (!e->dry && a.gn_scale && a.gn_shift != a.gn_scale + (size_t)a.in0->N * (a.in0->C + (a.in1 ? a.in1->C : 0)))
+    SDM_FAIL(e, SDM_ERR_STATE, "fused GroupNorm: shift table is not scale + N * C");
   if ((long)a.in0->rows() >= (1L << 31) || p.M >= (1L << 31)) SDM_FAIL(e, SDM_ERR_INVALID, "conv %s: tensor too large for 32-bit pixel indices", L.name.c_str());
   {   // 3x3: per-tile descriptors span only the rows of the tile's halo (k_conv.h band0), so an image may exceed 4 GB; what
       // stays 32-bit is the byte offset inside that band
@@ -1044,8 +1031,7 @@ static int op_conv(sdm_ctx* e, const ConvL& L, const ConvArgs& a) {
     T mb = talloc(e, 1, 1, 1, (int)(((size_t)p.N * p.Hout * p.Wout + 3) / 4), 1);
     a.out->cmask = (unsigned char*)mb.p; a.out->cm_off = mb.off; a.out->cm_bytes = mb.bytes; a.out->cm_n0 = a.in0->cm_n0;
     cm_skip = p.f8 && p.w_dma && cfg == 0 && a.stride == 1 && p.Hout % 8 == 0 && p.Wout % 32 == 0 && p.out_f32 == 1 && !L.geglu && p.out_scale == 1.0f &&
-              p.Cout_valid == p.Cout_pad && p.Cout_pad % 128 == 0 && p.Cout_store == p.Cout_pad && p.out_ch_off == 0 && (!p.res || p.res_f32) && ksplit == 1 &&
-              !opt("conv_swap");
+              p.Cout_valid == p.Cout_pad && p.Cout_pad % 128 == 0 && p.Cout_store == p.Cout_pad && p.out_ch_off == 0 && (!p.res || p.res_f32) && ksplit == 1;
     if (cm_skip) {
       cm_flag = talloc(e, 1, 1, 1, (p.N * cm_tiles + 3) / 4, 1);
       cm_rep = talloc(e, 1, 1, 1, p.N * 8, 1);
@@ -1778,6 +1764,7 @@ static int forward_impl(sdm_ctx* e, int mode, const float* image, const float* t
                         const float* cond, int cond_dim, int cond_kind, bool use_mask, float* out, int ptr_kind, void* stream_arg,
                         const NodeTail* tail = nullptr) {
   if (!e->finalized) SDM_FAIL(e, SDM_ERR_STATE, "weights not finalised: call sdm_load_tensor(...) and sdm_finalize_weights first");
+  OptReadLock opt_lock;          // kernel-selection options stay put for both passes of this forward
   const int SH = (mode == 0) ? H : S, SW = (mode == 0) ? W : S;
   if (B <= 0 || SH <= 0 || SW <= 0 || SH % 64 || SW % 64)
     SDM_FAIL(e, SDM_ERR_INVALID, "inference size must be a positive multiple of 64 (got %dx%d)", SH, SW);
@@ -1874,6 +1861,7 @@ static int forward_impl(sdm_ctx* e, int mode, const float* image, const float* t
 // runs an op outside forward(): arena sized by a dry pass of the same code
 template <typename F>
 static int run_two_pass(sdm_ctx* e, F body) {
+  OptReadLock opt_lock;          // (never nested: forward_impl does not come through here)
   for (int pass = 0; pass < 2; ++pass) {
     e->dry = (pass == 0);
     arena_reset(e);
@@ -2303,6 +2291,7 @@ int sdm_release_memory(sdm_ctx* e) {
 int sdm_set_option(const char* name, int value) {
   OptEntry* o = opt_find(name);
   if (!o) return SDM_ERR_INVALID;
+  std::unique_lock<std::shared_mutex> g(g_opt_mu);      // waits for the forwards in flight on other host threads
   o->value = value;
   return SDM_OK;
 }
@@ -2315,6 +2304,7 @@ int sdm_get_option(const char* name, int* value) {
 }
 
 void sdm_reset_options(void) {
+  std::unique_lock<std::shared_mutex> g(g_opt_mu);
   for (auto& o : g_opts) o.value = o.def;
 }
 
@@ -2328,12 +2318,13 @@ const char* sdm_option_help(int i) {
 
 int sdm_kernel_counts(char* buf, int cap) {
   std::string out;
+  std::lock_guard<std::mutex> g(g_count_mu);
   for (auto& kv : g_kernel_counts) { out += kv.first; out += "="; out += std::to_string(kv.second); out += ";"; }
   if (buf && cap > 0) { const int n = (int)out.size() < cap - 1 ? (int)out.size() : cap - 1; memcpy(buf, out.data(), (size_t)n); buf[n] = 0; }
   return (int)out.size();
 }
 
-void sdm_kernel_counts_reset(void) { g_kernel_counts.clear(); }
+void sdm_kernel_counts_reset(void) { std::lock_guard<std::mutex> g(g_count_mu); g_kernel_counts.clear(); }
 
 int64_t sdm_weight_bytes(sdm_ctx* e) { return e ? (int64_t)e->warena_bytes : 0; }
 

@@ -160,6 +160,55 @@ def test_emu_single_process_fan_out(pkg):
     one.close(); fan.close()
 
 
+def test_emu_two_host_threads_share_options_and_launch_counters(pkg):
+    """Two engines driven by two host threads (what parallel.MultiGpuEngine does with the GIL released inside ctypes) while a third thread flips an
+    engine option and reads the launch counters: the counters are a guarded map, and sdm_set_option waits for the forwards in flight (g_opt_mu in
+    sdm_engine.cpp), so an option can never change between a forward's arena-sizing pass and its launch pass.  attn_dense selects between two
+    bit-identical attention walks, so every result must equal the serial one whenever the flips land."""
+    import threading
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    from comfyui_sdmatte_amd.weights import synthetic_state_dict
+    from comfyui_sdmatte_amd.synth import synthetic_inputs
+    cfg = SDMatteConfig.tiny()
+    w = synthetic_state_dict(cfg, 0)
+    engs = [_emu_engine(cfg) for _ in range(2)]
+    for e in engs:
+        e.load_state_dict(w)
+    lib = engs[0].lib
+    img, tri = synthetic_inputs(2, 64, 64, seed=21)
+    want = engs[0].apply_matte(img, tri, 64)
+    lib.kernel_counts(reset=True)
+    got, errs, stop = [None, None], [], threading.Event()
+
+    def work(i):
+        try:
+            for _ in range(3):
+                got[i] = engs[i].apply_matte(img, tri, 64)
+                assert torch.equal(got[i], want)
+        except Exception as ex:      # noqa: BLE001
+            errs.append(ex)
+
+    def flip():
+        v = 0
+        while not stop.is_set():
+            v ^= 1
+            lib.set_option("attn_dense", v)
+            lib.kernel_counts()
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    tf = threading.Thread(target=flip)
+    for t in ts + [tf]:
+        t.start()
+    for t in ts:
+        t.join()
+    stop.set(); tf.join()
+    lib.set_option("attn_dense", 0)
+    assert not errs, errs
+    counts = lib.kernel_counts()
+    assert sum(counts.values()) > 0 and all(c > 0 for c in counts.values())
+    for e in engs:
+        e.close()
+
+
 def test_emu_full_forward_matches_oracle(pkg):
     from comfyui_sdmatte_amd.config import SDMatteConfig
     from comfyui_sdmatte_amd.weights import synthetic_state_dict

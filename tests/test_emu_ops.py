@@ -293,22 +293,16 @@ def test_fp8_residual_kernels_random_shapes(emu_engine):
         S.check_conv(emu_engine, DEV, N, H, W, cin, cout, ntaps=1, tile_cfg=4, in_f32=True, out_f32=True, split=True, f8=True, res="f32", seed=200 + it, atol=3e-4)
 
 
-def test_conv3x3_role_swap_kernel(emu_engine, engine_option):
-    """k_conv_f8s.h (engine option conv_swap = 1): role-swapping wave groups, three tiles per block on the emulator; against the fp32
-    reference, and bit-identical to the one-role-per-wave kernel where no residual changes the order of the last additions."""
-    import torch
-    engine_option(emu_engine, "conv_swap", 1)
+def test_conv3x3_f8_tiles_back_to_back(emu_engine):
+    """F8 3x3 kernel, several tiles per block (three on the emulator) with the cross-tile prefetch: the next tile's chunk 0 waits in the producers'
+    registers across the tile boundary (its high planes are written during the last step of the previous tile, its fp8 image in front of the next
+    tile's first barrier), even and odd chunk counts (odd: no prefetch, ring slots restart), fused GroupNorm, residual as accumulator init."""
     emu_engine.lib.kernel_counts(reset=True)
     S.check_conv(emu_engine, DEV, 2, 40, 96, 128, 128, tile_cfg=0, in_f32=True, out_f32=True, split=True, f8=True, gn=(1e-6, True), res="f32", seed=81, atol=3e-4)
     S.check_conv(emu_engine, DEV, 1, 24, 32, 192, 128, tile_cfg=0, in_f32=True, out_f32=True, split=True, f8=True, gn=(1e-5, False), seed=82, atol=3e-4)
-    assert emu_engine.lib.kernel_counts().get("conv3x3_f8_swap<gn>", 0) == 2
-    g = torch.Generator().manual_seed(3)
-    x, w, b = torch.randn(1, 16, 64, 256, generator=g), torch.randn(256, 256, 3, 3, generator=g) / 48.0, torch.randn(256, generator=g)
-    outs = []
-    for sw in (1, 0):
-        engine_option(emu_engine, "conv_swap", sw)
-        outs.append(emu_engine.op_conv(x, w, b, out_f32=True, split=True, tile_cfg=0))
-    assert torch.equal(outs[0], outs[1])
+    S.check_conv(emu_engine, DEV, 1, 24, 64, 96, 128, tile_cfg=0, in_f32=True, out_f32=True, split=True, f8=True, res="f32", seed=83, atol=3e-4)
+    S.check_conv(emu_engine, DEV, 1, 16, 64, 256, 256, tile_cfg=0, in_f32=True, out_f32=True, split=True, f8=True, seed=84, atol=3e-4)
+    assert emu_engine.lib.kernel_counts().get("conv3x3_f8<gn>", 0) == 2 and emu_engine.lib.kernel_counts().get("conv3x3_f8", 0) == 2
 
 
 def test_conv_split_k(emu_engine, engine_option):

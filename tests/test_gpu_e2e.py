@@ -119,21 +119,6 @@ def test_e2e_tiny_through_each_attention_pipeline_kernel(pkg, engine_option, nw)
     m.engine.close()
 
 
-def test_e2e_tiny_d512_role_swap_convs(pkg, engine_option):
-    """The role-swap conv kernel (option conv_swap = 1) inside the graph: its drain produces the GroupNorm statistics the next layer
-    normalises with, and adds the ResBlock residual."""
-    from comfyui_sdmatte_amd.config import SDMatteConfig
-    from comfyui_sdmatte_amd import engine as E
-    lib = E.load_library()
-    engine_option(lib, "conv_swap", 1)
-    lib.kernel_counts(reset=True)
-    m, w, img, tri, data, ref, out, d = _run(pkg, SDMatteConfig.tiny_d512(), 256, 2)
-    counts = lib.kernel_counts()
-    print(counts)
-    assert d.max().item() <= TOL and counts.get("conv3x3_f8_swap<gn>", 0) > 0
-    m.engine.close()
-
-
 def test_e2e_tiny_d512_vae_attention(pkg):
     from comfyui_sdmatte_amd.config import SDMatteConfig
     m, w, img, tri, data, ref, out, d = _run(pkg, SDMatteConfig.tiny_d512(), 128, 1)
@@ -685,8 +670,8 @@ def test_e2e_rectangular_inference(pkg):
 
 def test_e2e_trimap_constant_tiles_are_filled_not_multiplied(pkg, engine_option):
     """The VAE encoder's trimap images are piecewise constant: with the engine option trimap_skip (default on) the wide 3x3 convs fill the output tiles
-    that lie inside one region from a representative tile instead of multiplying them.  Same alpha as with the option off (the tiles are bit-identical;
-    the GroupNorm statistics are summed in a different order), both at the oracle's tolerance, and the launch counter shows the path ran."""
+    that lie inside one region from a representative tile instead of multiplying them.  Bit-identical alpha with the option on and off, at the oracle's
+    tolerance, and the launch counter shows the path ran."""
     from comfyui_sdmatte_amd.config import SDMatteConfig
     from comfyui_sdmatte_amd.weights import synthetic_state_dict
     from comfyui_sdmatte_amd.synth import synthetic_inputs
@@ -716,15 +701,14 @@ def test_e2e_trimap_constant_tiles_are_filled_not_multiplied(pkg, engine_option)
         print(f"trimap_skip={skip}: gpu_ms={ms:.2f} const-tile convs {counts.get('conv3x3_f8_const_tiles', 0)} max|d| vs oracle {(outs[skip] - ref).abs().max():.3e}")
         assert (counts.get("conv3x3_f8_const_tiles", 0) > 0) == bool(skip), counts
         assert (outs[skip] - ref).abs().max().item() <= TOL
-    # (the tiles are bit-identical; the statistics of the filled tiles are count x value instead of a sum of equal values, and the variance of a nearly
-    #  constant image amplifies that last-bit difference)
-    assert (outs[1] - outs[0]).abs().max().item() <= 0.5 * TOL
+    # the filled tiles are bit-identical to the multiplied ones, and so are their partial GroupNorm statistics (the fill kernel copies the representative
+    # tile's own rows - the sums the conv kernel would have produced for the tile): the alpha does not change by a single bit
+    assert torch.equal(outs[1], outs[0]), (outs[1] - outs[0]).abs().max().item()
 
 
 def test_e2e_full_model_trimap_skip_with_a_resized_trimap(pkg, engine_option):
     """The constant-tile path on what the ComfyUI node usually sees: a trimap that is NOT at the inference size (900 x 1300 -> 1024^2), so that only the regions
-    whose resized value is bit-constant (the background, certainly) qualify.  Full architecture, alpha with the option on == alpha with it off up to the
-    summation order of the GroupNorm statistics, and the launch counter shows that tiles were left out in the 1024- and 512-row levels of the encoder."""
+    whose resized value is bit-constant (the background, certainly) qualify.  Full architecture, alpha with the option on == alpha with it off (bit for bit), and the launch counter shows that tiles were left out in the 1024- and 512-row levels of the encoder."""
     from comfyui_sdmatte_amd.config import SDMatteConfig
     from comfyui_sdmatte_amd.weights import synthetic_state_dict
     from comfyui_sdmatte_amd import engine as E
@@ -747,8 +731,6 @@ def test_e2e_full_model_trimap_skip_with_a_resized_trimap(pkg, engine_option):
         assert n == (8 if skip else 0), n          # 4 + 4 wide 3x3 convs in the two levels with >= 512 rows
     d = (outs[1] - outs[0]).abs().max().item()
     print(f"max|alpha(skip) - alpha(all tiles)| = {d:.3e}")
-    # the tiles are bit-identical; what differs is the order of the fp32 additions behind the GroupNorm statistics (count x value against a sum of equal
-    # values).  This architecture with random weights turns ANY such reordering into ~7e-5 of alpha (tools/summation_order_sensitivity.py: the same image
-    # alone and in a batch of two differ by 6.4e-5, split-K on / off by 6.0e-5) - the bar here is that scale, far below the 1e-3 parity tolerance
-    assert d <= 2e-4
+    # tiles and partial statistics rows are bit-identical to the multiplied ones (the fill kernel copies the representative tile's own sums): no bit of the alpha moves
+    assert d == 0.0
     eng.close()

@@ -279,16 +279,17 @@ def test_attention_pipeline_kernels_with_trimap_bias_and_skipped_tiles(eng, engi
     assert counts.get(kern, 0) >= 5 and all(c == 0 for n, c in counts.items() if n.startswith("attn_d64") and n != kern), counts
 
 
-def test_conv3x3_role_swap_kernel(eng, engine_option):
-    """k_conv_f8s.h (engine option conv_swap = 1; off by default - correct, measured slower): wave groups that alternate between multiplying
-    a tile and draining / staging, several tiles per block; fused GroupNorm, residual added in the drain, concat input."""
-    engine_option(eng, "conv_swap", 1)
+def test_conv3x3_f8_tiles_back_to_back(eng):
+    """F8 3x3 kernel (one A buffer, ring of four weight steps; k_conv.h ConvCfg::R4), 1 / 2 / 4 tiles per block with the cross-tile prefetch: fused
+    GroupNorm, residual as accumulator init, odd chunk counts (no prefetch), a concat input."""
     eng.lib.kernel_counts(reset=True)
     S.check_conv(eng, DEV, 2, 64, 128, 128, 128, tile_cfg=0, in_f32=True, out_f32=True, split=True, f8=True, gn=(1e-6, True), res="f32", seed=81, atol=3e-4)
-    S.check_conv(eng, DEV, 4, 256, 256, 256, 256, tile_cfg=0, in_f32=True, out_f32=True, split=True, f8=True, gn=(1e-5, True), res=None, seed=82, atol=3e-4)      # 4 tiles per block
+    S.check_conv(eng, DEV, 4, 256, 256, 256, 256, tile_cfg=0, in_f32=True, out_f32=True, split=True, f8=True, gn=(1e-5, True), res=None, seed=82, atol=3e-4)      # 2 tiles per block
     S.check_conv(eng, DEV, 1, 32, 64, 512, 384, tile_cfg=0, in_f32=True, out_f32=True, split=True, f8=True, res="f32", seed=83, atol=3e-4)
+    S.check_conv(eng, DEV, 4, 512, 512, 128, 128, tile_cfg=0, in_f32=True, out_f32=True, split=True, f8=True, gn=(1e-6, True), res="f32", seed=84, atol=3e-4)   # 4 tiles per block
+    S.check_conv(eng, DEV, 2, 128, 128, 96, 128, C1=64, tile_cfg=0, in_f32=True, out_f32=True, split=True, f8=True, gn=(1e-5, True), seed=85, atol=3e-4)       # 5 chunks
     counts = eng.lib.kernel_counts()
-    assert counts.get("conv3x3_f8_swap<gn>", 0) >= 2 and counts.get("conv3x3_f8_swap", 0) >= 1, counts
+    assert counts.get("conv3x3_f8<gn>", 0) >= 4 and counts.get("conv3x3_f8", 0) >= 1, counts
 
 
 def test_conv_split_k(eng, engine_option):

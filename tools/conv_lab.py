@@ -13,7 +13,8 @@ import ctypes
 from comfyui_sdmatte_amd import build as B
 from comfyui_sdmatte_amd.engine import Bindings, Engine
 from comfyui_sdmatte_amd.config import SDMatteConfig
-lib = B.build_all(extra_flags=("-DSDM_CONV_LAB",), out=os.path.join(B.CSRC, "libsdmatte_hip_lab.so"))      # prebuilt in the build container
+os.makedirs(os.path.join(ROOT, "tools", "_build"), exist_ok=True)      # bench-only build, kept out of the package directory (prebuilt in the build container)
+lib = B.build_all(extra_flags=("-DSDM_CONV_LAB",), out=os.path.join(ROOT, "tools", "_build", "libsdmatte_hip_lab.so"))
 eng = Engine(SDMatteConfig.tiny(), 0, precision="fp16", _lib=Bindings(ctypes.CDLL(lib)))
 eng._on_device = True
 quick = len(sys.argv) > 1 and sys.argv[1].startswith("quick")

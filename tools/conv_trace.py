@@ -18,7 +18,9 @@ def child(a):
     from comfyui_sdmatte_amd import build as B
     from comfyui_sdmatte_amd.engine import Bindings, Engine
     from comfyui_sdmatte_amd.config import SDMatteConfig
-    lib = B.build_all(extra_flags=("-DSDM_CONV_TRACE",), out=os.path.join(B.CSRC, "libsdmatte_hip_trace.so"))      # prebuilt in the build container
+    # bench-only build, kept out of the package directory (prebuilt in the build container; SDM_TRACE_LIB names another traced build, e.g. of an older tree)
+    os.makedirs(os.path.join(ROOT, "tools", "_build"), exist_ok=True)
+    lib = os.environ.get("SDM_TRACE_LIB") or B.build_all(extra_flags=("-DSDM_CONV_TRACE",), out=os.path.join(ROOT, "tools", "_build", "libsdmatte_hip_trace.so"))
     eng = Engine(SDMatteConfig.tiny(), 0, precision="fp16", _lib=Bindings(ctypes.CDLL(lib)))
     eng._on_device = True
     N, H, W, ci, co, res, gn, skip, b0 = a
