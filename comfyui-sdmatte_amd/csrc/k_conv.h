@@ -837,10 +837,7 @@ conv_mfma_kernel(ConvParams p) {
       // that the transform of the next chunk can be spread evenly over the six steps of the current one (one vector per step)
       // (a_nx / gqn live at kernel scope: they carry the next tile's chunk 1 across the tile boundary)
       // ---- the NEXT tile of this block, as far as the producers need it (3x3 only; even chunk counts keep the A buffer parity) ----
-      bool has_next = false, chk_nxt = true;
-      // a halo pixel of this tile lies outside the image (zero padding): only then the staged values need the per-pixel test (xform)
-      const bool chk_cur = (NTAPS == 9) ? (SDM_UNIFORM_I((int)((oy0 * STRIDE - p.pad_t < 0) || (oy0 * STRIDE - p.pad_t + C::HPH > Hl) ||
-                                                            (ox0 * STRIDE - p.pad_l < 0) || (ox0 * STRIDE - p.pad_l + HPW > Wl))) != 0) : true;
+      bool has_next = false;
       int n_img = 0, n_n0 = 0;
       int n_pix[A_PER];
       sdm_rsrc n_rs0 = rs0, n_rs1 = rs1;
@@ -856,8 +853,6 @@ conv_mfma_kernel(ConvParams p) {
           n_n0 = nnt * BN;
           const int npx = (p.Wout + TW - 1) / TW;
           const int noy0 = (nmt / npx) * TH, nox0 = (nmt % npx) * TW;
-          chk_nxt = SDM_UNIFORM_I((int)((noy0 * STRIDE - p.pad_t < 0) || (noy0 * STRIDE - p.pad_t + C::HPH > Hl) || (nox0 * STRIDE - p.pad_l < 0) ||
-                                        (nox0 * STRIDE - p.pad_l + HPW > Wl))) != 0;
           const int nband0 = ((noy0 * STRIDE - p.pad_t) > 0 ? ((noy0 * STRIDE - p.pad_t) >> p.up) : 0);
           const int nband_rows = ((p.Hin - nband0) < (C::HPH + 1) ? (p.Hin - nband0) : (C::HPH + 1));
 #pragma unroll
@@ -1097,10 +1092,10 @@ conv_mfma_kernel(ConvParams p) {
       // vector i of this thread: raw fp32 (a_raw[i][0 | 1]) -> a_raw[i][0] = high parts, a_raw[i][1] = fp8 image.
       // A producer wave issues ONE instruction per four cycles at best, and it has to stage a vector per step beside the DMA and load issue: every
       // instruction here is 1/400 of a step.  Hence: ONE conversion per pair to fp16 (v_cvt_pk_f16_f32) whose halves are converted back for the low
-      // parts, SILU / CHK (zero padding stays zero after the normalisation:
-      // only tiles at the image border have such pixels) as compile-time variants chosen by a wave-uniform branch, no per-lane validity test
-      // (vectors beyond the tile are transformed like the others and dropped by the LDS writes).
-      auto xform = [&](const bool SILU, const bool CHK, int i0, bool nxt) {
+      // parts, SiLU as a compile-time variant chosen by a wave-uniform branch, no per-lane validity test (vectors beyond the tile are transformed
+      // like the others and dropped by the LDS writes).  NO packed fp32 (v_pk_fma / mul / add): beside a saturated matrix pipe they issue far slower
+      // than two scalar instructions (measured: the step 1.65 k -> 2.1 k cycles, profiles/r05_conv_f8_producer_variants.txt).
+      auto xform = [&](const bool SILU, int i0, bool nxt) {
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
           if (i != i0) continue;
@@ -1108,6 +1103,11 @@ conv_mfma_kernel(ConvParams p) {
           float y[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) y[e] = e < 4 ? v0[e & 3] : v1[e & 3];
+          // zero padding stays zero AFTER the normalisation: a pixel outside the image is clamped to [0, 0] - two selects per vector instead of eight
+          int pa = a_pix[i], pn = n_pix[i];      // (pinned in registers: see issue_nx_vec)
+          SDM_OPAQUE_I(pa); SDM_OPAQUE_I(pn);
+          const bool inside = !GN || (nxt ? pn : pa) >= 0;
+          const float c_lo = inside ? -F8_AMAX : 0.0f, c_hi = inside ? F8_AMAX : 0.0f;
           if (GN) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) y[e] = y[e] * (e < 4 ? gq[0][e & 3] : gq[1][e & 3]) + (e < 4 ? gq[2][e & 3] : gq[3][e & 3]);
@@ -1125,17 +1125,10 @@ conv_mfma_kernel(ConvParams p) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) y[e] = y[e] * t[e];
             }
-            if (CHK) {
-              int pa = a_pix[i], pn = n_pix[i];      // (pinned in registers: see issue_nx_vec)
-              SDM_OPAQUE_I(pa); SDM_OPAQUE_I(pn);
-              const bool inside = (nxt ? pn : pa) >= 0;
-#pragma unroll
-              for (int e = 0; e < 8; ++e) y[e] = inside ? y[e] : 0.0f;
-            }
           }
-          // one clamp keeps hi, x8 and x_lo8 finite (e5m2 has the range of fp16)
+          // one clamp keeps hi, x8 and x_lo8 finite (e5m2 has the range of fp16) - and makes padding pixels exactly zero
 #pragma unroll
-          for (int e = 0; e < 8; ++e) y[e] = SDM_MED3(y[e], -F8_AMAX, F8_AMAX);
+          for (int e = 0; e < 8; ++e) y[e] = SDM_MED3(y[e], c_lo, c_hi);
           u32x4 hq, q;
           float lo[8];
 #pragma unroll
@@ -1154,14 +1147,10 @@ conv_mfma_kernel(ConvParams p) {
           a_raw[i][IN_F32 ? 1 : 0] = q;
         }
       };
-      // the variant of a step: SiLU is a property of the layer; the zero-padding test is needed by tiles that touch the image border only (a halo
-      // pixel outside the image, or - cross-tile staging - outside the next tile's image): wave-uniform, decided once per tile
-      auto xform_sel = [&](bool chk, int i0, bool nxt) {
-        if (!GN) { xform(false, false, i0, nxt); return; }
-        if (p.gn_silu) { if (chk) xform(true, true, i0, nxt); else xform(true, false, i0, nxt); }
-        else xform(false, true, i0, nxt);
+      // the SiLU variant of the layer (wave-uniform branch; GroupNorm without SiLU exists in the op tests only)
+      auto xform_sel = [&](int i0, bool nxt) {
+        if (GN && p.gn_silu) xform(true, i0, nxt); else xform(false, i0, nxt);
       };
-      // high planes: 4 planes of 16-byte rows (channel group g of the chunk); fp8 region behind: sub-planes [x_lo8 ch 0-15 | x_lo8 ch 16-31 | x8 ch 0-15 | x8 ch 16-31]
       auto write_hi = [&](int i0, int i1) {
         const int g = a_part >> 3;
 #pragma unroll
@@ -1193,7 +1182,7 @@ conv_mfma_kernel(ConvParams p) {
           issue_loads_a(0);
           issue_gn(0);
 #pragma unroll
-          for (int i = 0; i < A_PER; ++i) xform_sel(chk_cur, i, false);
+          for (int i = 0; i < A_PER; ++i) xform_sel(i, false);
           write_hi(0, A_PER);
           write_f8(false);
           SDM_WAIT_VMCNT0();
@@ -1222,7 +1211,6 @@ conv_mfma_kernel(ConvParams p) {
           const bool ld_second = ld_c0 >= p.C0;
           const sdm_rsrc_raw ld_rq = ld_nxt ? (ld_second ? n_rq1 : n_rq0) : (ld_second ? rq1 : rq0);
           const unsigned int ld_Cs = (unsigned int)(ld_second ? p.C1 : p.C0) * es, ld_cc = (unsigned int)((ld_second ? ld_c0 - p.C0 : ld_c0) + a_part) * es;
-          const bool x_chk = more ? chk_cur : chk_nxt;
 #pragma unroll
           for (int k = 0; k < 6; ++k) {                  // step t = 6c + k: (dx = k / 2, S1 | S2)
             const int t = c * 6 + k;
@@ -1250,7 +1238,7 @@ conv_mfma_kernel(ConvParams p) {
             SDM_SCHED_FENCE();
             stamp2();
             if (k == 5 && morex && !lab_nowr) write_hi(0, 5);      // (five of the six writes complete under the last vector's transform)
-            if (morex && !lab_nowr) xform_sel(x_chk, k, !more);
+            if (morex && !lab_nowr) xform_sel(k, !more);
             if (k == 5 && morex && !lab_nowr) write_hi(5, 6);
             stamp2();
             // the DMAs of step t + 2 (issued one step ago) are visible behind this barrier; what was issued after them may stay in flight: the previous

@@ -279,6 +279,15 @@ def test_attention_pipeline_kernels_with_trimap_bias_and_skipped_tiles(eng, engi
     assert counts.get(kern, 0) >= 5 and all(c == 0 for n, c in counts.items() if n.startswith("attn_d64") and n != kern), counts
 
 
+def test_conv3x3_f8_forced_tiles_per_block(eng, engine_option):
+    """Three and four tiles per block (option conv_f8_tpb; the engine picks four from 32 tiles per CU on, i.e. at sizes the CPU reference cannot follow): every
+    tile but a block's first is staged by its predecessor - chunk 0 through the previous tile's last steps, chunk 1 in registers across the boundary."""
+    for tpb in (3, 4):
+        engine_option(eng, "conv_f8_tpb", tpb)
+        S.check_conv(eng, DEV, 2, 256, 256, 128, 128, tile_cfg=0, in_f32=True, out_f32=True, split=True, f8=True, gn=(1e-6, True), res="f32", seed=90 + tpb, atol=3e-4)
+        S.check_conv(eng, DEV, 1, 128, 256, 256, 256, tile_cfg=0, in_f32=True, out_f32=True, split=True, f8=True, seed=94 + tpb, atol=3e-4)
+
+
 def test_conv3x3_f8_tiles_back_to_back(eng):
     """F8 3x3 kernel (one A buffer, ring of four weight steps; k_conv.h ConvCfg::R4), 1 / 2 / 4 tiles per block with the cross-tile prefetch: fused
     GroupNorm, residual as accumulator init, odd chunk counts (no prefetch), a concat input."""
