@@ -1640,17 +1640,31 @@ conv_mfma_kernel(ConvParams p) {
       // the two rows of a lane half meet in a wave-private LDS scratch (the second A buffer is free during the epilogue), from which
       // lane c writes channel c of the partial row - one coalesced store, as the LDS-staged epilogue does
       float* sc = (float*)(smem + C::SCR_OFF) + wave * 256;            // [2 rows][64 channels][sum, sumsq]
+      // (stage by stage over all 64 values: a value-by-value chain of four dependent DPP adds costs a wait state each - 125 s_nop and 3.8 k cycles
+      //  per tile in the round-4 trace; and ONE masked region for the 32 writes instead of 32)
+#ifdef SDM_EMU
 #pragma unroll
       for (int j = 0; j < NTL; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float t1 = sdm_sum_row16(s1[j][r]), t2 = sdm_sum_row16(s2[j][r]);
-          if ((lane & 15) == 0) {
+        for (int r = 0; r < 16; ++r) { s1[j][r] = sdm_sum_row16(s1[j][r]); s2[j][r] = sdm_sum_row16(s2[j][r]); }
+#else
+#define SDM_STAT_STAGE(ctrl)                                                                                   \
+      _Pragma("unroll") for (int j = 0; j < NTL; ++j) _Pragma("unroll") for (int r = 0; r < 16; ++r) {        \
+        s1[j][r] = SDM_DPP_ADD(s1[j][r], ctrl); s2[j][r] = SDM_DPP_ADD(s2[j][r], ctrl); }                     \
+      SDM_SCHED_FENCE();
+      SDM_STAT_STAGE(0xB1) SDM_STAT_STAGE(0x4E) SDM_STAT_STAGE(0x124) SDM_STAT_STAGE(0x128)
+#undef SDM_STAT_STAGE
+#endif
+      if ((lane & 15) == 0) {
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
             f32x2 o2;
-            o2[0] = t1; o2[1] = t2;
+            o2[0] = s1[j][r]; o2[1] = s2[j][r];
             *(f32x2*)(sc + (((lane >> 4) & 1) * WTN + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 2) = o2;
           }
-        }
+      }
       SDM_WAVE_SYNC();
       if (lane < WTN) {
         const f32x2 a = *(const f32x2*)(sc + lane * 2), b = *(const f32x2*)(sc + (WTN + lane) * 2);
