@@ -473,6 +473,74 @@ def test_e2e_full_model_2048_images_beyond_4gb(pkg):
 
 
 @pytest.mark.slow
+def test_e2e_operand_images_beyond_4gb_vs_oracle(pkg):
+    """SURVEY.md 8(f)4, oracle-grade, ABOVE the 4 GB operand limit: a reduced-width, full-depth architecture whose first VAE level has 256 channels,
+    at 2048x2048 - every activation of that level is one 4.3 GB fp32 NHWC image, more than a buffer descriptor spans, and goes through the F8 3x3
+    kernel's per-tile row-band descriptors - against the fp32 oracle (row-blocked attention at this size: 65536 tokens), at the north star's tolerance.
+    (The full architecture at this size exceeds what the host oracle can follow; test_e2e_full_model_2048_images_beyond_4gb covers it by self-comparison.)"""
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    cfg = SDMatteConfig(vae_channels=(256, 64, 64, 64), unet_channels=(64, 128, 128, 128), unet_heads=(1, 2, 2, 2), cross_attention_dim=64,
+                        point_embeddings_input_dim=64, bbox_embeddings_input_dim=256, name="wide_first_level")
+    S = 2048
+    assert S * S * cfg.vae_channels[0] * 4 >= (1 << 32)
+    from comfyui_sdmatte_amd import engine as E
+    lib = E.load_library()
+    lib.kernel_counts(reset=True)
+    m, w, img, tri, data, ref, out, d = _run(pkg, cfg, S, 1, seed=41)
+    counts = lib.kernel_counts()
+    print(f"\n[2048^2, 256-channel first VAE level: 4.3 GB operand images] max|d|={d.max():.3e} mean|d|={d.mean():.3e}  F8 3x3 launches {counts.get('conv3x3_f8', 0) + counts.get('conv3x3_f8<gn>', 0)}")
+    assert counts.get("conv3x3_f8<gn>", 0) >= 4, counts          # the 256 -> 256 ResBlock convs of the 2048-row level ran on the row-band kernel
+    assert d.max().item() <= TOL
+    m.engine.close()
+
+
+def test_checkpoint_variants_load_to_identical_engines_on_gpu(pkg, tmp_path):
+    """The checkpoint shapes a real `SDMatte*.safetensors` may have (fp16 / bf16 storage, diffusers' legacy VAE attention names, a text_encoder.* subtree),
+    streamed through the node's loader into the REAL engine: pinned staging ring -> HIP pack kernels -> derived layouts on the device.  Every variant must
+    give the packed canonical arena of an fp32 file holding the same values, bit for bit, and the same alpha (tests/test_emu_e2e.py has the emulator form)."""
+    from safetensors.torch import save_file
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    from comfyui_sdmatte_amd.engine import Engine
+    from comfyui_sdmatte_amd.weights import synthetic_state_dict
+    from comfyui_sdmatte_amd.synth import synthetic_inputs
+    from comfyui_sdmatte_amd.sdmatte_nodes import LazyCheckpoint
+    cfg = SDMatteConfig.tiny_d512()
+    w = synthetic_state_dict(cfg, 3)
+    img, tri = synthetic_inputs(1, 128, 128, seed=5)
+
+    def load(path):
+        eng = Engine(cfg, 0)
+        missing, ignored = eng.load_state_dict(LazyCheckpoint(str(path)), strict=True)
+        assert not missing and ignored == 0
+        dev = torch.empty(eng.weight_blob_bytes(), dtype=torch.uint8, device="cuda")
+        host = torch.empty(eng.host_blob_bytes(), dtype=torch.uint8)
+        eng.export_weights(dev, host)
+        a = eng.apply_matte(img.cuda(), tri.cuda(), 128, False).cpu()
+        eng.close()
+        return dev.cpu(), host, a
+
+    def legacy_names(sd):
+        out = {}
+        for k, v in sd.items():
+            if k.startswith("vae.") and "mid_block.attentions.0" in k:
+                for a, b in ((".to_q.", ".query."), (".to_k.", ".key."), (".to_v.", ".value."), (".to_out.0.", ".proj_attn.")):
+                    k = k.replace(a, b)
+            out[k] = v
+        return out
+
+    for dt in (torch.float16, torch.bfloat16):
+        f32 = tmp_path / f"f32_{dt}.safetensors"
+        save_file({k: v.to(dt).float().contiguous() for k, v in w.items()}, str(f32))
+        low = {k: v.to(dt).contiguous() for k, v in legacy_names(w).items()}
+        low["text_encoder.text_model.embeddings.token_embedding.weight"] = torch.zeros(8, 4, dtype=dt)
+        lowf = tmp_path / f"low_{dt}.safetensors"
+        save_file(low, str(lowf))
+        d0, h0, a0 = load(f32)
+        d1, h1, a1 = load(lowf)
+        assert torch.equal(d0, d1) and torch.equal(h0, h1) and torch.equal(a0, a1), str(dt)
+
+
+@pytest.mark.slow
 def test_e2e_beyond_1024_vs_oracle(pkg):
     """SURVEY.md 8(f)4, oracle-grade: an input beyond the node's 1024x1024 (1536x1536: 36864 tokens at the first U-Net level, 147456 pixels
     per VAE attention) against the fp32 oracle, whose attention walks the query rows in blocks at this size (same numbers, bounded
