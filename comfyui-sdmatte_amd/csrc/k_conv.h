@@ -1593,42 +1593,63 @@ conv_mfma_kernel(ConvParams p) {
     for (int j = 0; j < NTL; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) b4[j][g] = *(const f32x4*)(bias_tab + wn * WTN + j * 32 + 8 * g + 4 * hi);
-    float s1[NTL][16], s2[NTL][16];
-#pragma unroll
-    for (int j = 0; j < NTL; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { s1[j][r] = 0.0f; s2[j][r] = 0.0f; }
 #if defined(SDM_CONV_LAB) && !defined(SDM_EMU)
     const bool do_store = !(p.ablate & 8);
 #else
     constexpr bool do_store = true;
 #endif
     const bool do_stats = p.stats != nullptr;
-    // (fast_epi: acc_scale == 1 - F8 layers accumulate in the output's unit -, out_scale == 1, every channel of the tile valid: no
-    // predicates, no scaling, no vector-memory wait)
+    // per-channel sums over this wave's 128 pixels for the consumer's GroupNorm: in-lane over the 4 sub-tiles, then over the 16 lanes of each DPP row; the two
+    // rows of a lane half meet in a wave-private LDS scratch, from which lane c writes channel c of the partial row - one coalesced store
+    float* sc = (float*)(smem + C::SCR_OFF) + wave * 256;            // [2 rows][64 channels][sum, sumsq]
+    unsigned int so[MT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const unsigned int so = sub_px(i) * cs4;
+    for (int i = 0; i < MT; ++i) so[i] = sub_px(i) * cs4;
+    // (fast_epi: acc_scale == 1 - F8 layers accumulate in the output's unit -, out_scale == 1, every channel of the tile valid: no predicates, no scaling,
+    // no vector-memory wait.)  Channel quad by channel quad, the four sub-tiles of a quad back to back: a quad's statistics are complete after its four
+    // stores and are reduced (four DPP stages over eight independent values: no wait states) while the wave would otherwise sit in the store queue - the CU
+    // accepts one 16-byte store instruction per ~65 cycles.  (Reduced after the last store, value by value, the statistics cost 3.8 k cycles per tile.)
 #pragma unroll
-      for (int j = 0; j < NTL; ++j)
+    for (int j = 0; j < NTL; ++j)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          // the bias is added in place and the quad stored from the accumulator registers themselves (no temporary quad whose rewrite could
-          // run into the store-data hazard below; timing is unchanged: the 32 stores issue at the CU's store rate either way)
+      for (int g = 0; g < 4; ++g) {
+        float t1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, t2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          // the bias is added in place and the quad stored from the accumulator registers themselves (no temporary quad whose rewrite could run into the
+          // store-data hazard below)
           f32x4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) { acc[i][j][4 * g + e] += b4[j][g][e]; v[e] = acc[i][j][4 * g + e]; }
-          if (do_store) sdm_buffer_store16(__builtin_bit_cast(u32x4, v), rso, vo + (unsigned int)((j * 32 + 8 * g) * 4), so);
+          if (do_store) sdm_buffer_store16(__builtin_bit_cast(u32x4, v), rso, vo + (unsigned int)((j * 32 + 8 * g) * 4), so[i]);
           if (do_stats) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { s1[j][4 * g + e] += v[e]; s2[j][4 * g + e] += v[e] * v[e]; }
+            for (int e = 0; e < 4; ++e) { t1[e] += v[e]; t2[e] += v[e] * v[e]; }
           }
           // the store's data registers stay untouched until here: on gfx950 a v_pk_* that rewrites them two instructions behind a
           // buffer_store_dwordx4 changes what lanes 12-15 of each 16 store (profiles/r03_conv_epilogue_branchfree_ab.txt)
           SDM_PIN_STORE_DATA(v);
         }
-      stamp();                   // (traced builds) sub-tile i issued
-    }
+        if (do_stats) {
+#ifdef SDM_EMU
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { t1[e] = sdm_sum_row16(t1[e]); t2[e] = sdm_sum_row16(t2[e]); }
+#else
+#define SDM_STAT_STAGE(ctrl) _Pragma("unroll") for (int e = 0; e < 4; ++e) { t1[e] = SDM_DPP_ADD(t1[e], ctrl); t2[e] = SDM_DPP_ADD(t2[e], ctrl); } SDM_SCHED_FENCE();
+          SDM_STAT_STAGE(0xB1) SDM_STAT_STAGE(0x4E) SDM_STAT_STAGE(0x124) SDM_STAT_STAGE(0x128)
+#undef SDM_STAT_STAGE
+#endif
+          if ((lane & 15) == 0) {
+            float* dst = sc + (((lane >> 4) & 1) * WTN + j * 32 + 8 * g + 4 * hi) * 2;
+            f32x4 o0, o1;
+            o0[0] = t1[0]; o0[1] = t2[0]; o0[2] = t1[1]; o0[3] = t2[1];
+            o1[0] = t1[2]; o1[1] = t2[2]; o1[2] = t1[3]; o1[3] = t2[3];
+            *(f32x4*)dst = o0;
+            *(f32x4*)(dst + 4) = o1;
+          }
+        }
+        if (g & 1) stamp();        // (traced builds) a quarter of the tile issued
+      }
 #if !defined(SDM_EMU) && defined(__HIP_DEVICE_COMPILE__)      // (device pass only: a 512-bit "v" operand is not valid x86 inline asm)
     // the biased accumulators stay live to this point, so that hipcc really keeps every store's data in its own registers
     asm volatile("" :: "v"(acc[0][0]), "v"(acc[0][NTL - 1]), "v"(acc[MT > 1 ? 1 : 0][0]), "v"(acc[MT > 1 ? 1 : 0][NTL - 1]),
@@ -1636,35 +1657,6 @@ conv_mfma_kernel(ConvParams p) {
     static_assert(!FASTEPI || (MT <= 4 && NTL <= 2), "operand list above");
 #endif
     if (do_stats) {
-      // per-channel sums over this wave's 128 pixels: in-lane over the 4 sub-tiles (above), then over the 16 lanes of each DPP row;
-      // the two rows of a lane half meet in a wave-private LDS scratch (the second A buffer is free during the epilogue), from which
-      // lane c writes channel c of the partial row - one coalesced store, as the LDS-staged epilogue does
-      float* sc = (float*)(smem + C::SCR_OFF) + wave * 256;            // [2 rows][64 channels][sum, sumsq]
-      // (stage by stage over all 64 values: a value-by-value chain of four dependent DPP adds costs a wait state each - 125 s_nop and 3.8 k cycles
-      //  per tile in the round-4 trace; and ONE masked region for the 32 writes instead of 32)
-#ifdef SDM_EMU
-#pragma unroll
-      for (int j = 0; j < NTL; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s1[j][r] = sdm_sum_row16(s1[j][r]); s2[j][r] = sdm_sum_row16(s2[j][r]); }
-#else
-#define SDM_STAT_STAGE(ctrl)                                                                                   \
-      _Pragma("unroll") for (int j = 0; j < NTL; ++j) _Pragma("unroll") for (int r = 0; r < 16; ++r) {        \
-        s1[j][r] = SDM_DPP_ADD(s1[j][r], ctrl); s2[j][r] = SDM_DPP_ADD(s2[j][r], ctrl); }                     \
-      SDM_SCHED_FENCE();
-      SDM_STAT_STAGE(0xB1) SDM_STAT_STAGE(0x4E) SDM_STAT_STAGE(0x124) SDM_STAT_STAGE(0x128)
-#undef SDM_STAT_STAGE
-#endif
-      if ((lane & 15) == 0) {
-#pragma unroll
-        for (int j = 0; j < NTL; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            f32x2 o2;
-            o2[0] = s1[j][r]; o2[1] = s2[j][r];
-            *(f32x2*)(sc + (((lane >> 4) & 1) * WTN + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 2) = o2;
-          }
-      }
       SDM_WAVE_SYNC();
       if (lane < WTN) {
         const f32x2 a = *(const f32x2*)(sc + lane * 2), b = *(const f32x2*)(sc + (WTN + lane) * 2);
