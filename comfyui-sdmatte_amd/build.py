@@ -45,15 +45,37 @@ def build_all(verbose=False, force=False, extra_flags=(), out=None):
         if verbose:
             print(f"[sdmatte] {lib} is up to date")
         return lib
-    cmd = [_hipcc()] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", lib]
-    if verbose:
-        print("[sdmatte] " + " ".join(cmd))
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        sys.stderr.write(r.stdout + r.stderr)
-        raise RuntimeError("hipcc failed building libsdmatte_hip.so")
-    if verbose and r.stderr.strip():
-        print(r.stderr[-4000:])
+    # compiled in a scratch directory with -save-temps: the device assembly is a by-product there, and the F8 3x3 kernel's asynchronous (inline-asm)
+    # activation loads are checked against it before the library is accepted (tools/check_async_loads.py: no instruction may touch a load's
+    # destination registers before the hand-over six barriers later - hipcc has no notion of a result that is still in flight)
+    import tempfile
+    with tempfile.TemporaryDirectory(prefix="sdmatte_build_") as tmp:
+        tlib = os.path.join(tmp, "lib.so")
+        cmd = [_hipcc()] + FLAGS + ["-save-temps"] + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tlib]
+        if verbose:
+            print("[sdmatte] " + " ".join(cmd))
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=tmp)
+        if r.returncode != 0:
+            sys.stderr.write(r.stdout + r.stderr)
+            raise RuntimeError("hipcc failed building libsdmatte_hip.so")
+        if verbose and r.stderr.strip():
+            print(r.stderr[-4000:])
+        asm = [f for f in os.listdir(tmp) if f.endswith("gfx950.s")]
+        if not asm:
+            raise RuntimeError("device assembly not found behind -save-temps: cannot check the asynchronous loads of the F8 conv kernel")
+        sys.path.insert(0, os.path.join(HERE, "..", "tools"))
+        try:
+            import check_async_loads
+            with open(os.path.join(tmp, asm[0])) as fh:
+                checked, problems = check_async_loads.check(fh.read())
+        finally:
+            sys.path.pop(0)
+        if problems:
+            sys.stderr.write("\n".join(problems) + "\n")
+            raise RuntimeError("F8 conv kernel: an asynchronously loaded register is touched before its hand-over (tools/check_async_loads.py)")
+        if verbose:
+            print(f"[sdmatte] {checked} asynchronous loads of the F8 conv kernels checked")
+        shutil.move(tlib, lib)
     # a kernel whose body the HOST pass rejects (e.g. inline asm that is only valid for gfx950) is dropped without a diagnostic and leaves
     # an undefined stub symbol: load the library once so that this fails here, in the build container, and not on the GPU box
     # (in a child process: the library must not stay mapped in the builder - a later rebuild to the same path would otherwise meet a stale mapping - and a

@@ -1172,7 +1172,6 @@ conv_mfma_kernel(ConvParams p) {
       };
       stamp(1);                         // tile start (both roles)
       if (role) {
-        const bool pre_at_entry = pre_done != 0;
         dma_bias_tab(bias_tab, img, n0);      // (needed by the consumers' epilogue; the step loop's waits see it landed long before)
         if (!pre_done) {                // (a tile prepared by its predecessor has its weights in the ring, its chunk 0 in LDS (high planes) / f8h, its chunk 1 in a_nx)
           dma_step(0, 0);
@@ -1186,12 +1185,21 @@ conv_mfma_kernel(ConvParams p) {
           write_hi(0, A_PER);
           write_f8(false);
           SDM_WAIT_VMCNT0();
-          if (nch > 1) {                // chunk 1: in flight across the first barrier (waited for at the first step, below)
+          if (nch > 1) {
+            // chunk 1 - waited for HERE, inside the block that issues the loads: a_nx / gqn are loop-carried, and a register copy hipcc may place
+            // where this path joins the loop must not find them half-written (an asm load's result "exists" at once for the compiler).  A
+            // block's first tile only: every later tile is staged by its predecessor
 #pragma unroll
             for (int i = 0; i < A_PER; ++i) issue_nx_vec(i, (32 >= p.C0) ? rq1 : rq0, (unsigned int)((32 >= p.C0) ? p.C1 : p.C0) * es,
                                                          (unsigned int)(((32 >= p.C0) ? 32 - p.C0 : 32) + a_part) * es, false);
             issue_nx_gn(32, false);
             SDM_SCHED_FENCE();
+            SDM_WAIT_VMCNT0();
+#ifndef SDM_EMU
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i) asm volatile("" : "+v"(a_nx[i][0]), "+v"(a_nx[i][IN_F32 ? 1 : 0]) :: "memory");
+            if (GN) asm volatile("" : "+v"(gqn[0]), "+v"(gqn[1]), "+v"(gqn[2]), "+v"(gqn[3]) :: "memory");
+#endif
           }
         } else {
           write_f8(true);               // chunk 0's fp8 image: nobody reads that region between a tile's last barrier and the next tile's first
@@ -1215,7 +1223,6 @@ conv_mfma_kernel(ConvParams p) {
           for (int k = 0; k < 6; ++k) {                  // step t = 6c + k: (dx = k / 2, S1 | S2)
             const int t = c * 6 + k;
             if (k == 0 && c > 0) write_f8(false);         // the current chunk's fp8 image (its high planes went out during the previous step)
-            if (k == 0 && c == 0 && !pre_at_entry && nch > 1) SDM_WAIT_VMCNT0();      // the prologue's loads of chunk 1 (a block's first tile only)
             // vector k of the staged chunk: loaded six steps ago (every step's end waits for everything but the two youngest steps' operations)
             if (morex) { take_vec(k); if (k == 0) take_gn(); }
             SDM_SCHED_FENCE();
