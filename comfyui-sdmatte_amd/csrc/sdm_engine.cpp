@@ -242,11 +242,6 @@ static int conv_pick_cfg(int ntaps, int stride, const ConvParams& p) {
           (long)p.N * sdm_cdiv(p.Hout, 8) * sdm_cdiv(p.Wout, 32) * sdm_cdiv(p.Cout_pad, 128) >= 256) return 3;
       // fp32 activations into the 256x128 GEMM tile: K-chunks of 32 (the 64-channel chunk needs 64 staging registers on top of
       // the 128 accumulators and spills)
-      // square transformer projections (K <= 640 into <= 640 channels, fp32 activations): the 128 x 64 tile - five exact column tiles of 320 channels
-      // instead of three 128-wide ones with a sixth of the last idle, and 2.5 x the blocks in flight; measured x1.09-1.11 on 320 -> 320 @128^2 and
-      // 640 -> 640 @64^2 at four images (tools/gemm_cfg_ab.py, profiles/r05_gemm_cfg_ab.txt); wider outputs and K >= 1024 stay on the 256 x 128 tile
-      if (ntaps == 1 && i == 0 && p.in_f32 && p.Cout_pad <= 640 && (p.C0 + p.C1) <= 640 && conv_cfg_ok(t[1], p) &&
-          ((p.M + 127) / 128) * sdm_cdiv(p.Cout_pad, 64) >= 1024) return 1;
       if (ntaps == 1 && i == 0 && p.in_f32 && conv_cfg_ok(t[4], p)) return 4;
       return i;
     }
