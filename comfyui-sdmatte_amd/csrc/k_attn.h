@@ -33,6 +33,12 @@ struct AttnParams {
   // bias <= max - margin, so its probability 2^(x - rowmax) underflows to EXACTLY 0 in fp32 - in the reference too (trimap keys carry
   // (1-m)*-10000: replace.py:401-403) - and its tile is not loaded at all.
   const int* tiles; int tiles_bs;
+  // Key split (d = 64, fp32 output; grid.y = nsplit > 1): block row y walks the 64-key tiles [y, y + 1) * ceil(ntiles / nsplit) only and leaves
+  // UNNORMALISED partial results - O^T sums in `o` (which then is a workspace: fp32 [nsplit][b][row][head*64 + d], split stride part_stride elements),
+  // running maximum and denominator in part_ml[((y * batch + b) * heads + head) * Lq + row][2] - for attn_combine_kernel.  Launches whose blocks do not
+  // fill the chip's block slots a whole number of times (one image: 640 four-wave blocks on 512 slots) run as twice or four times as many
+  // short blocks.  The ranges are ranges of KEY TILES, so a walk along the active-tile list and the dense walk split at the same keys.
+  int nsplit; long part_stride; float* part_ml;
   int batch, heads, nq_blocks, q_chunks;   // XCD-aware 1-D grid (attn_d64): see attn_block_coords
   int ablate;   // bench only (sdm_bench_attn): 1 skip softmax VALU, 2 skip PV MFMAs, 4 skip QK^T MFMAs, 8 skip K/V global prefetch; 0 in the engine
 };
@@ -69,6 +75,34 @@ SDM_DEV_INLINE bool attn_block_coords(const AttnParams& p, int bid, int& b, int&
   qblk = chunk * qb + s % qb;
   b = bh / p.heads; head = bh % p.heads;
   return qblk < p.nq_blocks;
+}
+
+// key split: the part of the tile walk that belongs to block row `sp` -> first walk index, number of tiles (block-uniform; may be 0)
+SDM_DEV_INLINE void attn_split_range(const AttnParams& p, const int* tl, int ntiles, int nwalk_all, int sp, int& i0, int& nwalk) {
+  i0 = 0; nwalk = nwalk_all;
+  if (p.nsplit <= 1) return;
+  const int per = (ntiles + p.nsplit - 1) / p.nsplit, t0 = sp * per, t1 = (t0 + per < ntiles) ? t0 + per : ntiles;
+  if (!tl) { i0 = t0 < ntiles ? t0 : ntiles; nwalk = t1 > i0 ? t1 - i0 : 0; return; }
+  // sorted list of active tiles: lower bounds of t0 and t1 (binary search over wave-uniform scalar loads)
+  auto lower = [&](int key) {
+    int lo = 0, hi = nwalk_all;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (tl[1 + mid] < key) lo = mid + 1; else hi = mid; }
+    return lo;
+  };
+  i0 = lower(t0);
+  nwalk = lower(t1) - i0;
+}
+// partial results of a block row that has no tile to walk: nothing summed, maximum at the floor (weight 0 in the combine)
+SDM_DEV_INLINE void attn_write_empty_part(const AttnParams& p, int sp, int b, int head, int q0, int lane) {
+  float* po = (float*)p.o + (size_t)sp * p.part_stride + (size_t)b * p.o_bs;
+  for (int i = lane; i < 32 * 16; i += 64) {
+    const int row = i >> 4, part = i & 15, qg = q0 + row;
+    if (qg < p.Lq) *(f32x4*)(po + (size_t)qg * p.ldo + head * 64 + part * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if (lane < 32 && q0 + lane < p.Lq) {
+    float* ml = p.part_ml + ((((size_t)sp * p.batch + b) * p.heads + head) * p.Lq + q0 + lane) * 2;
+    ml[0] = SDM_NEG_BIG; ml[1] = 0.0f;
+  }
 }
 
 // PREC = 1 (precise mode): q, k and V^T arrive as fp16 pairs hi + lo and the probabilities are split the same way, every
@@ -233,8 +267,11 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_kernel(AttnParams p) {
   };
   // tile walk: all ntiles tiles, or the active-tile list of this image (wave-uniform scalar loads)
   const int* tl = p.tiles ? p.tiles + (size_t)b * p.tiles_bs : nullptr;
-  const int nwalk = tl ? tl[0] : ntiles;
-  auto tile_at = [&](int i) { return tl ? tl[1 + i] : i; };
+  const int sp = p.nsplit > 1 ? (int)blockIdx.y : 0;
+  int i0, nwalk;
+  attn_split_range(p, tl, ntiles, tl ? tl[0] : ntiles, sp, i0, nwalk);
+  if (nwalk <= 0) { attn_write_empty_part(p, sp, b, head, q0, lane); return; }      // (key split only; block-uniform, before the first barrier)
+  auto tile_at = [&](int i) { return tl ? tl[1 + i0 + i] : i0 + i; };
   prefetch(tile_at(0), ra);
   stage(0, ra);
   __syncthreads();
@@ -436,7 +473,13 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_kernel(AttnParams p) {
     unsigned char* stf = smem + wave * (32 * PS);
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-      const float inv = 1.0f / (PVS ? (lsum + __shfl_xor(lsum, 32)) : ls[qt][0]);      // PVS: lanes l and l^32 hold the two key halves of query l&31
+      const float lsum_q = PVS ? (lsum + __shfl_xor(lsum, 32)) : ls[qt][0];      // PVS: lanes l and l^32 hold the two key halves of query l&31
+      const float inv = p.nsplit > 1 ? 1.0f : 1.0f / lsum_q;                      // key split: unnormalised partial sums (attn_combine_kernel divides)
+      float* obase = (float*)p.o + (p.nsplit > 1 ? (size_t)sp * p.part_stride : (size_t)0) + (size_t)b * p.o_bs;
+      if (p.nsplit > 1 && hi == 0 && q0 + qt * 32 + l31 < p.Lq) {
+        float* ml = p.part_ml + ((((size_t)sp * p.batch + b) * p.heads + head) * p.Lq + q0 + qt * 32 + l31) * 2;
+        ml[0] = m_i[qt]; ml[1] = lsum_q;
+      }
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -452,7 +495,7 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_kernel(AttnParams p) {
         const int row = pass * 4 + (lane >> 4), part = lane & 15;
         const int qg = q0 + qt * 32 + row;
         if (qg < p.Lq)
-          *(f32x4*)((float*)p.o + (size_t)b * p.o_bs + (size_t)qg * p.ldo + head * 64 + part * 4) = *(const f32x4*)(stf + row * PS + part * 16);
+          *(f32x4*)(obase + (size_t)qg * p.ldo + head * 64 + part * 4) = *(const f32x4*)(stf + row * PS + part * 16);
       }
       SDM_WAVE_SYNC();
     }
@@ -546,8 +589,11 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_pipe_kernel(AttnParams p)
   const float* bsrc = bbase ? bbase : (const float*)(p.k + (size_t)b * p.k_bs);
   const int ntiles = (p.Lk + 63) / 64;
   const int* tl = p.tiles ? p.tiles + (size_t)b * p.tiles_bs : nullptr;
-  const int nwalk = tl ? tl[0] : ntiles;
-  auto tile_at = [&](int i) { return tl ? tl[1 + i] : i; };
+  const int sp = p.nsplit > 1 ? (int)blockIdx.y : 0;
+  int i0, nwalk;
+  attn_split_range(p, tl, ntiles, tl ? tl[0] : ntiles, sp, i0, nwalk);
+  if (nwalk <= 0) { attn_write_empty_part(p, sp, b, head, q0, lane); return; }      // (key split only; block-uniform, before the first barrier)
+  auto tile_at = [&](int i) { return tl ? tl[1 + i0 + i] : i0 + i; };
 
   // one raw tile between global memory and LDS (VPT 16-byte vectors of K_hi, K pair plane and V^T per thread, one bias value per lane)
   f16x8 rk[VPT], rkl[VPT], rv[VPT];
@@ -688,7 +734,12 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_pipe_kernel(AttnParams p)
   // epilogue (fp32 output): per-wave staging [32 q][64 d] at pitch 272 B -> coalesced 16-byte row stores
   constexpr int PS = 272;
   unsigned char* stf = smem + wave * (32 * PS);
-  const float inv = 1.0f / ls[0];
+  const float inv = p.nsplit > 1 ? 1.0f : 1.0f / ls[0];                 // key split: unnormalised partial sums (attn_combine_kernel divides)
+  float* obase = (float*)p.o + (p.nsplit > 1 ? (size_t)sp * p.part_stride : (size_t)0) + (size_t)b * p.o_bs;
+  if (p.nsplit > 1 && hi == 0 && q0 + l31 < p.Lq) {
+    float* ml = p.part_ml + ((((size_t)sp * p.batch + b) * p.heads + head) * p.Lq + q0 + l31) * 2;
+    ml[0] = m_i; ml[1] = ls[0];
+  }
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -704,7 +755,7 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_pipe_kernel(AttnParams p)
     const int row = pass * 4 + (lane >> 4), part = lane & 15;
     const int qg = q0 + row;
     if (qg < p.Lq)
-      *(f32x4*)((float*)p.o + (size_t)b * p.o_bs + (size_t)qg * p.ldo + head * 64 + part * 4) = *(const f32x4*)(stf + row * PS + part * 16);
+      *(f32x4*)(obase + (size_t)qg * p.ldo + head * 64 + part * 4) = *(const f32x4*)(stf + row * PS + part * 16);
   }
 }
 
@@ -912,6 +963,36 @@ __global__ void __launch_bounds__(512) attn_d512_kernel(AttnParams p) {
 }
 
 // Active key tiles of every image (see AttnParams::tiles): one block per image.  bias is the log2-domain key bias [B][Lk].
+// Key split, second pass: out[b][row][head*64 + d] = sum_s o_s * 2^(m_s - M) / sum_s l_s * 2^(m_s - M), M = max_s m_s (log2 domain, as the kernels keep it).
+// A block row that walked no contributing key has l_s = 0 or m_s far below M: weight exactly 0 - the same zero its keys have in the unsplit walk.
+// 16 threads per (row, head), 4 channels each; grid = ceil(batch * Lq * heads * 16 / 256).
+__global__ void __launch_bounds__(256) attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml, float* __restrict__ out,
+                                                           int nsplit, long part_stride, int batch, int heads, int Lq, long o_bs, int ldo) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int part = (int)(t & 15);
+  const long rh = t >> 4;                       // (b * Lq + row) * heads + head
+  if (rh >= (long)batch * Lq * heads) return;
+  const int head = (int)(rh % heads);
+  const long br = rh / heads;
+  const int row = (int)(br % Lq), b = (int)(br / Lq);
+  float M = SDM_NEG_BIG;
+  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, part_ml[((((size_t)s * batch + b) * heads + head) * Lq + row) * 2]);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float L = 0.0f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float* ml = part_ml + ((((size_t)s * batch + b) * heads + head) * Lq + row) * 2;
+    const float w = sdm_exp2(ml[0] - M);
+    L += ml[1] * w;
+    const f32x4 v = *(const f32x4*)(part_o + (size_t)s * part_stride + (size_t)b * o_bs + (size_t)row * ldo + head * 64 + part * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] += v[e] * w;
+  }
+  const float inv = 1.0f / L;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc[e] *= inv;
+  *(f32x4*)(out + (size_t)b * o_bs + (size_t)row * ldo + head * 64 + part * 4) = acc;
+}
+
 __global__ void __launch_bounds__(256) attn_active_tiles_kernel(const float* __restrict__ bias, int Lk, int ntiles, int* __restrict__ out,
                                                                 int out_bs, float margin) {
   SDM_SHARED float red[256];

@@ -115,6 +115,7 @@ static OptEntry g_opts[] = {
   {"attn_nw", 0, 0, "waves per d=64 attention block: 0 by launch size, 4, 8"},
   {"attn_pipe", 1, 1, "8-wave split-precision d=64 attention: two-tile software pipeline"},
   {"attn_pipe4", 1, 1, "the same pipeline for the 4-wave launches (two K / three V^T buffers)"},
+  {"attn_ksplit", 0, 0, "key split of the d=64 split-precision attention: 0 by launch size (blocks that do not fill the chip's block slots a whole number of times), 1 off, 2 / 4 forced"},
   {"precise_mask", -1, -1, "stages in split precision (-1 = the config's own mask; per-stage attribution experiments; read at sdm_create)"},
 };
 static OptEntry* opt_find(const char* name) {
@@ -277,17 +278,29 @@ static int conv_pick_ksplit(int ntaps, int stride, int cfg, const ConvParams& p)
 
 // F8 conv kernel: tiles a block runs back to back (the producer waves stage tile k+1 under the epilogue of tile k).  Only when
 // every CU still gets a block: 160 tiles as 80 two-tile blocks measured 0.43 vs 0.26 ms.  The option conv_f8_tpb overrides (A/B).
+// compute units of the current device (256 on an MI355X)
+static int device_cus() {
+#ifdef SDM_EMU
+  return 256;
+#else
+  static std::atomic<int> cus{0};
+  int c = cus.load(std::memory_order_relaxed);
+  if (!c) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    c = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+    cus.store(c, std::memory_order_relaxed);
+  }
+  return c;
+#endif
+}
+
 static int conv_f8_tiles_per_block(long tiles) {
 #ifdef SDM_EMU
   return tiles >= 6 ? 3 : (tiles >= 2 ? 2 : 1);
 #else
   if (opt("conv_f8_tpb") >= 1 && opt("conv_f8_tpb") <= 8) return opt("conv_f8_tpb");
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    hipDeviceProp_t pr;
-    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
-  }
+  const int cus = device_cus();
   // measured (profiles/r02_conv_f8_tiles_per_block.txt): 128->128 @1024^2 (64 tiles per CU) 490 / 504 / 516 TFLOP/s at 1 / 2 / 4 tiles per
   // block; 320->320 @128^2 (3 per CU) 542 / 455; 1280->1280 @32^2 (0.6 per CU) 575 / 299: only deep queues gain
   const long per_cu = tiles / cus;
@@ -1189,6 +1202,28 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
   T tl_own;
   const bool own_list = (D == 64) && bias_l2 && !tiles && !dense_attn;
   if (own_list) tl_own = talloc(e, B, 1, 1, ntiles64 + 1, 1);
+  // Key split (k_attn.h AttnParams::nsplit; split-precision d = 64 with fp32 output only).  A launch whose blocks fill the chip's block slots 1.25 times
+  // takes as long as one that fills them twice; walking half (a quarter) of the keys per block and combining the partial sums afterwards turns
+  // that into 2.5 (5) rounds of half (quarter) length.  Chosen by block count alone - the same for the dense and the tile-list walk, whose ranges are key
+  // ranges - and only for long walks (>= 32 tiles per part).  One image at 1024^2: 640 four-wave blocks on 512 slots at the first U-Net level.
+  int nsplit = 1;
+  T part_o, part_ml;
+  if (D == 64 && ap.prec && ap.out_f32 && !(ap.prec == 1 && opt("attn_pv_split"))) {
+    const int force_nw = opt("attn_nw");
+    const bool nw8 = force_nw ? (force_nw == 8) : ((long)B * heads * sdm_cdiv(Lq, 256) >= 1024);
+    const long blocks = (long)B * heads * 8 * sdm_cdiv(sdm_cdiv(Lq, nw8 ? 256 : 128), 8), slots = (long)device_cus() * (nw8 ? 1 : 2);
+    const int o = opt("attn_ksplit");
+    if (o >= 2) nsplit = (o == 2 || o == 4) ? o : 1;
+    else if (o == 0) {
+      auto rounds = [&](int s) { return (double)((blocks * s + slots - 1) / slots) / s; };
+      for (int s = 2; s <= 4; s *= 2)
+        if (ntiles64 / s >= 32 && rounds(s) < 0.85 * rounds(nsplit)) nsplit = s;
+    }
+    if (nsplit > 1) {
+      part_o = talloc(e, nsplit * B, Lq, 1, ldo, 1);
+      part_ml = talloc(e, nsplit * B, heads, Lq, 2, 1);
+    }
+  }
   if (!e->dry) {
     if (own_list) {
       SDM_LAUNCH(attn_active_tiles_kernel, dim3(B), dim3(256), 0, e->stream, bias_l2, Lk, ntiles64, (int*)tl_own.p, ntiles64 + 1, SDM_ATTN_SKIP_MARGIN);
@@ -1217,6 +1252,8 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
     p.q_lo = ap.q_lo; p.k_lo = ap.k_lo; p.vt_lo = (long)B * vt_bs;
     p.Lq = Lq; p.Lk = Lk;
     p.scale_log2e = q_prescaled ? 1.0f : (1.0f / sqrtf((float)D)) * SDM_LOG2E;      // engine: folded into the to_q weights (d = 64 only)
+    if (nsplit > 1) { p.nsplit = nsplit; p.o = (half_t*)part_o.p; p.part_stride = (long)B * p.o_bs; p.part_ml = (float*)part_ml.p; }
+    const unsigned gy = (unsigned)(nsplit > 1 ? nsplit : 1);
     double flops = 4.0 * B * heads * (double)Lq * Lk * D;
     const double bytes = 2.0 * B * heads * D * (2.0 * Lq + 2.0 * Lk);
     std::string adesc = "B=" + std::to_string(B) + " h=" + std::to_string(heads) + " Lq=" + std::to_string(Lq) + " Lk=" + std::to_string(Lk);
@@ -1248,19 +1285,25 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
         // 8-wave blocks with fp32 output (the engine's level-0 attentions): the two-tile software pipeline of the kernel (k_attn.h,
         // attn_d64_pipe_kernel: same arithmetic, bit-identical results, -9 % kernel time); option attn_pipe = 0 selects the plain form.
         const bool pipe8 = opt("attn_pipe") != 0, pipe4 = opt("attn_pipe4") != 0;
-        if (nw8 && pipe8 && p.o_f32) { count_kernel("attn_d64_pipe<8>"); auto kp = attn_d64_pipe_kernel<8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(512), ATTN64PIPE_SMEM, e->stream, p); }
-        else if (!nw8 && pipe4 && p.o_f32) { count_kernel("attn_d64_pipe<4>"); auto kp = attn_d64_pipe_kernel<4>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(256), ATTN64PIPE4_SMEM, e->stream, p); }
-        else if (nw8) { count_kernel("attn_d64<prec3,8>"); auto kp = attn_d64_kernel<1, 3, 8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(512), ATTN64P_SMEM, e->stream, p); }
-        else { count_kernel("attn_d64<prec3,4>"); auto kp = attn_d64_kernel<1, 3, 4>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(256), ATTN64P_SMEM, e->stream, p); }
+        if (nw8 && pipe8 && p.o_f32) { count_kernel("attn_d64_pipe<8>"); auto kp = attn_d64_pipe_kernel<8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, gy, 1), dim3(512), ATTN64PIPE_SMEM, e->stream, p); }
+        else if (!nw8 && pipe4 && p.o_f32) { count_kernel("attn_d64_pipe<4>"); auto kp = attn_d64_pipe_kernel<4>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, gy, 1), dim3(256), ATTN64PIPE4_SMEM, e->stream, p); }
+        else if (nw8) { count_kernel("attn_d64<prec3,8>"); auto kp = attn_d64_kernel<1, 3, 8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, gy, 1), dim3(512), ATTN64P_SMEM, e->stream, p); }
+        else { count_kernel("attn_d64<prec3,4>"); auto kp = attn_d64_kernel<1, 3, 4>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, gy, 1), dim3(256), ATTN64P_SMEM, e->stream, p); }
       } else if (ap.prec && pv_split) {
-        if (nw8) { count_kernel("attn_d64<prec1,8>"); auto kp = attn_d64_kernel<1, 1, 8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(512), ATTN64P_SMEM, e->stream, p); }
-        else { count_kernel("attn_d64<prec1,4>"); auto kp = attn_d64_kernel<1, 1, 4>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(256), ATTN64P_SMEM, e->stream, p); }
+        if (nw8) { count_kernel("attn_d64<prec1,8>"); auto kp = attn_d64_kernel<1, 1, 8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, gy, 1), dim3(512), ATTN64P_SMEM, e->stream, p); }
+        else { count_kernel("attn_d64<prec1,4>"); auto kp = attn_d64_kernel<1, 1, 4>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, gy, 1), dim3(256), ATTN64P_SMEM, e->stream, p); }
       } else if (ap.prec) {
-        if (nw8) { count_kernel("attn_d64<prec2,8>"); auto kp = attn_d64_kernel<1, 2, 8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(512), ATTN64P_SMEM, e->stream, p); }
-        else { count_kernel("attn_d64<prec2,4>"); auto kp = attn_d64_kernel<1, 2, 4>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, 1, 1), dim3(256), ATTN64P_SMEM, e->stream, p); }
+        if (nw8) { count_kernel("attn_d64<prec2,8>"); auto kp = attn_d64_kernel<1, 2, 8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, gy, 1), dim3(512), ATTN64P_SMEM, e->stream, p); }
+        else { count_kernel("attn_d64<prec2,4>"); auto kp = attn_d64_kernel<1, 2, 4>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, gy, 1), dim3(256), ATTN64P_SMEM, e->stream, p); }
       } else {
-        if (nw8) { count_kernel("attn_d64<fp16,8>"); auto kf = attn_d64_kernel<1, 0, 8>; SDM_SET_SMEM(kf, 160 * 1024); SDM_LAUNCH(kf, dim3(nblk, 1, 1), dim3(512), ATTN64P_SMEM, e->stream, p); }
-        else { count_kernel("attn_d64<fp16,4>"); SDM_LAUNCH((attn_d64_kernel<1, 0, 4>), dim3(nblk, 1, 1), dim3(256), ATTN64_SMEM, e->stream, p); }
+        if (nw8) { count_kernel("attn_d64<fp16,8>"); auto kf = attn_d64_kernel<1, 0, 8>; SDM_SET_SMEM(kf, 160 * 1024); SDM_LAUNCH(kf, dim3(nblk, gy, 1), dim3(512), ATTN64P_SMEM, e->stream, p); }
+        else { count_kernel("attn_d64<fp16,4>"); SDM_LAUNCH((attn_d64_kernel<1, 0, 4>), dim3(nblk, gy, 1), dim3(256), ATTN64_SMEM, e->stream, p); }
+      }
+      if (nsplit > 1) {
+        count_kernel("attn_combine");
+        const long nthr = (long)B * Lq * heads * 16;
+        SDM_LAUNCH(attn_combine_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, e->stream, (const float*)part_o.p, (const float*)part_ml.p, (float*)out,
+                   nsplit, (long)B * (long)Lq * ldo, B, heads, Lq, (long)Lq * ldo, ldo);
       }
       prof_end(e);
     } else {
@@ -1272,6 +1315,7 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
       prof_end(e);
     }
   }
+  if (nsplit > 1) { tfree(e, part_ml); tfree(e, part_o); }
   if (own_list) tfree(e, tl_own);
   tfree(e, vt);
   return 0;

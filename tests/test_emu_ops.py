@@ -233,6 +233,35 @@ def test_attention_d64_skips_underflowing_key_tiles(emu_engine, engine_option):
     assert torch.equal(sparse, dense)
 
 
+def test_attention_d64_key_split(emu_engine, engine_option):
+    """AttnParams::nsplit (engine option attn_ksplit): block row y walks its range of key tiles and leaves unnormalised partial sums, attn_combine_kernel
+    merges them.  Against fp64 attention, close to the unsplit kernel, and - the ranges being ranges of KEYS - still bit-identical between the walk
+    along the active-tile list and the dense walk; a range without any active tile (an empty part) included."""
+    import torch
+    for ns in (2, 4):
+        engine_option(emu_engine, "attn_ksplit", ns)
+        emu_engine.lib.kernel_counts(reset=True)
+        S.check_attention(emu_engine, DEV, 2, 2, 40, 500, 64, use_bias=True, blocks=True, seed=7, split=True, atol=1e-3)
+        S.check_attention(emu_engine, DEV, 1, 1, 70, 200, 64, use_bias=False, seed=8, split=True, atol=1e-3)
+        assert emu_engine.lib.kernel_counts().get("attn_combine", 0) == 2
+    g = torch.Generator().manual_seed(12)
+    q, k, v = (torch.randn(2, n, 64, generator=g) for n in (50, 640, 640))
+    bias = torch.full((2, 640), -10000.0)
+    bias[0, 130:150] = 0.0          # image 0: active keys in the first quarter only -> three empty parts at nsplit = 4
+    bias[1, 5:9] = 0.0
+    bias[1, 400:] = -5000.0
+    outs = {}
+    for ns in (1, 4):
+        engine_option(emu_engine, "attn_ksplit", ns)
+        engine_option(emu_engine, "attn_dense", 0)
+        sparse = emu_engine.op_attention_split(q, k, v, 1, bias)
+        engine_option(emu_engine, "attn_dense", 1)
+        dense = emu_engine.op_attention_split(q, k, v, 1, bias)
+        assert torch.equal(sparse, dense), ns
+        outs[ns] = sparse
+    assert (outs[1] - outs[4]).abs().max().item() < 2e-6
+
+
 def test_attention_d512(emu_engine):
     S.check_attention(emu_engine, DEV, 1, 1, 40, 64, 512, use_bias=False, atol=5e-3)
     S.check_attention(emu_engine, DEV, 1, 1, 33, 50, 512, use_bias=False, atol=5e-3, seed=2)   # ragged last key tile (clamped DMA rows + mask)

@@ -126,6 +126,36 @@ def test_attention_d64_skips_underflowing_key_tiles(eng, engine_option):
     assert torch.equal(sparse, dense)
 
 
+def test_attention_d64_key_split(eng, engine_option):
+    """AttnParams::nsplit (engine option attn_ksplit): block row y walks its range of key tiles and leaves unnormalised partial sums, attn_combine_kernel
+    merges them.  Against fp64 attention, close to the unsplit kernel, and - the ranges being ranges of KEYS - still bit-identical between the walk
+    along the active-tile list and the dense walk; a range without any active tile (an empty part) included."""
+    import torch
+    for ns in (2, 4):
+        engine_option(eng, "attn_ksplit", ns)
+        eng.lib.kernel_counts(reset=True)
+        S.check_attention(eng, DEV, 2, 5, 1000, 4096, 64, use_bias=True, blocks=True, seed=7, split=True, atol=1e-3)
+        S.check_attention(eng, DEV, 1, 2, 700, 1333, 64, use_bias=False, seed=8, split=True, atol=1e-3)
+        assert eng.lib.kernel_counts().get("attn_combine", 0) == 2
+    g = torch.Generator().manual_seed(12)
+    q, k, v = (torch.randn(2, n, 64, generator=g).to(DEV) for n in (300, 6400, 6400))
+    bias = torch.full((2, 6400), -10000.0)
+    bias[0, 1300:1500] = 0.0          # image 0: active keys in the first quarter only -> three empty parts at nsplit = 4
+    bias[1, 5:9] = 0.0
+    bias[1, 4000:] = -5000.0
+    bias = bias.to(DEV)
+    outs = {}
+    for ns in (1, 4):
+        engine_option(eng, "attn_ksplit", ns)
+        engine_option(eng, "attn_dense", 0)
+        sparse = eng.op_attention_split(q, k, v, 1, bias).cpu()
+        engine_option(eng, "attn_dense", 1)
+        dense = eng.op_attention_split(q, k, v, 1, bias).cpu()
+        assert torch.equal(sparse, dense), ns
+        outs[ns] = sparse
+    assert (outs[1] - outs[4]).abs().max().item() < 2e-6
+
+
 def test_attention_d512(eng):
     S.check_attention(eng, DEV, 1, 1, 1024, 1024, 512, use_bias=False, atol=5e-3)
     S.check_attention(eng, DEV, 2, 1, 200, 320, 512, use_bias=False, atol=5e-3, seed=1)

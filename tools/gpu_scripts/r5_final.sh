@@ -5,4 +5,3 @@ mkdir -p gpurun_out/r5final
 export TMPDIR=/tmp
 timeout 1800 python -m pytest tests -m gpu -q --durations=12 > gpurun_out/r5final/pytest_gpu.log 2>&1; tail -20 gpurun_out/r5final/pytest_gpu.log
 bash tools/gpu_scripts/r5_evidence.sh r5final
-SDM_TRACE_LIB=$PWD/tools/_build/libsdmatte_hip_trace.so timeout 600 python tools/conv_trace.py > gpurun_out/r5final/conv_trace.txt 2>&1
