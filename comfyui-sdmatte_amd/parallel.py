@@ -92,20 +92,25 @@ def matte_stream(engine, images, trimaps, sizes, is_transparent: bool = False, m
     if world == 1:
         return [mine[i] for i in range(len(sizes))]
     order = lambda r: sorted(i for v in plan[r].values() for i in v)      # the same deterministic order on both ends
+    # non-blocking point-to-point: `dst` posts every receive up front (one per remote alpha, in each sender's own order - messages between a pair of
+    # ranks match in posting order), so the seven peers of an 8-GPU node drain concurrently over their own xGMI links instead of one after the other
     if rank != dst:
-        for i in order(rank):
-            dist.send(mine[i].contiguous(), dst)
+        reqs = [dist.isend(mine[i].contiguous(), dst) for i in order(rank)]
+        for q in reqs:
+            q.wait()
         return None
     out = [None] * len(sizes)
     for i, a in mine.items():
         out[i] = a
+    reqs = []
     for r in range(world):
         if r == dst:
             continue
         for i in order(r):
-            buf = torch.empty(tuple(images[i].shape[:2]), dtype=torch.float32, device=device)
-            dist.recv(buf, r)
-            out[i] = buf
+            out[i] = torch.empty(tuple(images[i].shape[:2]), dtype=torch.float32, device=device)
+            reqs.append(dist.irecv(out[i], r))
+    for q in reqs:
+        q.wait()
     return out
 
 
