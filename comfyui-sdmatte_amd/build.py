@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libsdmatte_hip.so")
 SOURCES = ["sdm_engine.cpp"]
-HEADERS = ["sdm_common.h", "k_conv.h", "k_norm.h", "k_attn.h", "k_misc.h", os.path.join("..", "..", "include", "sdmatte.h")]
+HEADERS = ["sdm_common.h", "k_conv.h", "k_gemm.h", "k_norm.h", "k_attn.h", "k_misc.h", os.path.join("..", "..", "include", "sdmatte.h")]
 # -fno-slp-vectorize: hipcc's SLP pass turns adjacent scalar fp32 adds / multiplies into v_pk_* plus the v_mov that assemble the pairs -
 # more issue slots than the scalar form, beside MFMAs (measured: -0.5 % step time without it, profiles/r03_no_slp_ab.txt)
 # -amdgpu-sched-strategy=max-ilp: the d=512 attention kernel gains 16 % (9.1 -> 7.6 ms / step), the d=64 one 1 %, the conv kernels (whose

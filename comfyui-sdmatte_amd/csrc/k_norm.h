@@ -12,6 +12,7 @@
 // 16-B vectors, consecutive threads -> consecutive channel vectors -> fully coalesced rows.
 #pragma once
 #include "sdm_common.h"
+#include "k_gemm.h"      // p3_store8: the P3 operand planes of the plane-fed GEMM
 
 struct GnSrc {
   const void* in0; const void* in1;  // channel concat (in1 may be null)
@@ -181,7 +182,9 @@ __global__ void __launch_bounds__(512) gn_apply_kernel(GnSrc s, const float* __r
       if (silu) y[e] = sdm_silu(y[e]);
     }
     const size_t oi = ((size_t)n * s.HW + p) * C + c;
-    if (out_f32) {                                 // precise mode: the consumer splits the fp32 value into an fp16 pair itself
+    if (out_f32 == 4) {                            // P3 planes (k_gemm.h): the consumer is the plane-fed GEMM (Transformer2DModel.proj_in)
+      p3_store8(y, (unsigned char*)out, (unsigned char*)out + p3_rows_pad((size_t)gridDim.y * s.HW) * (size_t)C * 2, (size_t)n * s.HW + p, C, c);
+    } else if (out_f32) {                                 // precise mode: the consumer splits the fp32 value into an fp16 pair itself
       f32x4 o0, o1;
 #pragma unroll
       for (int e = 0; e < 4; ++e) { o0[e] = y[e]; o1[e] = y[4 + e]; }

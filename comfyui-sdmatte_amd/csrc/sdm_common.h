@@ -35,6 +35,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define SDM_LAUNCH(kernel, grid, block, smem, stream, ...) \
   emu::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); })
 #define SDM_DEV_INLINE static inline
+#define SDM_HD_INLINE static inline
 #define SDM_WAVE_SYNC() emu::wave_barrier()
 #define SDM_SCHED_FENCE() ((void)0)
 #define SDM_PIN_STORE_DATA(v) ((void)(v))
@@ -66,6 +67,7 @@ static inline float sdm_rcp(float x) { return 1.0f / x; }
 #define SDM_LAUNCH(kernel, grid, block, smem, stream, ...) \
   hipLaunchKernelGGL(kernel, (grid), (block), (smem), (hipStream_t)(stream), __VA_ARGS__)
 #define SDM_DEV_INLINE __device__ __forceinline__
+#define SDM_HD_INLINE __host__ __device__ __forceinline__      // layout arithmetic shared by kernels and their launchers
 // LDS operations of ONE wave execute in issue order, so lanes of a wave may exchange data through a wave-private LDS
 // region without s_barrier; only the compiler must not reorder the accesses.
 #define SDM_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
@@ -217,6 +219,30 @@ __device__ __forceinline__ float sdm_sum_row16(float v) {
   v = SDM_DPP_ADD(v, 0x124);
   v = SDM_DPP_ADD(v, 0x128);
   return v;
+}
+#endif
+
+// v_perm_b32: byte i of the result = byte sel[i] of the 8-byte value {s0 (bytes 4-7), s1 (bytes 0-3)} (selector values 0-7 only)
+// v_permlane32_swap_b32: lanes 32-63 of `a` trade places with lanes 0-31 of `b` (a register pair crosses the wave's two halves in
+// one VALU instruction, no LDS crossbar): the accumulator layout of the 32x32 MFMAs splits every 8-channel run over the two halves
+#ifdef SDM_EMU
+static inline unsigned int sdm_perm_b32(unsigned int s0, unsigned int s1, unsigned int sel) {
+  const unsigned long long v = ((unsigned long long)s0 << 32) | s1;
+  unsigned int r = 0;
+  for (int i = 0; i < 4; ++i) r |= (unsigned int)((v >> (8 * ((sel >> (8 * i)) & 7))) & 0xffull) << (8 * i);
+  return r;
+}
+static inline void sdm_permlane32_swap(unsigned int& a, unsigned int& b) {
+  auto& w = emu::wave(); const int l = emu::lane_id();
+  w.slot[l][0] = a; w.slot[l][1] = b; emu::wave_barrier();
+  if (l < 32) b = w.slot[l + 32][0]; else a = w.slot[l - 32][1];
+  emu::wave_barrier();
+}
+#else
+__device__ __forceinline__ unsigned int sdm_perm_b32(unsigned int s0, unsigned int s1, unsigned int sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
+__device__ __forceinline__ void sdm_permlane32_swap(unsigned int& a, unsigned int& b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r[0]; b = r[1];
 }
 #endif
 

@@ -13,6 +13,7 @@
 //   * the dead CLIP text branch (meta_arch.py:220-234, never consumed: replace.py:414-416) is not built.
 #include "sdm_common.h"
 #include "k_conv.h"
+#include "k_gemm.h"
 #include "k_norm.h"
 #include "k_attn.h"
 #include "k_misc.h"
@@ -94,6 +95,10 @@ static OptEntry g_opts[] = {
   {"conv_f8", 1, 1, "residual terms of the wide split-precision 3x3 convs on fp8 MFMAs (read when a model is built)"},
   {"gemm_f8", 1, 1, "the same for Linear / 1x1 layers with K >= gemm_f8_min_k (read when a model is built)"},
   {"gemm_f8_min_k", 1024, 1024, "smallest K of a GEMM that takes the 8-wave fp8-residual kernel"},
+  {"gemm_p3", 1, 1, "transformer-block Linear layers on the plane-fed GEMM (k_gemm.h): pre-split operand planes from LayerNorm / GroupNorm / attention / GEGLU, LDS-DMA only (the W3 weight copies are built when a model is built)"},
+  {"gemm_p3_tile", 0, 0, "row tile of the plane-fed GEMM: 0 by shape, 256 / 128 / 64 forced"},
+  {"gemm_p3_stages", 0, 0, "LDS stages of the plane-fed GEMM: 0 default, n = lab forms (fp32 / GEGLU epilogues)"},
+  {"gemm_p3_ablate", 0, 0, "bench only: 1 no MFMAs, 2 no DMAs behind the prologue, 4 no epilogue (sdm_bench_gemm_p3)"},
   {"conv_epi", 4, 4, "F8 kernels' epilogue: 4 register-direct stores + residual as accumulator init, 3 residual init only, 0 LDS-staged"},
   {"conv_xtile", 1, 1, "F8 3x3: cross-tile prefetch by the producer waves"},
   {"conv_f8_tpb", 0, 0, "F8: tiles per block (0 = by queue depth)"},
@@ -377,6 +382,58 @@ static void launch_gemm_f8(const ConvParams& p_in, void* stream) {
   SDM_LAUNCH(k, dim3(pg, 1, 1), dim3(CD::LAUNCH_THREADS), (size_t)CD::SMEM_F8, stream, p);      // LDS map: ConvCfg (k_conv.h)
 }
 
+// ---- plane-fed GEMM (k_gemm.h): tile = (64 * MT) rows x 128 channels, 4 waves; NS LDS stages (2 stages of the 256-row tile: two blocks per CU) ----
+template <int MT, int EPI, int NS>
+static void launch_gemm_p3_t(GemmP3Params p, void* stream) {
+  constexpr int BM = 64 * MT, SMEM = NS * (BM * 96 + 128 * 128);
+  const long rows = p.rows_per_img ? (long)p.rows_per_img : p.M;
+  p.tiles_per_img = (int)((rows + BM - 1) / BM);
+  p.tiles_m = p.tiles_per_img * (p.rows_per_img ? (int)(p.M / p.rows_per_img) : 1);
+  p.tiles_n = sdm_cdiv(p.N, 128);
+  unsigned grid;
+  if (p.tiles_m >= 8) { p.xcd_chunk = (p.tiles_m + 7) / 8; grid = (unsigned)(8L * p.xcd_chunk * p.tiles_n); }
+  else { p.xcd_chunk = 0; grid = (unsigned)(p.tiles_m * p.tiles_n); }
+  auto k = gemm_p3_kernel<MT, 2, EPI, NS>;
+  SDM_SET_SMEM(k, SMEM);
+  SDM_LAUNCH(k, dim3(grid, 1, 1), dim3(256), (size_t)SMEM, stream, p);
+}
+// LDS stages per row tile: the option gemm_p3_stages = 0 takes the default of the tile, n >= 2 asks for n (lab forms exist for the fp32 and GEGLU epilogues)
+template <int EPI>
+static void launch_gemm_p3_e(const GemmP3Params& p, int bm, void* stream) {
+  const int ns = opt("gemm_p3_stages");
+  if (EPI == 0 || EPI == 1) {
+    if (bm == 256 && ns == 3) return launch_gemm_p3_t<4, EPI, 3>(p, stream);
+    if (bm == 256 && ns == 4) return launch_gemm_p3_t<4, EPI, 4>(p, stream);
+    if (bm == 128 && ns == 4) return launch_gemm_p3_t<2, EPI, 4>(p, stream);
+    if (bm == 128 && ns == 5) return launch_gemm_p3_t<2, EPI, 5>(p, stream);
+    if (bm == 64 && ns == 4) return launch_gemm_p3_t<1, EPI, 4>(p, stream);
+    if (bm == 64 && ns == 7) return launch_gemm_p3_t<1, EPI, 7>(p, stream);
+  }
+  if (bm == 256) launch_gemm_p3_t<4, EPI, 2>(p, stream);
+  else if (bm == 128) launch_gemm_p3_t<2, EPI, 2>(p, stream);
+  else launch_gemm_p3_t<1, EPI, 2>(p, stream);
+}
+// row tile: the largest of 256 / 128 / 64 that still gives every CU a block (the option gemm_p3_tile forces one)
+static int gemm_p3_pick_bm(long M, int N, int rows_per_img) {
+  const int forced = opt("gemm_p3_tile");
+  if (forced == 256 || forced == 128 || forced == 64) return forced;
+  const long tn = sdm_cdiv(N, 128);
+  const long imgs = rows_per_img ? M / rows_per_img : 1, rows = rows_per_img ? rows_per_img : M;
+  const int cus = device_cus();
+  for (int bm : {256, 128}) if (imgs * ((rows + bm - 1) / bm) * tn >= cus) return bm;
+  return 64;
+}
+static void launch_gemm_p3(const GemmP3Params& p, int epi, void* stream) {
+  const int bm = gemm_p3_pick_bm(p.M, p.N, p.rows_per_img);
+  switch (epi) {
+    case 0: launch_gemm_p3_e<0>(p, bm, stream); break;
+    case 1: launch_gemm_p3_e<1>(p, bm, stream); break;
+    case 2: launch_gemm_p3_e<2>(p, bm, stream); break;
+    case 3: launch_gemm_p3_e<3>(p, bm, stream); break;
+    default: launch_gemm_p3_e<4>(p, bm, stream); break;
+  }
+}
+
 static int launch_conv(int ntaps, int stride, int cfg, const ConvParams& p, void* stream) {
   if (ntaps == 9 && stride == 1) {
     switch (cfg) {
@@ -474,6 +531,9 @@ struct ConvL {
   half_t* w_dma = nullptr;
   int f8 = 0;                 // w_dma holds the fp8-residual layout (F8 conv kernel) instead of the stage-ordered hi | lo pair
   int f8_exp = 8;             // f8: the layer's e4m3 weight scale 2^f8_exp, the largest power of two with max|w| * 2^f8_exp <= 448 (derive_layer)
+  // Linear layers of the split-precision stages also keep the W3 layout of the plane-fed GEMM (k_gemm.h; same f8_exp)
+  size_t w3_off = 0, w3_bytes = 0;
+  unsigned char* w3 = nullptr;
 };
 static const int kSplitWeightExp = 8;      // pre-scale 2^8: typical |w| ~ 1e-2 .. 1 -> low parts ~ 1e-3 .. 1e-1 * 2^-4: fp16-normal
 struct NormL {
@@ -510,8 +570,10 @@ struct T {  // NHWC activation tensor living in the arena
 };
 
 // activation element formats (T::f32): 0 fp16, 1 fp32, 2 two fp16 planes hi | lo (split-precision attention operands),
-// 3 fp16 plane hi + e5m2 pair plane (the same, with the residual operands of Q.K^T already in fp8: ConvParams::out_f32)
-static inline size_t fmt_bytes(int f) { return f ? 4 : 2; }
+// 3 fp16 plane hi + e5m2 pair plane (the same, with the residual operands of Q.K^T already in fp8: ConvParams::out_f32),
+// 4 "P3": fp16 plane hi + one plane of e5m2 residual bytes, 3 bytes per element - the operand format of the plane-fed GEMM (k_gemm.h)
+static const int kFmtP3 = 4;
+static inline size_t fmt_bytes(int f) { return f == kFmtP3 ? 3 : (f ? 4 : 2); }
 static const int kMinVariantRows = 8;     // initial rows of the per-ResBlock bias tables (one row per distinct conditioning); grows on demand
 // conditioning of one image: opacity class + either 4 box coordinates (kind 0: bbox_embedding) or N point coordinates
 // (kind 1: point_embedding), meta_arch.py:147-197 / replace.py:446-457
@@ -655,6 +717,11 @@ struct Builder {
       L.wdma_bytes = (size_t)L.Cin_pad * L.Cout_pad * 4;
       L.wdma_off = doff; doff += rupz(L.wdma_bytes, 256);
       L.f8 = 1;
+    }
+    // every Linear of a split-precision stage whose K splits into 32-channel chunks: W3 copy for the plane-fed GEMM (k_gemm.h)
+    if (ntaps == 1 && L.split && L.Cin_pad % 32 == 0 && L.Cin_pad >= 32 && conv_f8_enabled() && opt("gemm_p3") != 0) {
+      L.w3_bytes = (size_t)L.Cin_pad * L.Cout_pad * 4;
+      L.w3_off = doff; doff += rupz(L.w3_bytes, 256);
     }
     e->convs.push_back(L);
     return (int)e->convs.size() - 1;
@@ -870,7 +937,7 @@ static void build_model(sdm_ctx* e) {
 // ------------------------------------------------------------------------------------------------
 static T talloc(sdm_ctx* e, int N, int H, int W, int C, int f32) {
   T t; t.N = N; t.H = H; t.W = W; t.C = C; t.f32 = f32;
-  t.bytes = rupz((size_t)N * H * W * C * fmt_bytes(f32), 256);
+  t.bytes = rupz((f32 == kFmtP3 ? p3_rows_pad((size_t)N * H * W) : (size_t)N * H * W) * C * fmt_bytes(f32), 256);      // (P3 planes are blocked: rows padded to 32)
   // first fit in the free list
   for (auto it = e->freelist.begin(); it != e->freelist.end(); ++it) {
     if (it->second >= t.bytes) {
@@ -1159,20 +1226,28 @@ static int op_groupnorm_raw(sdm_ctx* e, const void* in0, const void* in1, int C0
   return 0;
 }
 
-static int op_gn(sdm_ctx* e, const NormL& n, const T& x, const T* x2, int silu, float eps, T* out) {
+static int op_gn(sdm_ctx* e, const NormL& n, const T& x, const T* x2, int silu, float eps, T* out, int out_fmt = -1) {
   const int C = x.C + (x2 ? x2->C : 0);
   if (C != n.C) SDM_FAIL(e, SDM_ERR_INVALID, "groupnorm: C %d != %d", C, n.C);
-  *out = talloc(e, x.N, x.H, x.W, C, e->act_f32);
+  *out = talloc(e, x.N, x.H, x.W, C, out_fmt >= 0 ? out_fmt : e->act_f32);
   const bool hs = x.sbytes && (!x2 || x2->sbytes);     // statistics already produced by the conv epilogue(s)
   return op_groupnorm_raw(e, x.p, x2 ? x2->p : nullptr, x.C, x2 ? x2->C : 0, x.f32, x.N, x.H * x.W, e->cfg.groups, n.g, n.b, eps, silu,
                           out->p, out->f32, x.stats, x.srows, x2 ? x2->stats : nullptr, x2 ? x2->srows : 0, hs);
 }
 
-static int op_ln(sdm_ctx* e, const NormL& n, const T& x, float eps, T* out) {
+static int op_ln(sdm_ctx* e, const NormL& n, const T& x, float eps, T* out, int out_fmt = -1) {
   if (x.C != n.C || x.C % 64 || x.C > 64 * SDM_LN_MAXV) SDM_FAIL(e, SDM_ERR_INVALID, "layernorm: unsupported C %d", x.C);
-  *out = talloc(e, x.N, x.H, x.W, x.C, e->act_f32);
+  *out = talloc(e, x.N, x.H, x.W, x.C, out_fmt >= 0 ? out_fmt : e->act_f32);
   if (e->dry) return 0;
   const long rows = x.rows();
+  if (out->f32 == kFmtP3) {
+    if (x.f32 != 1 || x.C > 512 * SDM_LNP_MAXV) SDM_FAIL(e, SDM_ERR_INVALID, "layernorm (P3): fp32 input, C <= %d expected", 512 * SDM_LNP_MAXV);
+    prof_begin(e, "layernorm", 0, (double)rows * x.C * 7);
+    SDM_LAUNCH(layernorm_p3_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, e->stream, (const float*)x.p, (const float*)n.g, (const float*)n.b,
+               (unsigned char*)out->p, rows, x.C, eps);
+    prof_end(e);
+    return 0;
+  }
   prof_begin(e, "layernorm", 0, (double)rows * x.C * ((x.f32 ? 4 : 2) + (out->f32 ? 4 : 2)));
   SDM_LAUNCH(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, e->stream, (const void*)x.p, x.f32, (const float*)n.g,
              (const float*)n.b, out->p, out->f32, rows, x.C, eps);
@@ -1407,9 +1482,75 @@ static int resblock(sdm_ctx* e, const ResB& r, const T& x, const T* x2, float ep
   return 0;
 }
 
+// ---- plane-fed GEMM path (k_gemm.h).  `in` is a P3 tensor (T::f32 == kFmtP3); the output format picks the epilogue: fp32 (+residual, +statistics),
+//      P3 (GEGLU layers, or linear + residual), or the q | k | v operand planes of the attention cores (format 3) ----
+static bool p3_ok(sdm_ctx* e, const ConvL& L) { return L.w3 != nullptr && e->act_f32 && opt("gemm_p3") != 0; }
+static int op_gemm_p3(sdm_ctx* e, const ConvL& L, const T& in, T* out, const T* res, int lo_cols) {
+  if (in.f32 != kFmtP3 || in.C != L.Cin_pad) SDM_FAIL(e, SDM_ERR_INVALID, "gemm %s: needs a P3 operand of %d channels", L.name.c_str(), L.Cin_pad);
+  if (!L.w3) SDM_FAIL(e, SDM_ERR_STATE, "gemm %s: no W3 weight copy", L.name.c_str());
+  if (res && res->f32 != 1) SDM_FAIL(e, SDM_ERR_INVALID, "gemm %s: fp32 residual expected", L.name.c_str());
+  const int nout = L.geglu ? L.Cout_pad / 2 : L.Cout_pad;
+  if (out->C % 32 || std::min(nout, out->C) % 32) SDM_FAIL(e, SDM_ERR_INVALID, "gemm %s: output channels %d", L.name.c_str(), out->C);
+  int epi;
+  if (L.geglu) { if (out->f32 != kFmtP3) SDM_FAIL(e, SDM_ERR_INVALID, "gemm %s: GEGLU writes P3", L.name.c_str()); epi = 1; }
+  else if (out->f32 == 1) epi = out->want_stats ? 4 : 0;
+  else if (out->f32 == 3) epi = 2;
+  else if (out->f32 == kFmtP3) epi = 3;
+  else SDM_FAIL(e, SDM_ERR_INVALID, "gemm %s: unsupported output format %d", L.name.c_str(), out->f32);
+  GemmP3Params p;
+  memset(&p, 0, sizeof(p));
+  p.M = in.rows(); p.K = L.Cin_pad;
+  p.a_hi = (const half_t*)in.p; p.a_xl = (const unsigned char*)in.p + p3_rows_pad((size_t)p.M) * p.K * 2;
+  p.w = L.w3; p.N = L.Cout_pad; p.bias = L.b;
+  p.out = out->p; p.ldo = out->C; p.n_valid = std::min(nout, out->C);
+  p.out_lo_off = (epi == 2) ? (size_t)out->rows() * out->C : p3_rows_pad((size_t)out->rows()) * out->C * 2;
+  p.lo_cols = lo_cols >= 0 ? lo_cols : (1 << 30);
+  if (res) { p.res = (const float*)res->p; p.ldr = res->C; }
+  p.sa = 127 - 11; p.sb = 127 - L.f8_exp;
+  if (epi == 4) {
+    if ((in.H * in.W) % 32) SDM_FAIL(e, SDM_ERR_INVALID, "gemm %s: fused statistics need images of a multiple of 32 rows (blocked operand planes)", L.name.c_str());
+    p.rows_per_img = in.H * in.W;
+    const int bm = gemm_p3_pick_bm(p.M, p.N, p.rows_per_img);
+    out->srows = sdm_cdiv(p.rows_per_img, bm) * 2;
+    T sb = talloc(e, 1, 1, 1, (int)((size_t)in.N * out->srows * out->C * 2), 1);
+    out->soff = sb.off; out->sbytes = sb.bytes; out->stats = (float*)sb.p;
+    p.stats = out->stats;
+  }
+  if (e->dry) return 0;
+  const double flops = 2.0 * (double)p.M * L.O * L.I;
+  const double bytes = (double)p.M * p.K * 3 + (double)p.M * p.n_valid * (double)fmt_bytes(out->f32) + (double)p.K * p.N * 4 + (res ? (double)p.M * p.n_valid * 4 : 0.0);
+  if (e->prof_on) {
+    char d[256];
+    snprintf(d, sizeof(d), "%s N=%d Hout=%d Wout=%d Cin=%d Cout=%d p3 epi=%d bm=%d", L.name.c_str(), in.N, in.H, in.W, L.Cin_pad, L.O, epi, gemm_p3_pick_bm(p.M, p.N, p.rows_per_img));
+    prof_begin(e, "gemm_mfma", flops, bytes, d);
+  } else {
+    prof_begin(e, "conv", flops, bytes);
+  }
+  count_kernel("gemm_p3");
+  launch_gemm_p3(p, epi, e->stream);
+#ifndef SDM_EMU
+  { const hipError_t le = hipGetLastError(); if (le != hipSuccess) SDM_FAIL(e, SDM_ERR_HIP, "gemm %s: launch failed: %s", L.name.c_str(), hipGetErrorString(le)); }
+#endif
+  prof_end(e);
+  return 0;
+}
+
+// fp32 [rows][C] -> P3 (operands whose producer does not emit planes itself)
+static int op_to_p3(sdm_ctx* e, const T& x, T* out) {
+  if (x.f32 != 1 || x.C % 32) SDM_FAIL(e, SDM_ERR_INVALID, "to_p3: fp32 input with C %% 32 == 0 expected (C = %d)", x.C);
+  *out = talloc(e, x.N, x.H, x.W, x.C, kFmtP3);
+  if (e->dry) return 0;
+  const long units = ((x.rows() + 31) / 32) * (x.C / 32);      // one wave per 32 rows x 32 channels
+  prof_begin(e, "to_p3", 0, (double)x.rows() * x.C * 7);
+  SDM_LAUNCH(to_p3_kernel, dim3((unsigned)std::min<long>((units + 3) / 4, 1 << 20)), dim3(256), 0, e->stream, (const float*)x.p, (unsigned char*)out->p, x.rows(), x.C);
+  prof_end(e);
+  return 0;
+}
+
 static int linear(sdm_ctx* e, int layer, const T& in, T* out, int Cout, int out_f32, const T* res = nullptr, bool want_stats = false, int lo_cols = -1) {
   *out = talloc(e, in.N, in.H, in.W, Cout, out_f32);
   if (want_stats) TRY(tstats(e, *out));
+  if (in.f32 == kFmtP3) return op_gemm_p3(e, e->convs[layer], in, out, res, lo_cols);
   ConvArgs a; a.in0 = &in; a.out = out; a.res = res; a.lo_cols = lo_cols;
   return op_conv(e, e->convs[layer], a);
 }
@@ -1445,14 +1586,27 @@ static int transformer(sdm_ctx* e, const TfB& t, const T& x, const T& uin, const
   const int sf = e->cfg.stream_f32;
   const int C = t.C, L = x.H * x.W, L0 = uin.H * uin.W;
   T hn, h, n, qkv, ao, h2, q2, kv, f;
-  TRY(op_gn(e, e->norms[t.gn], x, nullptr, 0, e->cfg.unet_tf_gn_eps, &hn));
-  TRY(linear(e, t.proj_in, hn, &h, C, sf));
-  tfree(e, hn);
-  // self-attention with the trimap key bias
-  TRY(op_ln(e, e->norms[t.ln1], h, e->cfg.unet_ln_eps, &n));
   const int pa = (e->cfg.precise_mask & SDM_PRECISE_UNET_ATTN) ? 1 : 0;      // split-precision attention cores: q|k|v as hi|lo planes
   const int pf = pa ? (attn_f8_enabled() ? 3 : 2) : 0;         // plane format of q | k | v; SDM_ATTN_PV_SPLIT=1 (fully split P.V, test hook) needs V_lo too
   const bool need_vlo = pf == 2 && opt("attn_pv_split") != 0;
+  // plane-fed GEMMs (k_gemm.h): every Linear of the block takes a P3 operand written by its producer - GroupNorm apply, LayerNorm, the GEGLU and
+  // ff.net.2 epilogues - or, behind the attention cores (fp32 output), by one conversion pass
+  bool p3 = sf == 1 && pf == 3 && C % 32 == 0;
+  for (int l : {t.proj_in, t.qkv1, t.o1, t.q2, t.o2, t.ff1, t.ff2, t.proj_out}) p3 = p3 && p3_ok(e, e->convs[l]);
+  const int nf = p3 ? kFmtP3 : -1;                             // operand format of the norms' outputs (-1: the engine's activation type)
+  auto attn_out = [&](T& a) -> int {                           // the attention output as the next GEMM's operand
+    if (!p3) return 0;
+    T ap;
+    TRY(op_to_p3(e, a, &ap));
+    tfree(e, a);
+    a = ap;
+    return 0;
+  };
+  TRY(op_gn(e, e->norms[t.gn], x, nullptr, 0, e->cfg.unet_tf_gn_eps, &hn, nf));
+  TRY(linear(e, t.proj_in, hn, &h, C, sf));
+  tfree(e, hn);
+  // self-attention with the trimap key bias
+  TRY(op_ln(e, e->norms[t.ln1], h, e->cfg.unet_ln_eps, &n, nf));
   TRY(linear(e, t.qkv1, n, &qkv, 3 * C, pf, nullptr, false, need_vlo ? -1 : 2 * C));
   tfree(e, n);
   ao = talloc(e, x.N, x.H, x.W, C, e->act_f32);
@@ -1463,10 +1617,11 @@ static int transformer(sdm_ctx* e, const TfB& t, const T& x, const T& uin, const
     TRY(op_attention_raw(e, q, 3 * C, q ? q + C : nullptr, 3 * C, q ? q + 2 * C : nullptr, 3 * C, bias, x.N, t.heads, L, L, 64, ao.p, C, true, tiles, ap));
   }
   tfree(e, qkv);
+  TRY(attn_out(ao));
   TRY(linear(e, t.o1, ao, &h2, C, sf, &h));
   tfree(e, ao); tfree(e, h);
   // cross-attention to the trimap-latent tokens
-  TRY(op_ln(e, e->norms[t.ln2], h2, e->cfg.unet_ln_eps, &n));
+  TRY(op_ln(e, e->norms[t.ln2], h2, e->cfg.unet_ln_eps, &n, nf));
   TRY(linear(e, t.q2, n, &q2, C, pf));
   tfree(e, n);
   TRY(conv_simple(e, t.kv2, uin, &kv, 2 * C, pf, 1, 0, 0, nullptr, 1.0f, false, need_vlo ? -1 : C));      // folded aux_conv_in + to_k|to_v: tokens = latent pixels, row-major
@@ -1478,13 +1633,15 @@ static int transformer(sdm_ctx* e, const TfB& t, const T& x, const T& uin, const
     TRY(op_attention_raw(e, (const half_t*)q2.p, C, kk, 2 * C, kk ? kk + C : nullptr, 2 * C, nullptr, x.N, t.heads, L, L0, 64, ao.p, C, true, nullptr, ap));
   }
   tfree(e, q2); tfree(e, kv);
+  TRY(attn_out(ao));
   TRY(linear(e, t.o2, ao, &h, C, sf, &h2));
   tfree(e, ao); tfree(e, h2);
   // GEGLU feed-forward
-  TRY(op_ln(e, e->norms[t.ln3], h, e->cfg.unet_ln_eps, &n));
-  TRY(linear(e, t.ff1, n, &f, 4 * C, e->act_f32));
+  TRY(op_ln(e, e->norms[t.ln3], h, e->cfg.unet_ln_eps, &n, nf));
+  TRY(linear(e, t.ff1, n, &f, 4 * C, p3 ? kFmtP3 : e->act_f32));
   tfree(e, n);
-  TRY(linear(e, t.ff2, f, &h2, C, sf, &h));
+  // (P3: h2 only feeds proj_out - whose fused statistics need image-aligned row tiles on whole 32-row blocks; otherwise proj_out keeps the fp32 kernel)
+  TRY(linear(e, t.ff2, f, &h2, C, (p3 && L % 32 == 0) ? kFmtP3 : sf, &h));
   tfree(e, f); tfree(e, h);
   TRY(linear(e, t.proj_out, h2, out, C, sf, &x, true));
   tfree(e, h2);
@@ -1996,6 +2153,7 @@ int sdm_create(sdm_ctx** out, int device_id, const sdm_config* cfg) {
     L.w = (half_t*)(e->warena + L.w_off); L.b = (float*)(e->warena + L.b_off);
     if (L.split) L.w_lo = (half_t*)(e->warena + L.wlo_off);
     if (L.wdma_bytes) L.w_dma = (half_t*)(e->warena + e->canon_bytes + L.wdma_off);
+    if (L.w3_bytes) L.w3 = e->warena + e->canon_bytes + L.w3_off;
   }
   for (auto& n : e->norms) { n.g = (float*)(e->warena + n.g_off); n.b = (float*)(e->warena + n.b_off); }
   for (auto& t : e->tembs) {
@@ -2173,7 +2331,7 @@ static int fold_cross_kv(sdm_ctx* e) {
 // layout kernels with the per-layer e4m3 scale 2^e8 = the largest power of two that keeps max|w| * 2^e8 <= 448.
 static int derive_layers(sdm_ctx* e, std::vector<ConvL*>& layers) {
   std::vector<ConvL*> f8;
-  for (ConvL* L : layers) if (L->w_dma && L->f8) f8.push_back(L);
+  for (ConvL* L : layers) if ((L->w_dma && L->f8) || L->w3) f8.push_back(L);
   if (!f8.empty()) {
     const size_t tb = rupz(f8.size() * 4, 256);
     if (ensure_buf(e, &e->stage, &e->stage_bytes, std::max(tb, (size_t)1 << 20)) != 0) return SDM_ERR_NOMEM;
@@ -2198,6 +2356,9 @@ static int derive_layers(sdm_ctx* e, std::vector<ConvL*>& layers) {
     }
   }
   for (ConvL* L : layers) {
+    if (L->w3)
+      SDM_LAUNCH(derive_gemm_w3_kernel, dim3((unsigned)std::min<size_t>(((size_t)L->Cin_pad * L->Cout_pad / 4 + 255) / 256, 65535)), dim3(256), 0, e->stream,
+                 (const half_t*)L->w, (const half_t*)L->w_lo, L->w3, L->Cin_pad, L->Cout_pad, ldexpf(1.0f, -L->w_exp), ldexpf(1.0f, L->f8_exp));
     if (!L->w_dma) continue;
     const size_t total = (size_t)L->Cin_pad * L->ntaps * L->Cout_pad;
     if (L->f8)
@@ -2512,6 +2673,64 @@ int sdm_op_conv_ex(sdm_ctx* e, const void* in0, const void* in1, int C0, int C1,
   return rc;
 }
 
+/* Plane-fed GEMM (k_gemm.h) as a stand-alone operator: x fp32 [N*H*W][K] (device) is converted to P3 planes (to_p3_kernel, or LayerNorm with P3 output
+ * when ln_gamma is given), w fp32 [O][K] is packed to K16 -> W3 exactly as a model layer.  mode 0: fp32 out (+bias, +fp32 residual); 1: GEGLU (O = 2 x outputs);
+ * 3: linear (+residual) to P3; both P3 results are decoded to fp32 (hi + xl * 2^-11) into `out`; 2: raw q | k | v operand planes (fp16 hi [rows][O] then the
+ * e5m2 pair plane, pair plane for channels < lo_cols only); 4: mode 0 + the consumer's GroupNorm statistics, [N][*srows][O][2] floats into `stats`. */
+int sdm_op_gemm_p3(sdm_ctx* e, const float* x, int N, int H, int W, int K, const float* w, const float* bias, int O, int mode, const float* res,
+                   const float* ln_gamma, const float* ln_beta, float ln_eps, int lo_cols, void* out, float* stats, int* srows) {
+  if (e) dev_use(e->device);
+  if (!e || !x || !w || !out) return SDM_ERR_INVALID;
+  const int geglu = mode == 1;
+  if (K % 32 || O % (geglu ? 64 : 32)) SDM_FAIL(e, SDM_ERR_INVALID, "sdm_op_gemm_p3: K %% 32 and O %% 32 (GEGLU: 64) required");
+  ConvL L;
+  L.name = "op_gemm_p3"; L.ntaps = 1; L.I = K; L.O = O; L.Cin_pad = K; L.Cout_pad = O; L.geglu = geglu; L.split = 1; L.w_exp = kSplitWeightExp;
+  void* wp = nullptr; void* bp = nullptr; void* wl = nullptr; void* w3 = nullptr;
+  const size_t total = (size_t)K * O, wbytes = total * 2;
+  SDM_CHECK_DEV(e, dev_malloc(&wp, wbytes)); SDM_CHECK_DEV(e, dev_malloc(&wl, wbytes)); SDM_CHECK_DEV(e, dev_malloc(&bp, (size_t)O * 4));
+  SDM_CHECK_DEV(e, dev_malloc(&w3, total * 4));
+  dev_memset(wp, 0, wbytes, e->stream); dev_memset(wl, 0, wbytes, e->stream); dev_memset(bp, 0, (size_t)O * 4, e->stream);
+  L.w = (half_t*)wp; L.w_lo = (half_t*)wl; L.b = (float*)bp; L.w3 = (unsigned char*)w3; L.w3_bytes = total * 4;
+  SDM_LAUNCH(pack_conv_weight_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 65535)), dim3(256), 0, e->stream, w, L.w, O, K, 1, K, O, 0, 0, geglu,
+             ldexpf(1.0f, L.w_exp), L.w_lo);
+  if (bias) SDM_LAUNCH(pack_bias_kernel, dim3(sdm_cdiv(O, 256)), dim3(256), 0, e->stream, bias, L.b, O, O, 0, geglu);
+  { std::vector<ConvL*> one{&L}; TRY(derive_layers(e, one)); }
+  const int Cst = geglu ? O / 2 : O;
+  const int act_prev = e->act_f32;
+  e->act_f32 = 1;
+  int rc = run_two_pass(e, [&]() -> int {
+    T tx, xp, to, tres;
+    tx.p = (void*)x; tx.N = N; tx.H = H; tx.W = W; tx.C = K; tx.f32 = 1;
+    if (ln_gamma) {
+      NormL nl; nl.C = K; nl.g = const_cast<float*>(ln_gamma); nl.b = const_cast<float*>(ln_beta);
+      TRY(op_ln(e, nl, tx, ln_eps, &xp, kFmtP3));
+    } else {
+      TRY(op_to_p3(e, tx, &xp));
+    }
+    tres.p = (void*)res; tres.N = N; tres.H = H; tres.W = W; tres.C = Cst; tres.f32 = 1;
+    const bool planes = (mode == 1 || mode == 3);
+    if (planes) to = talloc(e, N, H, W, Cst, kFmtP3);
+    else { to.p = out; to.N = N; to.H = H; to.W = W; to.C = Cst; to.f32 = (mode == 2) ? 3 : 1; }
+    to.want_stats = (mode == 4);
+    TRY(op_gemm_p3(e, L, xp, &to, res ? &tres : nullptr, lo_cols));
+    if (!e->dry) {
+      if (planes) SDM_LAUNCH(from_p3_kernel, dim3((unsigned)std::min<long>((to.rows() * Cst + 255) / 256, 1 << 20)), dim3(256), 0, e->stream, (const unsigned char*)to.p, (float*)out, to.rows(), Cst);
+      if (mode == 4 && stats) {
+        SDM_CHECK_DEV(e, dev_memcpy_d2d(stats, to.stats, (size_t)N * to.srows * Cst * 2 * 4, e->stream));
+        if (srows) *srows = to.srows;
+      }
+    }
+    if (planes) tfree(e, to);
+    else if (to.sbytes) { tfree_raw(e, to.soff, to.sbytes); to.sbytes = 0; }
+    tfree(e, xp);
+    return 0;
+  });
+  e->act_f32 = act_prev;
+  dev_sync(e->stream);
+  dev_free(wp); dev_free(wl); dev_free(bp); dev_free(w3);
+  return rc;
+}
+
 /* Test hook: `mask` (device, [N][Hin][Win] bytes, class ids 0..4; k_misc.h cmask_*) is the class plane of the input of the NEXT sdm_op_conv_ex call -
  * the conv then leaves the output tiles of constant regions to const_tile_fill_kernel, as the VAE encoder does for the trimap images. */
 int sdm_debug_set_input_cmask(sdm_ctx* e, const unsigned char* mask) {
@@ -2570,6 +2789,67 @@ int sdm_debug_temb_row(sdm_ctx* e, int temb_index, int is_trans, const float* co
 
 /* Bench/ablation helper (not used by the engine): times `iters` launches of one conv with HIP events; returns ms per launch
  * (negative on error).  ablate bits: see ConvParams::ablate. */
+/* bench only: ms per launch of the plane-fed GEMM (k_gemm.h) on random operands: M rows, K -> O, epilogue `epi` (0 fp32, 1 GEGLU, 2 q|k|v planes, 3 P3, 4 fp32 +
+ * statistics; bit 8: + fp32 residual).  The row tile follows the option gemm_p3_tile. */
+float sdm_bench_gemm_p3(sdm_ctx* e, long M, int K, int O, int epi_flags, int iters) {
+  if (e) dev_use(e->device);
+  if (!e || K % 32 || O % 64) return -1.f;
+#ifdef SDM_EMU
+  (void)M; (void)epi_flags; (void)iters;
+  return -1.f;
+#else
+  const int epi = epi_flags & 255, resf = (epi_flags >> 8) & 1;
+  void *xf = nullptr, *xp = nullptr, *w3 = nullptr, *bp = nullptr, *out = nullptr, *resb = nullptr, *st = nullptr;
+  const int Cst = epi == 1 ? O / 2 : O;
+  int p_sb = 127 - 8;
+  const size_t w3b = (size_t)K * O * 4;
+  if (dev_malloc(&xf, (size_t)M * K * 4) || dev_malloc(&xp, p3_rows_pad((size_t)M) * K * 3) || dev_malloc(&w3, w3b) || dev_malloc(&bp, (size_t)O * 4) ||
+      dev_malloc(&out, p3_rows_pad((size_t)M) * Cst * 4 + 256)) return -2.f;
+  if (resf && dev_malloc(&resb, (size_t)M * Cst * 4)) return -2.f;
+  if (epi == 4 && dev_malloc(&st, ((size_t)(M + 63) / 64 * 2 + 8) * O * 8)) return -2.f;
+  SDM_LAUNCH(fill_random_f32_kernel, dim3(4096), dim3(256), 0, e->stream, (float*)xf, (long)M * K, 5u, 1.0f);
+  SDM_LAUNCH(to_p3_kernel, dim3(4096), dim3(256), 0, e->stream, (const float*)xf, (unsigned char*)xp, M, K);
+  {   // weights: random fp32 [O][K] -> K16 hi | lo -> W3, as a model layer
+    void *wf = nullptr, *wp = nullptr, *wl = nullptr;
+    if (dev_malloc(&wf, (size_t)K * O * 4) || dev_malloc(&wp, (size_t)K * O * 2) || dev_malloc(&wl, (size_t)K * O * 2)) return -2.f;
+    SDM_LAUNCH(fill_random_f32_kernel, dim3(2048), dim3(256), 0, e->stream, (float*)wf, (long)K * O, 17u, 0.05f);
+    ConvL L;
+    L.name = "bench"; L.ntaps = 1; L.I = K; L.O = O; L.Cin_pad = K; L.Cout_pad = O; L.split = 1; L.w_exp = kSplitWeightExp;
+    L.w = (half_t*)wp; L.w_lo = (half_t*)wl; L.w3 = (unsigned char*)w3; L.w3_bytes = w3b;
+    SDM_LAUNCH(pack_conv_weight_kernel, dim3((unsigned)std::min<size_t>(((size_t)K * O + 255) / 256, 65535)), dim3(256), 0, e->stream, (const float*)wf, L.w, O, K, 1, K, O,
+               0, 0, 0, ldexpf(1.0f, L.w_exp), L.w_lo);
+    std::vector<ConvL*> one{&L};
+    if (derive_layers(e, one) != 0) return -2.f;
+    dev_free(wf); dev_free(wp); dev_free(wl);
+    p_sb = 127 - L.f8_exp;
+  }
+  if (resf) SDM_LAUNCH(fill_random_f32_kernel, dim3(4096), dim3(256), 0, e->stream, (float*)resb, (long)M * Cst, 31u, 1.0f);
+  dev_memset(bp, 0, (size_t)O * 4, e->stream);
+  GemmP3Params p;
+  memset(&p, 0, sizeof(p));
+  p.M = M; p.K = K; p.a_hi = (const half_t*)xp; p.a_xl = (const unsigned char*)xp + p3_rows_pad((size_t)M) * K * 2;
+  p.w = (const unsigned char*)w3; p.N = O; p.bias = (const float*)bp; p.out = out; p.ldo = Cst; p.n_valid = Cst;
+  p.out_lo_off = epi == 2 ? (size_t)M * Cst : p3_rows_pad((size_t)M) * Cst * 2; p.lo_cols = (O / 3) * 2;
+  if (resf) { p.res = (const float*)resb; p.ldr = Cst; }
+  if (epi == 4) { p.stats = (float*)st; p.rows_per_img = (int)M; }
+  p.sa = 127 - 11; p.sb = p_sb; p.ablate = opt("gemm_p3_ablate");
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  launch_gemm_p3(p, epi, e->stream);
+  (void)hipEventRecord(e0, (hipStream_t)e->stream);
+  for (int i = 0; i < iters; ++i) launch_gemm_p3(p, epi, e->stream);
+  (void)hipEventRecord(e1, (hipStream_t)e->stream);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  const hipError_t le = hipGetLastError();
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  dev_free(xf); dev_free(xp); dev_free(w3); dev_free(bp); dev_free(out); if (resb) dev_free(resb); if (st) dev_free(st);
+  if (le != hipSuccess) { e->err = hipGetErrorString(le); return -3.f; }
+  return ms / (float)iters;
+#endif
+}
+
 float sdm_bench_conv(sdm_ctx* e, int N, int H, int W, int Cin, int Cout, int ntaps, int stride, int in_f32, int tile_cfg, int ablate, int iters) {
   // in_f32: bit 0 = fp32 activations, bit 1 = split-precision kernel (implies fp32), bit 2 = fused GroupNorm+SiLU staging,
   // bit 3 = producer / consumer form of the split-precision DMA kernel

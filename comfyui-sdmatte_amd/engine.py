@@ -83,7 +83,7 @@ EXPORTS = [
     "sdm_weight_stats", "sdm_missing_key", "sdm_weight_blob_bytes", "sdm_export_weight_blob", "sdm_import_weight_blob",
     "sdm_host_blob_bytes", "sdm_export_host_blob", "sdm_import_host_blob", "sdm_forward", "sdm_forward_ex", "sdm_forward_rect", "sdm_apply_matte", "sdm_apply_matte_node",
     "sdm_synchronize", "sdm_release_memory", "sdm_resident_bytes", "sdm_weight_bytes", "sdm_last_forward_ms", "sdm_profile_enable", "sdm_profile_count", "sdm_profile_get", "sdm_profile_dump",
-    "sdm_op_conv", "sdm_op_conv_ex", "sdm_debug_run_layer", "sdm_debug_set_input_cmask", "sdm_debug_temb_row", "sdm_conv_num_cfgs", "sdm_bench_conv", "sdm_bench_attn", "sdm_op_groupnorm", "sdm_op_layernorm", "sdm_op_attention", "sdm_op_attention_split", "sdm_op_resize_aa",
+    "sdm_op_conv", "sdm_op_conv_ex", "sdm_op_gemm_p3", "sdm_debug_run_layer", "sdm_debug_set_input_cmask", "sdm_debug_temb_row", "sdm_conv_num_cfgs", "sdm_bench_conv", "sdm_bench_attn", "sdm_bench_gemm_p3", "sdm_op_groupnorm", "sdm_op_layernorm", "sdm_op_attention", "sdm_op_attention_split", "sdm_op_resize_aa",
     "sdm_op_mask_bias",
     "sdm_set_option", "sdm_get_option", "sdm_reset_options", "sdm_option_name", "sdm_option_help", "sdm_kernel_counts", "sdm_kernel_counts_reset",
 ]
@@ -129,12 +129,14 @@ class Bindings:
                                   f32, i32]),
             "sdm_op_conv_ex": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, i32,
                                      f32, i32, i32, vp, vp, f32, i32, i32]),
+            "sdm_op_gemm_p3": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp, f32, i32, vp, vp, C.POINTER(i32)]),
             "sdm_debug_run_layer": (i32, [vp, C.c_char_p, vp, i32, i32, i32, vp, i32]),
             "sdm_debug_set_input_cmask": (i32, [vp, vp]),
             "sdm_debug_temb_row": (i32, [vp, i32, i32, vp, vp, i32]),
             "sdm_conv_num_cfgs": (i32, [i32, i32]),
             "sdm_bench_conv": (f32, [vp] + [i32] * 11),
             "sdm_bench_attn": (f32, [vp] + [i32] * 7),
+            "sdm_bench_gemm_p3": (f32, [vp, C.c_long, i32, i32, i32, i32]),
             "sdm_op_groupnorm": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, f32, i32, vp]),
             "sdm_op_layernorm": (i32, [vp, vp, i32, C.c_long, i32, vp, vp, f32, vp]),
             "sdm_op_attention": (i32, [vp, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32]),
@@ -439,6 +441,33 @@ class Engine:
                     "sdm_op_conv_ex")
         return out[..., :Creal]
 
+    def op_gemm_p3(self, x, w, bias=None, mode=0, res=None, ln=None, lo_cols=-1):
+        """Test hook: the plane-fed GEMM (k_gemm.h) on x fp32 [N,H,W,K].  mode 0 fp32 (+res), 1 GEGLU, 3 planes (+res), 4 fp32 + statistics -> (out, stats[N,srows,O,2]),
+        2 -> (hi fp16 [N,H,W,O], pair uint8 [N,H,W,O,2]); ln = (gamma, beta, eps): LayerNorm with plane output in front."""
+        N, H, W_, K = x.shape
+        O = w.shape[0]
+        x = x.float().contiguous(); w = w.float().contiguous()
+        b = bias.float().contiguous() if bias is not None else None
+        r = res.float().contiguous() if res is not None else None
+        gam = ln[0].float().contiguous() if ln is not None else None
+        bet = ln[1].float().contiguous() if ln is not None else None
+        Cst = O // 2 if mode == 1 else O
+        if mode == 2:
+            out = torch.zeros(2 * N * H * W_ * O, dtype=torch.float16, device=x.device)
+        else:
+            out = torch.empty(N, H, W_, Cst, dtype=torch.float32, device=x.device)
+        srows_max = 2 * ((H * W_ + 63) // 64)
+        stats = torch.zeros(N * srows_max * O * 2, dtype=torch.float32, device=x.device) if mode == 4 else None
+        srows = C.c_int(0)
+        self._check(self.lib.sdm_op_gemm_p3(self.h, _ptr(x), N, H, W_, K, _ptr(w), _ptr(b), O, mode, _ptr(r), _ptr(gam), _ptr(bet),
+                                            float(ln[2]) if ln is not None else 0.0, lo_cols, _ptr(out), _ptr(stats), C.byref(srows)), "sdm_op_gemm_p3")
+        if mode == 2:
+            n = N * H * W_ * O
+            return out[:n].view(N, H, W_, O), out[n:].view(torch.uint8).view(N, H, W_, O, 2)
+        if mode == 4:
+            return out, stats[:N * srows.value * O * 2].view(N, srows.value, O, 2)
+        return out
+
     def debug_run_layer(self, name, x_nhwc, cout):
         """Test hook: one packed layer of the loaded model on an fp32 NHWC input -> fp32 NHWC [N,H,W,cout]."""
         N, H, W_, _ = x_nhwc.shape
@@ -457,6 +486,9 @@ class Engine:
 
     def bench_conv(self, N, H, W, Cin, Cout, ntaps=9, stride=1, in_f32=0, tile_cfg=-1, ablate=0, iters=10):
         return float(self.lib.sdm_bench_conv(self.h, N, H, W, Cin, Cout, ntaps, stride, in_f32, tile_cfg, ablate, iters))
+
+    def bench_gemm_p3(self, M, K, O, epi=0, res=False, iters=10):
+        return float(self.lib.sdm_bench_gemm_p3(self.h, M, K, O, epi | (256 if res else 0), iters))
 
     def bench_attn(self, B, heads, Lq, Lk, qt=1, ablate=0, iters=10):
         return float(self.lib.sdm_bench_attn(self.h, B, heads, Lq, Lk, qt, ablate, iters))

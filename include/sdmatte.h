@@ -215,6 +215,17 @@ int sdm_op_conv_ex(sdm_ctx* ctx, const void* in0, const void* in1, int C0, int C
                    int stride, int pad_mode, int ntaps, const float* w, const float* bias, int O, void* out, int out_f32,
                    const void* res, int res_f32, int geglu, float out_scale, int tile_cfg, int split, const float* gn_gamma,
                    const float* gn_beta, float gn_eps, int gn_groups, int gn_silu);
+/* bench only (tools/gemm_p3_bench.py): ms per launch of the plane-fed GEMM on random operands; epi_flags = epilogue (0 fp32, 1 GEGLU, 2 q|k|v planes, 3 planes,
+ * 4 fp32 + statistics) | 256 for an fp32 residual */
+float sdm_bench_gemm_p3(sdm_ctx* ctx, long M, int K, int O, int epi_flags, int iters);
+/* Plane-fed GEMM of the transformer blocks' Linear layers (k_gemm.h; reference call sites replace.py:232-362 -> diffusers BasicTransformerBlock) as a
+ * stand-alone operator.  x: fp32 [N*H*W][K] on the device, K % 32 == 0; converted to the kernel's operand planes by the conversion kernel or, when
+ * ln_gamma != NULL, by LayerNorm(eps) with plane output.  w: fp32 [O][K], packed exactly as a model layer.  mode 0: fp32 [rows][O] (+bias, +fp32 residual);
+ * 1: GEGLU, O = 2 x outputs, result planes decoded to fp32 [rows][O/2]; 3: linear (+residual) to planes, decoded to fp32; 2: the raw q | k | v operand planes of
+ * the attention cores (fp16 [rows][O], then the e5m2 pair plane of the same size; pair plane for channels < lo_cols only); 4: mode 0 + the per-(image, row
+ * block, channel) {sum, sumsq} rows of the consumer's GroupNorm into `stats` ([N][*srows][O][2] floats; size it for 2 * ceil(H*W / 64) rows). */
+int sdm_op_gemm_p3(sdm_ctx* ctx, const float* x, int N, int H, int W, int K, const float* w, const float* bias, int O, int mode, const float* res,
+                   const float* ln_gamma, const float* ln_beta, float ln_eps, int lo_cols, void* out, float* stats, int* srows);
 /* Test hooks for the exact algebraic folds done at load time (cross-attention K|V fold of aux_conv_in, logit scale in to_q,
  * time/opacity/bbox embedding constants in the conv1 bias tables): run one packed layer by name on an fp32 NHWC input
  * (DEVICE pointers; channel count = the layer's padded input channels), and read one folded bias row (HOST output). */

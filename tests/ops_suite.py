@@ -303,3 +303,73 @@ def check_resize(eng, dev, P, Hin, Win, Hout, Wout, seed=0, atol=2e-5):
     err = (out.cpu() - ref).abs().max().item()
     assert err < atol, f"resize mismatch {err:.4g} ({Hin}x{Win}->{Hout}x{Wout})"
     return err
+
+
+def _e5m2_to_f32(b):
+    """uint8 tensor of OCP e5m2 bytes -> float32 (an e5m2 byte is the top byte of an fp16)"""
+    return (b.to(torch.int32) << 8).to(torch.int16).view(torch.float16).float()
+
+
+def check_gemm_p3(eng, dev, N, H, W, K, O, mode=0, res=False, ln=False, lo_cols=-1, tile=0, seed=0, atol=3e-4, xscale=1.0, wscale=1.0, rel=False,
+                  set_option=None):
+    """Plane-fed GEMM (k_gemm.h): x . w^T (+bias) on pre-split operand planes - fp16 high parts x fp16 high parts + ONE fp8 K=64 MFMA for the two
+    residual terms - against the torch fp32 product of the UN-rounded operands.  mode 0 fp32 (+res), 1 GEGLU -> planes, 3 linear (+res) -> planes
+    (both decoded: the comparison then includes the 22-bit rounding of the output planes), 2 attention operand planes (hi + pair plane decoded),
+    4 fp32 + the consumer's GroupNorm statistics.  ln: LayerNorm with plane output in front of the GEMM.  tile: forced row tile (256 / 128 / 64)."""
+    g = _g(seed)
+    x = torch.randn(N, H, W, K, generator=g) * xscale
+    w = torch.randn(O, K, generator=g) / math.sqrt(K) * wscale
+    b = 0.1 * torch.randn(O, generator=g)
+    xr = x
+    ln_arg = None
+    if ln:
+        gamma = 1 + 0.2 * torch.randn(K, generator=g)
+        beta = 0.1 * torch.randn(K, generator=g)
+        xr = F.layer_norm(x, (K,), gamma, beta, 1e-5)
+        ln_arg = (gamma.to(dev), beta.to(dev), 1e-5)
+    ref = xr.double() @ w.double().t() + b.double()
+    if mode == 1:
+        u, gg = ref.chunk(2, dim=-1)
+        ref = u * F.gelu(gg)
+    r = None
+    if res:
+        r = torch.randn(ref.shape, generator=g)
+        ref = ref + r.double()
+    ref = ref.float()
+    if set_option is not None:
+        set_option(eng, "gemm_p3_tile", tile)
+    out = eng.op_gemm_p3(x.to(dev), w.to(dev), b.to(dev), mode=mode, res=r.to(dev) if r is not None else None, ln=ln_arg, lo_cols=lo_cols)
+    what = f"gemm_p3 mode={mode} N={N} H={H} W={W} K={K} O={O} res={res} ln={ln} tile={tile}"
+    if mode == 2:
+        hi, pair = out
+        hi = hi.float().cpu()
+        pair = pair.cpu()                                   # [..., O, 2] bytes: per 4 channels [x8 x 4 | xl x 4]
+        p = pair.reshape(N, H, W, O // 4, 8)
+        x8 = _e5m2_to_f32(p[..., :4]).reshape(N, H, W, O)
+        xl = _e5m2_to_f32(p[..., 4:]).reshape(N, H, W, O)
+        lc = O if lo_cols < 0 else lo_cols
+        got = hi.clone()
+        got[..., :lc] += xl[..., :lc] / 2048.0
+        err = (got - ref).abs()
+        e_lo = err[..., :lc].max().item() if lc else 0.0
+        e_hi = err[..., lc:].max().item() if lc < O else 0.0
+        assert e_lo < atol, f"{what}: split planes max|d|={e_lo:.4g}"
+        assert e_hi < 2e-3 * max(1.0, ref.abs().max().item()), f"{what}: hi-only channels max|d|={e_hi:.4g}"
+        # the e5m2(x) halves of the pair plane: within one e5m2 rounding of the value
+        d8 = (x8[..., :lc] - ref[..., :lc]).abs() - 0.126 * ref[..., :lc].abs() - 1e-4
+        assert d8.max().item() <= 0, f"{what}: e5m2(x) bytes off by {d8.max().item():.4g}"
+        return e_lo
+    stats = None
+    if mode == 4:
+        out, stats = out
+    got = out.float().cpu()
+    err = (got - ref).abs().max().item()
+    if rel:
+        err = err / ref.abs().max().item()
+    assert err < atol, f"{what}: max|d|={err:.4g}"
+    if stats is not None:
+        st = stats.cpu().double().sum(dim=1)                # [N, O, 2]
+        s1 = got.double().sum(dim=(1, 2)); s2 = (got.double() ** 2).sum(dim=(1, 2))
+        assert torch.allclose(st[..., 0], s1, rtol=1e-5, atol=1e-3), f"{what}: statistics (sum)"
+        assert torch.allclose(st[..., 1], s2, rtol=1e-5, atol=1e-3), f"{what}: statistics (sum of squares)"
+    return err

@@ -116,6 +116,29 @@ def test_f8_residual_operand_ranges(emu_engine):
                  xscale=300.0, wscale=4.0, rel=True)
 
 
+@pytest.mark.parametrize("tile", [256, 128, 64])
+def test_gemm_p3_plane_fed_gemm(emu_engine, engine_option, tile):
+    """k_gemm.h on the emulator: every epilogue (fp32 + residual, GEGLU -> planes, linear -> planes, attention operand planes, fused statistics),
+    1 / 2 / 3 K chunks, ragged row tiles (rows % 64 != 0), ragged / several output-channel tiles, a batch whose images do not fill a row tile,
+    LayerNorm with plane output in front.  Error bound: the residual terms are 2^-11 of the product on e5m2 x e4m3 operands (and e5m2(x) by truncation)."""
+    so = engine_option
+    e0 = S.check_gemm_p3(emu_engine, DEV, 1, 5, 13, 64, 96, mode=0, tile=tile, seed=1, set_option=so)
+    assert e0 < 1e-4, e0
+    S.check_gemm_p3(emu_engine, DEV, 2, 6, 11, 32, 160, mode=0, res=True, tile=tile, seed=2, set_option=so)
+    S.check_gemm_p3(emu_engine, DEV, 1, 9, 30, 96, 256, mode=1, tile=tile, seed=3, set_option=so)                      # GEGLU: 128 outputs, 3 chunks, 270 rows
+    S.check_gemm_p3(emu_engine, DEV, 1, 8, 16, 64, 64, mode=3, res=True, tile=tile, seed=4, set_option=so)
+    S.check_gemm_p3(emu_engine, DEV, 1, 7, 9, 64, 192, mode=2, lo_cols=128, tile=tile, seed=5, set_option=so)          # q | k | v: no pair plane for the V third
+    S.check_gemm_p3(emu_engine, DEV, 2, 8, 12, 64, 96, mode=4, res=True, tile=tile, seed=6, set_option=so)             # 96 rows per image: image-aligned ragged tiles
+    S.check_gemm_p3(emu_engine, DEV, 1, 4, 40, 64, 96, mode=0, ln=True, tile=tile, seed=7, set_option=so)
+
+
+def test_gemm_p3_operand_ranges(emu_engine):
+    """activations x300 / weights x4 and x1/64: the e5m2 operands (range of fp16) and the per-layer e4m3 weight scale keep the relative error at the level of the arithmetic"""
+    for xs, ws, seed in ((300.0, 4.0, 11), (0.01, 1.0 / 64, 12)):
+        e = S.check_gemm_p3(emu_engine, DEV, 1, 4, 32, 64, 128, mode=0, seed=seed, xscale=xs, wscale=ws, rel=True)
+        assert e < 1e-4, (xs, ws, e)
+
+
 def test_conv3x3_thin_output_tile(emu_engine):
     S.check_conv(emu_engine, DEV, 2, 10, 33, 32, 3, in_f32=True, tile_cfg=4, seed=9)          # conv_out shape: Cout 3 -> one 32-wide tile
 

@@ -348,3 +348,24 @@ def test_conv_const_tiles_are_filled_not_multiplied(eng):
     S.check_conv_const_tiles(eng, DEV)
     S.check_conv_const_tiles(eng, DEV, N=1, H=40, W=96, Cin=64, Cout=128, gn=False, res=False, seed=8)
     S.check_conv_const_tiles(eng, DEV, N=3, H=256, W=512, Cin=128, Cout=256, seed=9)
+
+
+@pytest.mark.parametrize("tile", [0, 256, 128, 64])
+def test_gemm_p3_plane_fed_gemm(eng, engine_option, tile):
+    """k_gemm.h on hardware at the transformer blocks' shapes (replace.py:232-362): every epilogue, 10 - 40 K chunks, ragged row / channel tiles,
+    image-aligned tiles with fused statistics, LayerNorm with plane output in front; tile 0 = the engine's own choice."""
+    so = engine_option
+    e0 = S.check_gemm_p3(eng, DEV, 2, 40, 40, 320, 320, mode=0, res=True, tile=tile, seed=1, set_option=so)
+    assert e0 < 1.5e-4, e0
+    S.check_gemm_p3(eng, DEV, 1, 32, 33, 320, 2560, mode=1, tile=tile, seed=2, set_option=so, atol=1e-4, rel=True)      # u * gelu(g): |values| up to ~15
+    S.check_gemm_p3(eng, DEV, 1, 24, 24, 1280, 640, mode=3, res=True, tile=tile, seed=3, set_option=so)
+    S.check_gemm_p3(eng, DEV, 2, 17, 19, 640, 1920, mode=2, lo_cols=1280, tile=tile, seed=4, set_option=so)
+    S.check_gemm_p3(eng, DEV, 3, 28, 24, 640, 640, mode=4, res=True, tile=tile, seed=5, set_option=so)      # 672 rows per image: ragged image-aligned tiles
+    S.check_gemm_p3(eng, DEV, 1, 16, 20, 1280, 1280, mode=0, ln=True, tile=tile, seed=6, set_option=so)
+    S.check_gemm_p3(eng, DEV, 1, 7, 9, 64, 96, mode=0, tile=tile, seed=7, set_option=so)
+
+
+@pytest.mark.parametrize("xs,ws", [(300.0, 4.0), (0.01, 1.0 / 64), (300.0, 1.0 / 64)])
+def test_gemm_p3_operand_ranges(eng, xs, ws):
+    e = S.check_gemm_p3(eng, DEV, 1, 16, 32, 640, 256, mode=0, seed=11, xscale=xs, wscale=ws, rel=True)
+    assert e < 1e-4, (xs, ws, e)
