@@ -15,6 +15,7 @@
 // Logits are computed in fp32 as s*scale*log2e + bias*log2e and exponentiated with v_exp_f32 (2^x).
 #pragma once
 #include "sdm_common.h"
+#include "k_gemm.h"      // p3_pack_block: the attention output as the operand planes of the next GEMM
 
 struct AttnParams {
   const half_t* q; long q_bs; int ldq;                     // q [b][row][head*D + d]
@@ -23,6 +24,10 @@ struct AttnParams {
   const float* bias; long bias_bs;                         // bias[b][key] * log2e, or null
   half_t* o; long o_bs; int ldo;                           // o [b][row][head*D + d]
   int o_f32;                                               // 1: o is fp32 (same indexing), 0: fp16
+  // o_p3 != 0 (with o_f32 == 1, Lq % 32 == 0, images contiguous): the result is written as the P3 operand planes of the GEMM that consumes it (k_gemm.h:
+  // `o` = HI plane of a [batch * Lq][ldo] tensor, XL plane o_xl_off bytes behind it) from the wave's staged result tile instead of as fp32 rows; with a key split the partial sums stay fp32 and attn_combine_kernel writes the planes.
+  // d = 64 kernels only (the d = 512 kernel sits at its register limit: its fp32 result takes one to_p3_kernel pass instead)
+  int o_p3; long o_xl_off;
   // precise (split-fp16) variant, d = 64: q / k / vt are the HIGH parts; the low parts live in a second plane at these element
   // offsets (q = q_hi + q_lo etc., written by the producing GEMM's `out_f32 == 2` epilogue and by transpose_v on both planes)
   long q_lo, k_lo, vt_lo;
@@ -48,6 +53,20 @@ struct AttnParams {
 // i.e. the margin minus the spread of the raw logits q.k*scale*log2e (which would have to exceed 1850 to matter; the reference's own
 // fp16 path overflows long before).  The trimap biases are 0 / -7213 / -14427 in this domain.
 #define SDM_ATTN_SKIP_MARGIN 2000.0f
+
+// the wave's staged fp32 result tile ([32 queries][64 channels] at pitch `ps` bytes in LDS) -> the P3 planes of the GEMM that consumes it (k_gemm.h).
+// Lane (row = lane & 15, run = lane >> 4) x 2 row halves x 2 channel chunks: a store instruction writes one whole 1 KB block of the HI plane; the XL bytes go
+// out as 256-byte runs.  (From the staged tile, not from the O^T accumulators: packing the planes in registers cost the pipelined kernels their schedule.)
+SDM_DEV_INLINE void attn_store_p3(const AttnParams& p, const unsigned char* stf, int ps, int b, int q0, int head, int lane) {
+  unsigned char* base = (unsigned char*)p.o;
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int row = (pass >> 1) * 16 + (lane & 15), cch = (pass & 1) * 32 + (lane >> 4) * 8;
+    const f32x4 a = *(const f32x4*)(stf + row * ps + cch * 4), c = *(const f32x4*)(stf + row * ps + cch * 4 + 16);
+    const float y[8] = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+    if (q0 + row < p.Lq) p3_store8(y, base, base + p.o_xl_off, (size_t)b * p.Lq + q0 + row, p.ldo, head * 64 + cch);
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // d = 64, any number of heads (grid.y).  4 waves per block, QT x 32 queries per wave (QT = 2 halves the K / V^T fragment
@@ -490,12 +509,16 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_kernel(AttnParams p) {
           *(f32x4*)(stf + l31 * PS + (dt * 32 + 8 * g + 4 * hi) * 4) = h;
         }
       SDM_WAVE_SYNC();
+      if (p.o_p3 && p.nsplit <= 1) {
+        attn_store_p3(p, stf, PS, b, q0 + qt * 32, head, lane);
+      } else {
 #pragma unroll
       for (int pass = 0; pass < 8; ++pass) {
         const int row = pass * 4 + (lane >> 4), part = lane & 15;
         const int qg = q0 + qt * 32 + row;
         if (qg < p.Lq)
           *(f32x4*)(obase + (size_t)qg * p.ldo + head * 64 + part * 4) = *(const f32x4*)(stf + row * PS + part * 16);
+      }
       }
       SDM_WAVE_SYNC();
     }
@@ -750,6 +773,7 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_pipe_kernel(AttnParams p)
       *(f32x4*)(stf + l31 * PS + (dt * 32 + 8 * g + 4 * hi) * 4) = h;
     }
   SDM_WAVE_SYNC();
+  if (p.o_p3 && p.nsplit <= 1) { attn_store_p3(p, stf, PS, b, q0, head, lane); return; }
 #pragma unroll
   for (int pass = 0; pass < 8; ++pass) {
     const int row = pass * 4 + (lane >> 4), part = lane & 15;
@@ -991,6 +1015,35 @@ __global__ void __launch_bounds__(256) attn_combine_kernel(const float* __restri
 #pragma unroll
   for (int e = 0; e < 4; ++e) acc[e] *= inv;
   *(f32x4*)(out + (size_t)b * o_bs + (size_t)row * ldo + head * 64 + part * 4) = acc;
+}
+
+// the same with the result as P3 planes (AttnParams::o_p3): 8 threads per (row, head), 8 channels each
+__global__ void __launch_bounds__(256) attn_combine_p3_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml, unsigned char* __restrict__ out,
+                                                              long xl_off, int nsplit, long part_stride, int batch, int heads, int Lq, long o_bs, int ldo) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int part = (int)(t & 7);
+  const long rh = t >> 3;
+  if (rh >= (long)batch * Lq * heads) return;
+  const int head = (int)(rh % heads);
+  const long br = rh / heads;
+  const int row = (int)(br % Lq), b = (int)(br / Lq);
+  float M = SDM_NEG_BIG;
+  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, part_ml[((((size_t)s * batch + b) * heads + head) * Lq + row) * 2]);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float L = 0.0f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float* ml = part_ml + ((((size_t)s * batch + b) * heads + head) * Lq + row) * 2;
+    const float w = sdm_exp2(ml[0] - M);
+    L += ml[1] * w;
+    const float* src = part_o + (size_t)s * part_stride + (size_t)b * o_bs + (size_t)row * ldo + head * 64 + part * 8;
+    const f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { acc[e] += v0[e] * w; acc[4 + e] += v1[e] * w; }
+  }
+  const float inv = 1.0f / L;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] *= inv;
+  p3_store8(acc, out, out + xl_off, (size_t)b * Lq + row, ldo, head * 64 + part * 8);
 }
 
 __global__ void __launch_bounds__(256) attn_active_tiles_kernel(const float* __restrict__ bias, int Lk, int ntiles, int* __restrict__ out,

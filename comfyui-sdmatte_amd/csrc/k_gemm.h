@@ -133,37 +133,42 @@ __global__ void __launch_bounds__(256, (NS * (2 * MT * 32 * 96 + 2 * NT * 32 * 1
   SDM_DYN_SMEM(smem);
   const int tx = (int)threadIdx.x, lane = tx & 63, wave = SDM_UNIFORM_I(tx >> 6);
   const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, l31 = lane & 31;
-  int mt, nt;
-  {
-    const int bid = (int)blockIdx.x;
-    if (p.xcd_chunk > 0) {
-      const int j = bid >> 3, ml = j / p.tiles_n;
-      nt = j - ml * p.tiles_n;
-      mt = (bid & 7) * p.xcd_chunk + ml;
-      if (mt >= p.tiles_m) return;
-    } else {
-      mt = bid / p.tiles_n;
-      nt = bid - mt * p.tiles_n;
-    }
-  }
-  int img = 0, mti = mt;
-  long m0 = (long)mt * BM, m_end = p.M;
-  if (p.rows_per_img) {
-    img = mt / p.tiles_per_img; mti = mt - img * p.tiles_per_img;
-    m0 = (long)img * p.rows_per_img + (long)mti * BM;
-    m_end = (long)(img + 1) * p.rows_per_img;
-  }
-  const int n0 = nt * BN;
   const int nch = p.K >> 5;
-  const unsigned int rows_left = (unsigned int)((m_end - m0) < (long)BM ? (m_end - m0) : (long)BM);
   const unsigned int K = (unsigned int)p.K, N = (unsigned int)p.N;
-  // the tile's blocks of the two planes (m0 % 32 == 0): 16-row block i, chunk c of HI at (i * K/32 + c) KB, 32-row block i of XL likewise
-  const unsigned int rows_avail = (unsigned int)((long)p3_rows_pad((size_t)p.M) - m0 < (long)BM ? (long)p3_rows_pad((size_t)p.M) - m0 : (long)BM);
-  const sdm_rsrc rs_ahi = sdm_make_rsrc((const unsigned char*)p.a_hi + (size_t)m0 * K * 2, rows_avail * K * 2u);
-  const sdm_rsrc rs_axl = sdm_make_rsrc(p.a_xl + (size_t)m0 * K, rows_avail * K);
+  const long rows_pad = (long)p3_rows_pad((size_t)p.M);
+  // Tiles of this block: the virtual ids blockIdx.x, + gridDim.x, ... (a persistent grid; gridDim.x % 8 == 0 keeps a block's tiles on its XCD's M range).
+  // The block treats its (tile, chunk) pairs as ONE stream: the DMAs of a tile's first chunk are issued while the previous tile's last chunk is
+  // multiplied, so they land underneath that tile's epilogue instead of in front of the first MFMA.
+  const int vgrid = (p.xcd_chunk > 0) ? 8 * p.xcd_chunk * p.tiles_n : p.tiles_m * p.tiles_n;
+  auto next_tile = [&](int v, int& mt, int& nt) -> int {      // first valid id >= v of this block's sequence, or -1 (padding ids of the XCD rounding are skipped)
+    for (; v < vgrid; v += (int)gridDim.x) {
+      if (p.xcd_chunk > 0) {
+        const int j = v >> 3, ml = j / p.tiles_n;
+        nt = j - ml * p.tiles_n;
+        mt = (v & 7) * p.xcd_chunk + ml;
+        if (mt < p.tiles_m) return v;
+      } else {
+        mt = v / p.tiles_n;
+        nt = v - mt * p.tiles_n;
+        return v;
+      }
+    }
+    return -1;
+  };
+  auto tile_rows = [&](int mt, int& img, int& mti, long& m_end) -> long {      // first row of M tile mt (image-aligned tiles: rows_per_img != 0)
+    img = 0; mti = mt; m_end = p.M;
+    if (!p.rows_per_img) return (long)mt * BM;
+    img = mt / p.tiles_per_img; mti = mt - img * p.tiles_per_img;
+    m_end = (long)(img + 1) * p.rows_per_img;
+    return (long)img * p.rows_per_img + (long)mti * BM;
+  };
   const sdm_rsrc rs_w = sdm_make_rsrc(p.w, (unsigned int)nch * N * 128u);
   const unsigned int vo_w = (unsigned int)lane * 16u;
-  auto issue = [&](int c, unsigned char* st) {
+  // chunk c of the tile at row m0 (m0 % 32 == 0), channel n0: 16-row block i of HI at (i * K/32 + c) KB behind the tile's first block, 32-row block i of XL likewise
+  auto issue = [&](long m0, int n0, int c, unsigned char* st) {
+    const unsigned int rows_avail = (unsigned int)(rows_pad - m0 < (long)BM ? rows_pad - m0 : (long)BM);
+    const sdm_rsrc rs_ahi = sdm_make_rsrc((const unsigned char*)p.a_hi + (size_t)m0 * K * 2, rows_avail * K * 2u);
+    const sdm_rsrc rs_axl = sdm_make_rsrc(p.a_xl + (size_t)m0 * K, rows_avail * K);
     // (a region of fewer than 4 pieces is copied redundantly by the surplus waves - same source, same destination - so that every wave's count is PER)
 #pragma unroll
     for (int i0 = 0; i0 < BM / 16; i0 += 4) {
@@ -189,12 +194,6 @@ __global__ void __launch_bounds__(256, (NS * (2 * MT * 32 * 96 + 2 * NT * 32 * 1
   };
 
   f32x16 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
   // fragment addresses inside a stage (constant for the tile)
   int wh_off[NT], w8_off[NT], ah_off[MT], ax_off[MT];
@@ -213,22 +212,78 @@ __global__ void __launch_bounds__(256, (NS * (2 * MT * 32 * 96 + 2 * NT * 32 * 1
   const int sa8 = p.sa, sb8 = p.sb;
 
   const bool ab_mm = (p.ablate & 1) != 0, ab_dma = (p.ablate & 2) != 0;
+  // the issue side of the stream: tile v_iss (row m0_i, channel n0_i), next chunk ic
+  int mt_c, nt_c, v_cur = next_tile((int)blockIdx.x, mt_c, nt_c);
+  if (v_cur < 0) return;
+  int v_iss = v_cur, ic = 0, st_cur = 0, st_nxt = 0, ahead = 0, n0_i = nt_c * BN;
+  long m0_i;
+  { int im, ti; long me; m0_i = tile_rows(mt_c, im, ti, me); }
+  auto stream_issue = [&]() {
+    if (v_iss < 0) return;
+    issue(m0_i, n0_i, ic, smem + st_nxt * STAGE);
+    st_nxt = (st_nxt + 1 == NS) ? 0 : st_nxt + 1;
+    ++ahead;
+    if (++ic == nch) {
+      int mt, nt;
+      ic = 0;
+      v_iss = next_tile(v_iss + (int)gridDim.x, mt, nt);
+      if (v_iss >= 0) { int im, ti; long me; m0_i = tile_rows(mt, im, ti, me); n0_i = nt * BN; }
+    }
+  };
 #pragma unroll
-  for (int s = 0; s < NS - 1; ++s)
-    if (s < nch) issue(s, smem + s * STAGE);
-  int st_cur = 0, st_nxt = NS - 1;       // ring slots of chunk c and of chunk c + NS - 1
+  for (int s = 0; s < NS - 1; ++s) stream_issue();
+  bool first = true;
+  while (v_cur >= 0) {
+  int img, mti;
+  long m_end;
+  const long m0 = tile_rows(mt_c, img, mti, m_end);
+  const int n0 = nt_c * BN;
+  const unsigned int rows_left = (unsigned int)((m_end - m0) < (long)BM ? (m_end - m0) : (long)BM);
+  // the accumulators start from the fp32 residual (register quad = four consecutive channels of a row = one 16-byte load; rows / channels beyond the end
+  // read 0): the loads fly while the tile's first chunk lands, and no epilogue waits for memory
+  if ((EPI == 0 || EPI == 3 || EPI == 4) && p.res) {
+    const sdm_rsrc rs_res = sdm_make_rsrc(p.res + (size_t)m0 * p.ldr, rows_left * (unsigned int)p.ldr * 4u);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int ch = n0 + (wn * NT + j) * 32 + 8 * g + 4 * h;
+          const unsigned int row = (unsigned int)((wm * MT + i) * 32 + l31);
+          const f32x4 r4 = __builtin_bit_cast(f32x4, sdm_buffer_load16(rs_res, ch < p.n_valid ? row * (unsigned int)p.ldr * 4u + (unsigned int)ch * 4u : SDM_BUF_INVALID, 0));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] = r4[e];
+        }
+#if !defined(SDM_EMU) && defined(__HIP_DEVICE_COMPILE__)
+    // the loads are waited for HERE: hipcc does not count LDS-DMAs, so a wait it placed in front of the first MFMA - behind the DMAs of the next chunk -
+    // would drain those as well
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(acc[i][j]));
+#endif
+  } else {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  }
   for (int c = 0; c < nch; ++c) {
-    // this wave's share of chunk c has landed; the chunks behind it (up to NS - 2 of them, PER instructions each) may stay in flight
+    // this wave's share of the oldest chunk in flight has landed; the `ahead - 1` chunks behind it (PER instructions each) may stay in flight
 #ifndef SDM_EMU
-    if (NS > 2 && c + NS - 2 < nch) { asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NS - 2) * PER) : "memory"); }
+    if (NS > 2 && ahead - 1 >= NS - 2) { asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NS - 2) * PER) : "memory"); }
     else
 #endif
       SDM_WAIT_VMCNT0();
-    SDM_RAW_BARRIER();           // ... everybody's has, and every wave is past its reads of chunk c - 1, whose slot the next DMAs overwrite
-    if (c + NS - 1 < nch && !(ab_dma && c > 0)) issue(c + NS - 1, smem + st_nxt * STAGE);
+    SDM_RAW_BARRIER();           // ... everybody's has, and every wave is past its reads of the previous chunk, whose slot the next DMAs overwrite
+    --ahead;
+    if (!(ab_dma && !first)) stream_issue();
+    first = false;
     const unsigned char* st = smem + st_cur * STAGE;
     st_cur = (st_cur + 1 == NS) ? 0 : st_cur + 1;
-    st_nxt = (st_nxt + 1 == NS) ? 0 : st_nxt + 1;
     if (ab_mm && c > 0) continue;
     f16x8 wh[2][NT];
     i32x8 w8[NT];
@@ -272,7 +327,8 @@ __global__ void __launch_bounds__(256, (NS * (2 * MT * 32 * 96 + 2 * NT * 32 * 1
   }
 
   // ---------------- epilogue: straight from the accumulators, 16 bytes per lane and store ----------------
-  if (p.ablate & 4) { if (acc[0][0][0] == 123.456f) ((float*)p.out)[0] = 1.0f; return; }
+  if (p.ablate & 4) { if (acc[0][0][0] == 123.456f) ((float*)p.out)[0] = 1.0f; }
+  else {
   const float* bias = p.bias;
   f32x4 bq[NT][4];
 #pragma unroll
@@ -282,71 +338,43 @@ __global__ void __launch_bounds__(256, (NS * (2 * MT * 32 * 96 + 2 * NT * 32 * 1
       const int ch = n0 + (wn * NT + j) * 32 + 8 * g + 4 * h;
       bq[j][g] = (bias && ch < p.N) ? *(const f32x4*)(bias + ch) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
-  const sdm_rsrc rs_res = sdm_make_rsrc(p.res ? (const void*)(p.res + (size_t)m0 * p.ldr) : (const void*)p.w, p.res ? rows_left * (unsigned int)p.ldr * 4u : 0u);
   if (EPI == 0 || EPI == 4) {
     const sdm_rsrc rs_out = sdm_make_rsrc((float*)p.out + (size_t)m0 * p.ldo, rows_left * (unsigned int)p.ldo * 4u);
-    constexpr bool do_stats = (EPI == 4);       // a separate instantiation: the 2 x 32 partial sums per lane must not cost the plain form registers
-    constexpr int SN = do_stats ? NT : 1, SR = do_stats ? 16 : 1;
-    float s1[SN][SR], s2[SN][SR];
+    constexpr bool do_stats = (EPI == 4);
+    // channel quad by channel quad, the MT row blocks of a quad back to back: a quad's statistics (per channel over this wave's MT * 32 rows) are complete
+    // after its MT stores and need 8 registers, not 64 (the residual is already in the accumulators)
+    const size_t prow = (size_t)img * (p.tiles_per_img * 2) + (size_t)mti * 2 + wm;
 #pragma unroll
-    for (int j = 0; j < SN; ++j)
+    for (int jg = 0; jg < NT * 4; ++jg) {
+      const int j = jg >> 2, g = jg & 3;
+      const int ch = n0 + (wn * NT + j) * 32 + 8 * g + 4 * h;
+      float t1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, t2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-      for (int r = 0; r < SR; ++r) { s1[j][r] = 0.0f; s2[j][r] = 0.0f; }
+      for (int i = 0; i < MT; ++i) {
+        const unsigned int row = (unsigned int)((wm * MT + i) * 32 + l31);
+        f32x4 v;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const unsigned int row = (unsigned int)((wm * MT + i) * 32 + l31);
-      u32x4 rr[NT][4];
-      if (p.res) {
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + bq[j][g][e];
+        sdm_buffer_store16(__builtin_bit_cast(u32x4, v), rs_out, ch < p.n_valid ? row * (unsigned int)p.ldo * 4u + (unsigned int)ch * 4u : SDM_BUF_INVALID, 0);
+        if (do_stats && row < rows_left) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int ch = n0 + (wn * NT + j) * 32 + 8 * g + 4 * h;
-            rr[j][g] = sdm_buffer_load16(rs_res, ch < p.n_valid ? row * (unsigned int)p.ldr * 4u + (unsigned int)ch * 4u : SDM_BUF_INVALID, 0);
-          }
+          for (int e = 0; e < 4; ++e) { t1[e] += v[e]; t2[e] += v[e] * v[e]; }
+        }
+        SDM_PIN_STORE_DATA(v);
       }
+      if (do_stats) {
+        // over the 32 lanes of the lane half; lane 0 / 32 writes its 4 channels of the partial row (image, M tile, wave row): [sum, sumsq] pairs = 32 contiguous bytes
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int ch = n0 + (wn * NT + j) * 32 + 8 * g + 4 * h;
-          f32x4 v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + bq[j][g][e];
-          if (p.res) {
-            const f32x4 r4 = __builtin_bit_cast(f32x4, rr[j][g]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += r4[e];
-          }
-          sdm_buffer_store16(__builtin_bit_cast(u32x4, v), rs_out, ch < p.n_valid ? row * (unsigned int)p.ldo * 4u + (unsigned int)ch * 4u : SDM_BUF_INVALID, 0);
-          if (do_stats && row < rows_left) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { s1[do_stats ? j : 0][do_stats ? 4 * g + e : 0] += v[e]; s2[do_stats ? j : 0][do_stats ? 4 * g + e : 0] += v[e] * v[e]; }
-          }
-          SDM_PIN_STORE_DATA(v);
+        for (int e = 0; e < 4; ++e) {
+          t1[e] = sdm_sum_row16(t1[e]); t2[e] = sdm_sum_row16(t2[e]);
+          t1[e] += __shfl_xor(t1[e], 16); t2[e] += __shfl_xor(t2[e], 16);
         }
-    }
-    if (do_stats) {
-      // per channel over this wave's MT * 32 rows: in-lane over the row blocks (above), then over the 32 lanes of the lane half; lane 0 / 32 of the wave
-      // writes the partial row (image, M tile, wave row) of its channels: [sum, sumsq] pairs, 4 consecutive channels = 32 contiguous bytes
-      const size_t prow = (size_t)img * (p.tiles_per_img * 2) + (size_t)mti * 2 + wm;
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float t1[4], t2[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            t1[e] = sdm_sum_row16(s1[do_stats ? j : 0][do_stats ? 4 * g + e : 0]); t2[e] = sdm_sum_row16(s2[do_stats ? j : 0][do_stats ? 4 * g + e : 0]);
-            t1[e] += __shfl_xor(t1[e], 16); t2[e] += __shfl_xor(t2[e], 16);
-          }
-          const int ch = n0 + (wn * NT + j) * 32 + 8 * g + 4 * h;
-          if (l31 == 0 && ch < p.n_valid) {
-            float* dst = p.stats + (prow * p.ldo + ch) * 2;
-            *(f32x4*)dst = f32x4{t1[0], t2[0], t1[1], t2[1]};
-            *(f32x4*)(dst + 4) = f32x4{t1[2], t2[2], t1[3], t2[3]};
-          }
+        if (l31 == 0 && ch < p.n_valid) {
+          float* dst = p.stats + (prow * p.ldo + ch) * 2;
+          *(f32x4*)dst = f32x4{t1[0], t2[0], t1[1], t2[1]};
+          *(f32x4*)(dst + 4) = f32x4{t1[2], t2[2], t1[3], t2[3]};
         }
+      }
     }
   } else if (EPI == 1 || EPI == 3) {
     constexpr int NB = (EPI == 1) ? 1 : NT;                         // 32-channel output blocks per wave and row block
@@ -370,22 +398,8 @@ __global__ void __launch_bounds__(256, (NS * (2 * MT * 32 * 96 + 2 * NT * 32 * 1
             v[r] = u * p3_gelu(g);
           }
         } else {
-          u32x4 rr[4];
-          if (p.res) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-              rr[g] = sdm_buffer_load16(rs_res, cb < p.n_valid ? row * (unsigned int)p.ldr * 4u + (unsigned int)(cb + 8 * g + 4 * h) * 4u : SDM_BUF_INVALID, 0);
-          }
 #pragma unroll
           for (int r = 0; r < 16; ++r) v[r] = acc[i][jb][r] + bq[jb][r >> 2][r & 3];
-          if (p.res) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const f32x4 r4 = __builtin_bit_cast(f32x4, rr[g]);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[4 * g + e] += r4[e];
-            }
-          }
         }
         u32x4 hi2[2], xl;
         p3_pack_block(v, hi2, xl);
@@ -445,6 +459,9 @@ __global__ void __launch_bounds__(256, (NS * (2 * MT * 32 * 96 + 2 * NT * 32 * 1
       }
     }
   }
+  }   // epilogue
+  v_cur = next_tile(v_cur + (int)gridDim.x, mt_c, nt_c);
+  }   // tiles of this block
 }
 
 // ---- W3 layout of a Linear / 1x1 weight from its canonical K16 tensors (k_hi / k_lo: [Cin_pad/16][Cout_pad][16], w * 2^w_exp = hi + lo).
@@ -564,21 +581,24 @@ __global__ void __launch_bounds__(256) from_p3_kernel(const unsigned char* __res
   }
 }
 
-// LayerNorm over the last dim (F.layer_norm, eps inside the root; BasicTransformerBlock norm1 / norm2 / norm3) with P3 output: one wave per
-// row, a lane owns 8-channel runs (run v of the row belongs to lane v % 64), two-pass statistics in registers as layernorm_kernel (k_norm.h)
-#define SDM_LNP_MAXV 3
+// LayerNorm over the last dim (F.layer_norm, eps inside the root; BasicTransformerBlock norm1 / norm2 / norm3) with P3 output.  FOUR rows per wave -
+// lane (r = lane & 3, u = lane >> 2) owns the 8-channel runs v = 16 i + u of row 4 w + r - so that a store instruction covers four consecutive rows of
+// sixteen runs: in the blocked planes the four rows of a run are 64 contiguous bytes (whole sectors; one row per wave wrote 64 separate 16-byte
+// pieces per instruction and cost LayerNorm +35 %).  Loads stay whole lines (512 contiguous bytes per row and instruction).  Two-pass statistics in
+// registers as layernorm_kernel (k_norm.h); the row sums cross the 16 lanes of a row with four xor-shuffles.  A block = 16 rows = one row block.
+#define SDM_LNP_MAXI 10      /* C <= 1280 */
 __global__ void __launch_bounds__(256) layernorm_p3_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            unsigned char* __restrict__ out, long rows, int C, float eps) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long row = (long)blockIdx.x * (blockDim.x >> 6) + wave;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 3, u = lane >> 2;
+  const long row = ((long)blockIdx.x * 4 + wave) * 4 + r;
   const bool active = row < rows;
-  const long rr = active ? row : rows - 1;
+  const long rr = active ? row : rows - 1;     // keep every lane in the shuffles
   const int nv = C / 8;
-  f32x4 v[SDM_LNP_MAXV][2];
+  f32x4 v[SDM_LNP_MAXI][2];
   float s = 0.0f;
 #pragma unroll
-  for (int i = 0; i < SDM_LNP_MAXV; ++i) {
-    const int q = i * 64 + lane;
+  for (int i = 0; i < SDM_LNP_MAXI; ++i) {
+    const int q = i * 16 + u;
     v[i][0] = v[i][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     if (q < nv) {
       const float* src = x + (size_t)rr * C + (size_t)q * 8;
@@ -587,25 +607,25 @@ __global__ void __launch_bounds__(256) layernorm_p3_kernel(const float* __restri
     }
   }
 #pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+  for (int m = 32; m >= 4; m >>= 1) s += __shfl_xor(s, m);
   const float mean = s / (float)C;
   float qs = 0.0f;
 #pragma unroll
-  for (int i = 0; i < SDM_LNP_MAXV; ++i)
-    if (i * 64 + lane < nv) {
+  for (int i = 0; i < SDM_LNP_MAXI; ++i)
+    if (i * 16 + u < nv) {
 #pragma unroll
       for (int k = 0; k < 2; ++k)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { const float d = v[i][k][e] - mean; qs += d * d; }
     }
 #pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) qs += __shfl_xor(qs, m);
+  for (int m = 32; m >= 4; m >>= 1) qs += __shfl_xor(qs, m);
   const float rstd = 1.0f / sqrtf(qs / (float)C + eps);
   if (!active) return;
   unsigned char* xl = out + p3_rows_pad((size_t)rows) * (size_t)C * 2;
 #pragma unroll
-  for (int i = 0; i < SDM_LNP_MAXV; ++i) {
-    const int q = i * 64 + lane;
+  for (int i = 0; i < SDM_LNP_MAXI; ++i) {
+    const int q = i * 16 + u;
     if (q < nv) {
       float y[8];
 #pragma unroll

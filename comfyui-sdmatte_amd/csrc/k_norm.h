@@ -182,9 +182,7 @@ __global__ void __launch_bounds__(512) gn_apply_kernel(GnSrc s, const float* __r
       if (silu) y[e] = sdm_silu(y[e]);
     }
     const size_t oi = ((size_t)n * s.HW + p) * C + c;
-    if (out_f32 == 4) {                            // P3 planes (k_gemm.h): the consumer is the plane-fed GEMM (Transformer2DModel.proj_in)
-      p3_store8(y, (unsigned char*)out, (unsigned char*)out + p3_rows_pad((size_t)gridDim.y * s.HW) * (size_t)C * 2, (size_t)n * s.HW + p, C, c);
-    } else if (out_f32) {                                 // precise mode: the consumer splits the fp32 value into an fp16 pair itself
+    if (out_f32) {                                 // precise mode: the consumer splits the fp32 value into an fp16 pair itself
       f32x4 o0, o1;
 #pragma unroll
       for (int e = 0; e < 4; ++e) { o0[e] = y[e]; o1[e] = y[4 + e]; }
@@ -196,6 +194,35 @@ __global__ void __launch_bounds__(512) gn_apply_kernel(GnSrc s, const float* __r
       for (int e = 0; e < 8; ++e) o[e] = (half_t)y[e];
       *(f16x8*)((half_t*)out + oi) = o;
     }
+  }
+}
+
+// The same with the result as the P3 operand planes of the plane-fed GEMM (k_gemm.h; Transformer2DModel.norm -> proj_in, VAE Attention.group_norm -> q | k | v).
+// A block = 16 consecutive rows (one row block of the HI plane); thread (r = tid & 15, u = tid >> 4) walks the 8-channel runs v = u, u + 16, ...: a wave
+// reads 16 rows x 128 bytes (whole lines) and writes one whole 1 KB block of the HI plane plus two 256-byte runs of the XL plane per step.
+__global__ void __launch_bounds__(256) gn_apply_p3_kernel(GnSrc s, const float* __restrict__ scale, const float* __restrict__ shift, unsigned char* __restrict__ out,
+                                                          int silu, long rows_total) {
+  const int C = s.C0 + s.C1, nv = C / 8;
+  const int tid = threadIdx.x;
+  const long row = (long)blockIdx.x * 16 + (tid & 15);
+  if (row >= rows_total) return;
+  const long n = row / s.HW;
+  unsigned char* xl = out + p3_rows_pad((size_t)rows_total) * (size_t)C * 2;
+  for (int v = tid >> 4; v < nv; v += 16) {
+    const int c = v * 8;
+    const void* src = s.in0; int Cs = s.C0, cc = c;
+    if (c >= s.C0) { src = s.in1; Cs = s.C1; cc = c - s.C0; }
+    float x8[8], y[8];
+    sdm_load8_as_f32(src, (size_t)row * Cs + cc, s.in_f32, x8);
+    const f32x4 a0 = *(const f32x4*)(scale + (size_t)n * C + c), a1 = *(const f32x4*)(scale + (size_t)n * C + c + 4);
+    const f32x4 b0 = *(const f32x4*)(shift + (size_t)n * C + c), b1 = *(const f32x4*)(shift + (size_t)n * C + c + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { y[e] = x8[e] * a0[e] + b0[e]; y[4 + e] = x8[4 + e] * a1[e] + b1[e]; }
+    if (silu) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[e] = sdm_silu(y[e]);
+    }
+    p3_store8(y, out, xl, (size_t)row, C, c);
   }
 }
 

@@ -97,6 +97,8 @@ static OptEntry g_opts[] = {
   {"gemm_f8_min_k", 1024, 1024, "smallest K of a GEMM that takes the 8-wave fp8-residual kernel"},
   {"gemm_p3", 1, 1, "transformer-block Linear layers on the plane-fed GEMM (k_gemm.h): pre-split operand planes from LayerNorm / GroupNorm / attention / GEGLU, LDS-DMA only (the W3 weight copies are built when a model is built)"},
   {"gemm_p3_tile", 0, 0, "row tile of the plane-fed GEMM: 0 by shape, 256 / 128 / 64 forced"},
+  {"gemm_p3_attn", 1, 1, "d=64 attention cores write the operand planes of to_out themselves (0: fp32 result + one conversion pass)"},
+  {"gemm_p3_persist", 1, 1, "plane-fed GEMM: persistent blocks that prefetch the next tile's first chunk underneath the epilogue (0: one block per tile, n > 1: a grid of n blocks - tests)"},
   {"gemm_p3_stages", 0, 0, "LDS stages of the plane-fed GEMM: 0 default, n = lab forms (fp32 / GEGLU epilogues)"},
   {"gemm_p3_ablate", 0, 0, "bench only: 1 no MFMAs, 2 no DMAs behind the prologue, 4 no epilogue (sdm_bench_gemm_p3)"},
   {"conv_epi", 4, 4, "F8 kernels' epilogue: 4 register-direct stores + residual as accumulator init, 3 residual init only, 0 LDS-staged"},
@@ -393,8 +395,21 @@ static void launch_gemm_p3_t(GemmP3Params p, void* stream) {
   unsigned grid;
   if (p.tiles_m >= 8) { p.xcd_chunk = (p.tiles_m + 7) / 8; grid = (unsigned)(8L * p.xcd_chunk * p.tiles_n); }
   else { p.xcd_chunk = 0; grid = (unsigned)(p.tiles_m * p.tiles_n); }
+  // persistent grid: as many blocks as the chip holds at once (a multiple of 8: a block's tiles stay on its XCD's M range), each walks its tiles as one
+  // DMA stream (k_gemm.h); the option gemm_p3_persist = 0 launches one block per tile
+  if (const int pp = opt("gemm_p3_persist")) {
+    const unsigned slots = pp > 1 ? (unsigned)pp : ((unsigned)(device_cus() * ((SMEM <= 80 * 1024) ? 2 : 1)) & ~7u);      // (pp > 1: forced grid, tests)
+    if (slots >= 1 && grid > slots) grid = slots;
+  }
   auto k = gemm_p3_kernel<MT, 2, EPI, NS>;
   SDM_SET_SMEM(k, SMEM);
+#ifndef SDM_EMU
+  if (opt("gemm_p3_ablate") & 256) {      // lab: resident blocks per CU as the runtime sees them
+    int nb = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 256, (size_t)SMEM);
+    fprintf(stderr, "[gemm_p3] tile %d stages %d epi %d: %d bytes of LDS, %d blocks per CU, grid %u\n", BM, NS, EPI, SMEM, nb, grid);
+  }
+#endif
   SDM_LAUNCH(k, dim3(grid, 1, 1), dim3(256), (size_t)SMEM, stream, p);
 }
 // LDS stages per row tile: the option gemm_p3_stages = 0 takes the default of the tile, n >= 2 asks for n (lab forms exist for the fp32 and GEGLU epilogues)
@@ -1218,7 +1233,11 @@ static int op_groupnorm_raw(sdm_ctx* e, const void* in0, const void* in1, int C0
     int ppb = std::max(slots * 8, sdm_cdiv(HW, 2048 / std::max(1, N)));
     ppb = rup(ppb, slots);
     const int nb = sdm_cdiv(HW, ppb);
-    prof_begin(e, "gn_apply", 0, (double)N * HW * C * (in_f32 ? 4 : 2) + (double)N * HW * C * (out_f32 ? 4 : 2));
+    prof_begin(e, "gn_apply", 0, (double)N * HW * C * (in_f32 ? 4 : 2) + (double)N * HW * C * (double)fmt_bytes(out_f32));
+    if (out_f32 == kFmtP3)
+      SDM_LAUNCH(gn_apply_p3_kernel, dim3((unsigned)(((long)N * HW + 15) / 16)), dim3(256), 0, e->stream, s, (const float*)scale, (const float*)shift, (unsigned char*)out,
+                 silu, (long)N * HW);
+    else
     SDM_LAUNCH(gn_apply_kernel, dim3(nb, N), dim3(threads), 0, e->stream, s, (const float*)scale, (const float*)shift, out, out_f32, silu, ppb);
     prof_end(e);
   }
@@ -1241,9 +1260,9 @@ static int op_ln(sdm_ctx* e, const NormL& n, const T& x, float eps, T* out, int 
   if (e->dry) return 0;
   const long rows = x.rows();
   if (out->f32 == kFmtP3) {
-    if (x.f32 != 1 || x.C > 512 * SDM_LNP_MAXV) SDM_FAIL(e, SDM_ERR_INVALID, "layernorm (P3): fp32 input, C <= %d expected", 512 * SDM_LNP_MAXV);
+    if (x.f32 != 1 || x.C > 128 * SDM_LNP_MAXI) SDM_FAIL(e, SDM_ERR_INVALID, "layernorm (P3): fp32 input, C <= %d expected", 128 * SDM_LNP_MAXI);
     prof_begin(e, "layernorm", 0, (double)rows * x.C * 7);
-    SDM_LAUNCH(layernorm_p3_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, e->stream, (const float*)x.p, (const float*)n.g, (const float*)n.b,
+    SDM_LAUNCH(layernorm_p3_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, e->stream, (const float*)x.p, (const float*)n.g, (const float*)n.b,
                (unsigned char*)out->p, rows, x.C, eps);
     prof_end(e);
     return 0;
@@ -1259,7 +1278,7 @@ static int op_ln(sdm_ctx* e, const NormL& n, const T& x, float eps, T* out, int 
 // Precise variant (d = 64): q / k / v point at the HIGH planes of split fp16 pairs, the low planes follow at element offsets
 // q_lo / k_lo / v_lo (written by the producing GEMM with out_f32 == 2); `out` is fp16 or fp32 (out_f32).
 // prec: 0 fp16 operands; 1 q / k / v as fp16 planes hi | lo; 2 q / k as fp16 plane + e5m2 pair plane (ConvParams::out_f32 == 3), v hi only
-struct AttnPrec { int prec = 0; long q_lo = 0, k_lo = 0, v_lo = 0; int out_f32 = 0; };
+struct AttnPrec { int prec = 0; long q_lo = 0, k_lo = 0, v_lo = 0; int out_f32 = 0; int out_p3 = 0; };      // out_p3 (with out_f32 = 1): `out` is a P3 tensor (k_gemm.h)
 static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* k, int ldk, const half_t* v, int ldv, const float* bias_l2,
                             int B, int heads, int Lq, int Lk, int D, void* out, int ldo, bool q_prescaled = false, const int* tiles = nullptr,
                             AttnPrec ap = AttnPrec()) {
@@ -1324,6 +1343,10 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
     p.bias = bias_l2; p.bias_bs = Lk;
     p.tiles = tiles; p.tiles_bs = ntiles64 + 1;
     p.o = (half_t*)out; p.o_bs = (long)Lq * ldo; p.ldo = ldo; p.o_f32 = ap.out_f32;
+    if (ap.out_p3) {
+      if (!ap.out_f32 || Lq % 32 || ldo % 32 || D != 64) SDM_FAIL(e, SDM_ERR_INVALID, "attention: plane output needs d = 64, Lq %% 32 == 0 and C %% 32 == 0");
+      p.o_p3 = 1; p.o_xl_off = (long)(p3_rows_pad((size_t)B * Lq) * ldo * 2);
+    }
     p.q_lo = ap.q_lo; p.k_lo = ap.k_lo; p.vt_lo = (long)B * vt_bs;
     p.Lq = Lq; p.Lk = Lk;
     p.scale_log2e = q_prescaled ? 1.0f : (1.0f / sqrtf((float)D)) * SDM_LOG2E;      // engine: folded into the to_q weights (d = 64 only)
@@ -1377,6 +1400,10 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
       if (nsplit > 1) {
         count_kernel("attn_combine");
         const long nthr = (long)B * Lq * heads * 16;
+        if (ap.out_p3)
+          SDM_LAUNCH(attn_combine_p3_kernel, dim3((unsigned)((nthr / 2 + 255) / 256)), dim3(256), 0, e->stream, (const float*)part_o.p, (const float*)part_ml.p,
+                     (unsigned char*)out, (long)(p3_rows_pad((size_t)B * Lq) * ldo * 2), nsplit, (long)B * (long)Lq * ldo, B, heads, Lq, (long)Lq * ldo, ldo);
+        else
         SDM_LAUNCH(attn_combine_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, e->stream, (const float*)part_o.p, (const float*)part_ml.p, (float*)out,
                    nsplit, (long)B * (long)Lq * ldo, B, heads, Lq, (long)Lq * ldo, ldo);
       }
@@ -1495,6 +1522,7 @@ static int op_gemm_p3(sdm_ctx* e, const ConvL& L, const T& in, T* out, const T* 
   if (L.geglu) { if (out->f32 != kFmtP3) SDM_FAIL(e, SDM_ERR_INVALID, "gemm %s: GEGLU writes P3", L.name.c_str()); epi = 1; }
   else if (out->f32 == 1) epi = out->want_stats ? 4 : 0;
   else if (out->f32 == 3) epi = 2;
+  else if (out->f32 == 0) { epi = 2; lo_cols = 0; }          // plain fp16 rows = the high plane alone (q | k | v of the d = 512 attention)
   else if (out->f32 == kFmtP3) epi = 3;
   else SDM_FAIL(e, SDM_ERR_INVALID, "gemm %s: unsupported output format %d", L.name.c_str(), out->f32);
   GemmP3Params p;
@@ -1558,7 +1586,6 @@ static int linear(sdm_ctx* e, int layer, const T& in, T* out, int Cout, int out_
 // VAE mid-block Attention (Appendix A.5): GN -> q|k|v (+bias) -> softmax(qk^T/sqrt(C)) v -> to_out -> + x
 static int vae_attention(sdm_ctx* e, const VaeAttnB& a, const T& x, T* out) {
   T hn, qkv, ao;
-  TRY(op_gn(e, e->norms[a.gn], x, nullptr, 0, e->cfg.vae_eps, &hn));
   // the single-head d=512 core always takes fp16 operands; a 64-channel VAE (test architectures) runs on the d=64 kernels and
   // follows the U-Net attention-core precision bit
   const int pa = ((e->cfg.precise_mask & SDM_PRECISE_UNET_ATTN) && a.C == 64) ? 1 : 0;
@@ -1566,16 +1593,21 @@ static int vae_attention(sdm_ctx* e, const VaeAttnB& a, const T& x, T* out) {
   // weights - which the fp8 pair planes do not allow); V needs no low-part plane unless the fully split P.V form is requested
   const int pf = pa ? 2 : 0;
   const bool need_vlo = pf == 2 && opt("attn_pv_split") != 0;
+  const int L = x.H * x.W;
+  // plane-fed GEMMs (k_gemm.h) around the fp16-operand core: GroupNorm writes the q | k | v projection's operand planes, the projection plain fp16 rows,
+  // the core fp32 rows that one pass converts to the planes of to_out - which adds the residual and emits the statistics of the next ResBlock's GroupNorm
+  const bool p3 = pf == 0 && e->cfg.stream_f32 == 1 && L % 32 == 0 && a.C % 32 == 0 && p3_ok(e, e->convs[a.qkv]) && p3_ok(e, e->convs[a.out]);
+  TRY(op_gn(e, e->norms[a.gn], x, nullptr, 0, e->cfg.vae_eps, &hn, p3 ? kFmtP3 : -1));
   TRY(linear(e, a.qkv, hn, &qkv, 3 * a.C, pf, nullptr, false, need_vlo ? -1 : 2 * a.C));
   tfree(e, hn);
   ao = talloc(e, x.N, x.H, x.W, a.C, e->act_f32);
-  const int L = x.H * x.W;
   const half_t* q = (const half_t*)qkv.p;
   AttnPrec ap; ap.out_f32 = ao.f32; ap.prec = pa ? pf - 1 : 0;
   ap.q_lo = ap.k_lo = ap.v_lo = (long)qkv.rows() * qkv.C;
   TRY(op_attention_raw(e, q, 3 * a.C, q ? q + a.C : nullptr, 3 * a.C, q ? q + 2 * a.C : nullptr, 3 * a.C, nullptr, x.N, 1, L, L, a.C,
                        ao.p, a.C, false, nullptr, ap));
   tfree(e, qkv);
+  if (p3) { T ap3; TRY(op_to_p3(e, ao, &ap3)); tfree(e, ao); ao = ap3; }      // (the d = 512 core keeps its fp32 epilogue: k_attn.h AttnParams::o_p3)
   TRY(linear(e, a.out, ao, out, a.C, e->cfg.stream_f32, &x, true));
   tfree(e, ao);
   return 0;
@@ -1594,8 +1626,9 @@ static int transformer(sdm_ctx* e, const TfB& t, const T& x, const T& uin, const
   bool p3 = sf == 1 && pf == 3 && C % 32 == 0;
   for (int l : {t.proj_in, t.qkv1, t.o1, t.q2, t.o2, t.ff1, t.ff2, t.proj_out}) p3 = p3 && p3_ok(e, e->convs[l]);
   const int nf = p3 ? kFmtP3 : -1;                             // operand format of the norms' outputs (-1: the engine's activation type)
+  const bool p3a = p3 && L % 32 == 0 && opt("gemm_p3_attn") != 0;                           // the attention cores write the planes themselves (O^T accumulators = the GEMM's operand layout)
   auto attn_out = [&](T& a) -> int {                           // the attention output as the next GEMM's operand
-    if (!p3) return 0;
+    if (!p3 || p3a) return 0;
     T ap;
     TRY(op_to_p3(e, a, &ap));
     tfree(e, a);
@@ -1609,10 +1642,10 @@ static int transformer(sdm_ctx* e, const TfB& t, const T& x, const T& uin, const
   TRY(op_ln(e, e->norms[t.ln1], h, e->cfg.unet_ln_eps, &n, nf));
   TRY(linear(e, t.qkv1, n, &qkv, 3 * C, pf, nullptr, false, need_vlo ? -1 : 2 * C));
   tfree(e, n);
-  ao = talloc(e, x.N, x.H, x.W, C, e->act_f32);
+  ao = talloc(e, x.N, x.H, x.W, C, p3a ? kFmtP3 : e->act_f32);
   {
     const half_t* q = (const half_t*)qkv.p;
-    AttnPrec ap; ap.prec = pa ? pf - 1 : 0; ap.out_f32 = ao.f32;
+    AttnPrec ap; ap.prec = pa ? pf - 1 : 0; ap.out_f32 = p3a ? 1 : ao.f32; ap.out_p3 = p3a ? 1 : 0;
     ap.q_lo = ap.k_lo = ap.v_lo = (long)qkv.rows() * qkv.C;
     TRY(op_attention_raw(e, q, 3 * C, q ? q + C : nullptr, 3 * C, q ? q + 2 * C : nullptr, 3 * C, bias, x.N, t.heads, L, L, 64, ao.p, C, true, tiles, ap));
   }
@@ -1625,10 +1658,10 @@ static int transformer(sdm_ctx* e, const TfB& t, const T& x, const T& uin, const
   TRY(linear(e, t.q2, n, &q2, C, pf));
   tfree(e, n);
   TRY(conv_simple(e, t.kv2, uin, &kv, 2 * C, pf, 1, 0, 0, nullptr, 1.0f, false, need_vlo ? -1 : C));      // folded aux_conv_in + to_k|to_v: tokens = latent pixels, row-major
-  ao = talloc(e, x.N, x.H, x.W, C, e->act_f32);
+  ao = talloc(e, x.N, x.H, x.W, C, p3a ? kFmtP3 : e->act_f32);
   {
     const half_t* kk = (const half_t*)kv.p;
-    AttnPrec ap; ap.prec = pa ? pf - 1 : 0; ap.out_f32 = ao.f32;
+    AttnPrec ap; ap.prec = pa ? pf - 1 : 0; ap.out_f32 = p3a ? 1 : ao.f32; ap.out_p3 = p3a ? 1 : 0;
     ap.q_lo = (long)q2.rows() * q2.C; ap.k_lo = ap.v_lo = (long)kv.rows() * kv.C;
     TRY(op_attention_raw(e, (const half_t*)q2.p, C, kk, 2 * C, kk ? kk + C : nullptr, 2 * C, nullptr, x.N, t.heads, L, L0, 64, ao.p, C, true, nullptr, ap));
   }

@@ -132,6 +132,18 @@ def test_gemm_p3_plane_fed_gemm(emu_engine, engine_option, tile):
     S.check_gemm_p3(emu_engine, DEV, 1, 4, 40, 64, 96, mode=0, ln=True, tile=tile, seed=7, set_option=so)
 
 
+@pytest.mark.parametrize("grid", [3, 8])
+def test_gemm_p3_persistent_blocks_walk_several_tiles(emu_engine, engine_option, grid):
+    """a forced small grid: every block multiplies several tiles as one DMA stream (the next tile's first chunk is issued during the current tile's last
+    chunk), with the XCD-aware tile order (>= 8 row tiles) and without, one and several chunks per tile, and every epilogue that keeps per-tile state"""
+    so = engine_option
+    so(emu_engine, "gemm_p3_persist", grid)
+    S.check_gemm_p3(emu_engine, DEV, 1, 9, 30, 32, 256, mode=0, res=True, tile=64, seed=21, set_option=so)          # 5 x 2 tiles, 1 chunk each
+    S.check_gemm_p3(emu_engine, DEV, 1, 16, 33, 96, 192, mode=3, res=True, tile=64, seed=22, set_option=so)         # 9 row tiles: XCD order, padding ids
+    S.check_gemm_p3(emu_engine, DEV, 3, 8, 12, 64, 160, mode=4, tile=64, seed=23, set_option=so)                    # image-aligned tiles + statistics
+    S.check_gemm_p3(emu_engine, DEV, 1, 10, 32, 64, 512, mode=1, tile=128, seed=24, set_option=so)
+
+
 def test_gemm_p3_operand_ranges(emu_engine):
     """activations x300 / weights x4 and x1/64: the e5m2 operands (range of fp16) and the per-layer e4m3 weight scale keep the relative error at the level of the arithmetic"""
     for xs, ws, seed in ((300.0, 4.0, 11), (0.01, 1.0 / 64, 12)):
