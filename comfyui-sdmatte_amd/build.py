@@ -46,9 +46,14 @@ def build_all(verbose=False, force=False, extra_flags=(), out=None):
             print(f"[sdmatte] {lib} is up to date")
         return lib
     # compiled in a scratch directory with -save-temps: the device assembly is a by-product there, and the F8 3x3 kernel's asynchronous (inline-asm)
-    # activation loads are checked against it before the library is accepted (tools/check_async_loads.py: no instruction may touch a load's
-    # destination registers before the hand-over six barriers later - hipcc has no notion of a result that is still in flight)
+    # activation loads are checked against it before the library is accepted (check_async_loads.py, part of this package: no instruction may touch a
+    # load's destination registers before the hand-over six barriers later - hipcc has no notion of a result that is still in flight).  The checker is
+    # imported FIRST: a missing checker fails the build before two minutes of hipcc, not after.
+    import importlib.util
     import tempfile
+    spec = importlib.util.spec_from_file_location("sdmatte_check_async_loads", os.path.join(HERE, "check_async_loads.py"))
+    check_async_loads = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(check_async_loads)
     with tempfile.TemporaryDirectory(prefix="sdmatte_build_") as tmp:
         tlib = os.path.join(tmp, "lib.so")
         cmd = [_hipcc()] + FLAGS + ["-save-temps"] + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tlib]
@@ -60,19 +65,15 @@ def build_all(verbose=False, force=False, extra_flags=(), out=None):
             raise RuntimeError("hipcc failed building libsdmatte_hip.so")
         if verbose and r.stderr.strip():
             print(r.stderr[-4000:])
-        asm = [f for f in os.listdir(tmp) if f.endswith("gfx950.s")]
+        # the device assembly behind -save-temps: whatever this ROCm names it, it is the .s file that holds the gfx950 kernels
+        asm = [f for f in os.listdir(tmp) if f.endswith(".s") and "gfx950" in f] or [f for f in os.listdir(tmp) if f.endswith(".s") and "host" not in f]
         if not asm:
             raise RuntimeError("device assembly not found behind -save-temps: cannot check the asynchronous loads of the F8 conv kernel")
-        sys.path.insert(0, os.path.join(HERE, "..", "tools"))
-        try:
-            import check_async_loads
-            with open(os.path.join(tmp, asm[0])) as fh:
-                checked, problems = check_async_loads.check(fh.read())
-        finally:
-            sys.path.pop(0)
+        with open(os.path.join(tmp, asm[0])) as fh:
+            checked, problems = check_async_loads.check(fh.read())
         if problems:
             sys.stderr.write("\n".join(problems) + "\n")
-            raise RuntimeError("F8 conv kernel: an asynchronously loaded register is touched before its hand-over (tools/check_async_loads.py)")
+            raise RuntimeError("F8 conv kernel: an asynchronously loaded register is touched before its hand-over (check_async_loads.py)")
         if verbose:
             print(f"[sdmatte] {checked} asynchronous loads of the F8 conv kernels checked")
         shutil.move(tlib, lib)

@@ -425,6 +425,72 @@ def test_e2e_full_model_1024_properties(pkg, engine_option):
     eng.close()
 
 
+@pytest.mark.slow
+@pytest.mark.parametrize("S", [640, 896])
+def test_e2e_full_model_node_sizes_640_896_vs_oracle(pkg, S):
+    """The node's two remaining inference sizes (sdmatte_nodes.py:226-229) on the FULL architecture against the oracle: their latent levels (80^2 / 112^2 and
+    down to 10^2 / 14^2) are ragged for the 256-pixel conv tiles, the 256 / 128-row GEMM tiles and the 64-key attention tiles, and the 10^2 / 14^2 levels
+    are not a multiple of 32 rows (the plane-fed GEMM's fused statistics and the attention cores' plane output then take their fallbacks)."""
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    m, w, img, tri, data, ref, out, d = _run(pkg, SDMatteConfig.full(), S, 1, seed=600 + S)
+    assert d.max().item() <= TOL
+    assert d.mean().item() <= 1e-4
+    m.engine.close()
+
+
+def test_e2e_full_model_512_is_transparent(pkg):
+    """is_transparent=True (sdmatte_nodes.py:345 -> meta_arch.py:237-238: the opacity class switches the time embedding of every ResBlock) on the full
+    architecture: both classes in one batch, each image against the oracle, and the two classes must differ."""
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    from comfyui_sdmatte_amd.weights import synthetic_state_dict
+    from comfyui_sdmatte_amd.synth import synthetic_inputs
+    from oracle import sdmatte_oracle as O
+    cfg = SDMatteConfig.full()
+    w = synthetic_state_dict(cfg, 0)
+    img, tri = synthetic_inputs(1, 512, 512, 99)
+    m = _model(cfg, w)
+    outs = {}
+    for trans in (False, True):
+        data = O.preprocess(img, tri, 512, trans)
+        ref = O.sdmatte_forward(w, cfg.as_dict(), data)
+        dcu = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data.items()}
+        out = m(dcu).cpu()
+        d = (out - ref).abs()
+        print(f"\n[full 512 is_transparent={trans}] max|d|={d.max():.3e} mean|d|={d.mean():.3e}")
+        assert d.max().item() <= TOL
+        outs[trans] = out
+    assert (outs[True] - outs[False]).abs().max().item() > 1e-6      # the class really reaches the network
+    m.engine.close()
+
+
+def test_e2e_full_model_1024_batch8_properties(pkg):
+    """B = 8 at 1024^2 on the full architecture (the VAE encoder then runs a 16-image batch; BASELINE configs[2] puts 4 per GPU, a ComfyUI batch may be larger):
+    determinism, batch-position independence, and image i of the batch == the same image alone within the parity tolerance."""
+    from comfyui_sdmatte_amd.config import SDMatteConfig
+    from comfyui_sdmatte_amd.engine import Engine
+    from comfyui_sdmatte_amd.synth import synthetic_inputs
+    from comfyui_sdmatte_amd.weights import synthetic_state_dict
+    cfg = SDMatteConfig.full()
+    eng = Engine(cfg, 0)
+    missing, _ = eng.load_state_dict(synthetic_state_dict(cfg, 0))
+    assert not missing
+    S = 1024
+    img, tri = synthetic_inputs(8, S, S, seed=88)
+    img, tri = img.cuda(), tri.cuda()
+    a = eng.apply_matte(img, tri, S, False).cpu()
+    assert a.shape == (8, S, S) and torch.isfinite(a).all() and a.min() >= 0.0 and a.max() <= 1.0
+    b = eng.apply_matte(img, tri, S, False).cpu()
+    assert torch.equal(a, b)
+    rolled = eng.apply_matte(img.roll(3, 0), tri.roll(3, 0), S, False).cpu()
+    assert torch.equal(rolled.roll(-3, 0), a)
+    for i in (0, 5):
+        single = eng.apply_matte(img[i:i + 1].contiguous(), tri[i:i + 1].contiguous(), S, False).cpu()
+        ds = (single[0] - a[i]).abs()
+        print(f"\n[full 1024 B=8 image {i} vs alone] max|d|={ds.max():.3e}")
+        assert ds.max().item() <= TOL
+    eng.close()
+
+
 def test_e2e_full_model_512_batch4_vs_oracle(pkg):
     """Full SD-2.1 architecture, B = 4 (the batch size the benchmark times: tile and kernel selection depend on it), every image against
     the oracle; the launch census shows the kernels of the timed configuration class (F8 3x3 convs, fp8-residual GEMMs, both attention
