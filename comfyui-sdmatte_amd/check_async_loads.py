@@ -112,30 +112,36 @@ def check(asm_text, verbose=False):
         if len(loads) < 12:
             problems.append(f"{key}: only {len(loads)} asynchronous loads found in the producer loop")
 
-        def walk_exit(first, R, nb):
-            """linear continuation out of the loop: fall through conditional branches, follow unconditional ones; -> verdict or None after six barriers"""
-            j, steps = first, 0
-            while j < len(K) and steps < 20000:
-                t = K[j]
-                steps += 1
-                if t.startswith("s_endpgm"):
-                    return None
-                if t.startswith("s_barrier"):
-                    nb += 1
-                r, w = _rw(t)
-                if r & R:
-                    return ("read", nb, t)
-                if w & R:
-                    return ("overwritten", nb, t)
-                if nb >= 12:
-                    return None
-                if t.startswith("s_branch"):
-                    tgt = labels.get(_branch_target(t))
-                    if tgt is None:
-                        return None
-                    j = tgt
-                    continue
-                j += 1
+        def walk_exit(first, R, nb0):
+            """every path out of the loop (depth-first over (instruction, barriers passed); both successors of a conditional branch): a path is safe once six
+            barriers have passed (the hand-over), at an s_waitcnt that drains the vector-memory counter (vmcnt(0): whatever was in flight has landed) and at
+            s_endpgm; -> the first violation found, or None"""
+            seen, stack = set(), [(first, nb0)]
+            while stack:
+                j, nb = stack.pop()
+                while j < len(K):
+                    if (j, nb) in seen:
+                        break
+                    seen.add((j, nb))
+                    t = K[j]
+                    if t.startswith("s_endpgm") or (t.startswith("s_waitcnt") and re.search(r"vmcnt\(0\)", t)):
+                        break
+                    if t.startswith("s_barrier"):
+                        nb += 1
+                        if nb >= 6:
+                            break
+                    r, w = _rw(t)
+                    if r & R:
+                        return ("read", nb, t)
+                    if w & R:
+                        return ("overwritten", nb, t)
+                    if t.startswith(("s_branch", "s_cbranch")):
+                        tgt = labels.get(_branch_target(t))
+                        if tgt is not None:
+                            stack.append((tgt, nb))
+                        if t.startswith("s_branch"):
+                            break
+                    j += 1
             return None
 
         for idx, i in loads:
@@ -167,7 +173,7 @@ def check(asm_text, verbose=False):
                 if (r | w) & R:
                     early = t
                     break
-            v2 = None if early else walk_exit(max(hi, back) + 1, R, nb_end)
+            v2 = None if early else walk_exit(hi + 1, R, nb_end)
             if v2 is not None and v2[1] < 6:
                 problems.append(f"{key[:60]}...: `{K[i][:60]}` -> {v2} (on the loop's exit path, {nb_end} barriers inside the loop)")
             elif verbose:

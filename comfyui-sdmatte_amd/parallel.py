@@ -69,8 +69,8 @@ def bucket_requests(sizes, world: int):
 def matte_stream(engine, images, trimaps, sizes, is_transparent: bool = False, micro_batch: int = 4, dst: int = 0, device=None):
     """Mixed-resolution request stream (BASELINE config #5): request i = (images[i] [H,W,3], trimaps[i] [H,W], sizes[i]).
     Every rank holds the request list; `bucket_requests` gives each rank whole same-size groups balanced by estimated FLOPs;
-    a rank runs its groups in micro-batches of equal (H, W) and the alphas travel to `dst` point to point (shapes are known
-    from the request list, so no size exchange and no padding).  Returns the list of alphas [H,W] in request order on `dst`,
+    a rank runs its groups in micro-batches of equal (H, W) and the alphas travel to `dst` point to point, one packed message per
+    peer (shapes are known from the request list, so no size exchange and no padding).  Returns the list of alphas [H,W] in request order on `dst`,
     None on the other ranks.  No collective besides these sends exists on the path."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
@@ -92,25 +92,36 @@ def matte_stream(engine, images, trimaps, sizes, is_transparent: bool = False, m
     if world == 1:
         return [mine[i] for i in range(len(sizes))]
     order = lambda r: sorted(i for v in plan[r].values() for i in v)      # the same deterministic order on both ends
-    # non-blocking point-to-point: `dst` posts every receive up front (one per remote alpha, in each sender's own order - messages between a pair of
-    # ranks match in posting order), so the seven peers of an 8-GPU node drain concurrently over their own xGMI links instead of one after the other
+    numel = lambda i: int(images[i].shape[0]) * int(images[i].shape[1])
+    # ONE message per peer: a rank's alphas travel as one flat fp32 buffer (shapes are known on both ends from the request list), and `dst` posts the
+    # receives of all peers as ONE batch (dist.batch_isend_irecv: a single grouped launch on the NCCL / RCCL backend - un-batched point-to-point
+    # operations there may serialise per peer communicator), so the seven peers of an 8-GPU node drain concurrently over their own xGMI links
     if rank != dst:
-        reqs = [dist.isend(mine[i].contiguous(), dst) for i in order(rank)]
-        for q in reqs:
-            q.wait()
+        ids = order(rank)
+        if ids:
+            flat = torch.cat([mine[i].reshape(-1).to(torch.float32) for i in ids]) if len(ids) > 1 else mine[ids[0]].reshape(-1).to(torch.float32).contiguous()
+            for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, flat, dst)]):
+                q.wait()
         return None
     out = [None] * len(sizes)
     for i, a in mine.items():
         out[i] = a
-    reqs = []
+    ops, bufs = [], {}
     for r in range(world):
-        if r == dst:
+        ids = order(r) if r != dst else []
+        if not ids:
             continue
+        bufs[r] = torch.empty(sum(numel(i) for i in ids), dtype=torch.float32, device=device)
+        ops.append(dist.P2POp(dist.irecv, bufs[r], r))
+    if ops:
+        for q in dist.batch_isend_irecv(ops):
+            q.wait()
+    for r, flat in bufs.items():
+        off = 0
         for i in order(r):
-            out[i] = torch.empty(tuple(images[i].shape[:2]), dtype=torch.float32, device=device)
-            reqs.append(dist.irecv(out[i], r))
-    for q in reqs:
-        q.wait()
+            n = numel(i)
+            out[i] = flat[off:off + n].view(int(images[i].shape[0]), int(images[i].shape[1]))
+            off += n
     return out
 
 

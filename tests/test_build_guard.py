@@ -81,3 +81,18 @@ def test_guard_finds_the_kernels_by_pattern():
     assert G.kernel_symbols(_asm(lambda k: [])) == list(KERNELS)
     other = KERNELS[0].replace("ILi9ELi1ELi8E", "ILi1ELi1ELi8E")                       # a 1x1 instantiation is not an F8 3x3 kernel
     assert G.kernel_symbols(other + ":\n") == []
+
+
+def test_guard_exit_walk_takes_both_branch_successors_and_stops_at_a_drained_counter():
+    # the copy sits on the TAKEN side of a conditional branch behind the loop exit
+    taken = ["\ts_cbranch_vccnz .LBB0_9", "\ts_branch .LBB0_1", ".LBB0_9:", "\tv_mov_b32_e32 v160, v31"]
+    checked, problems = G.check(_asm(lambda k: [], exit_extra=taken))
+    assert problems and any("exit path" in p for p in problems), problems
+    # the same copy behind s_waitcnt vmcnt(0): everything in flight has landed - not a hazard
+    drained = ["\ts_waitcnt vmcnt(0)", "\tv_mov_b32_e32 v160, v31"]
+    checked, problems = G.check(_asm(lambda k: [], exit_extra=drained))
+    assert not problems, problems
+    # a counted wait that leaves loads in flight does not clear it
+    counted = ["\ts_waitcnt vmcnt(2)", "\tv_mov_b32_e32 v160, v31"]
+    checked, problems = G.check(_asm(lambda k: [], exit_extra=counted))
+    assert problems

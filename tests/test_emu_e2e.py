@@ -274,10 +274,14 @@ def test_emu_fused_groupnorm_path(pkg, engine_option):
 
 
 def _stream_requests():
+    """seven requests, two inference sizes, four image shapes: with two ranks the remote rank returns at least three alphas of unequal shapes in its one
+    packed message"""
     from comfyui_sdmatte_amd.synth import synthetic_inputs
     i0, t0 = synthetic_inputs(2, 64, 64, seed=21)
-    i1, t1 = synthetic_inputs(1, 50, 70, seed=22)
-    return [(i0[0], t0[0], 64), (i1[0], t1[0], 128), (i0[1], t0[1], 64)]
+    i1, t1 = synthetic_inputs(2, 50, 70, seed=22)
+    i2, t2 = synthetic_inputs(2, 40, 56, seed=23)
+    i3, t3 = synthetic_inputs(1, 72, 48, seed=24)
+    return [(i0[0], t0[0], 64), (i1[0], t1[0], 128), (i0[1], t0[1], 64), (i2[0], t2[0], 64), (i1[1], t1[1], 128), (i3[0], t3[0], 64), (i2[1], t2[1], 64)]
 
 
 def _dp_worker(rank, world, port, q):
@@ -351,6 +355,9 @@ def test_data_parallel_two_ranks_gloo(pkg):
     assert sorted(i for p in plan for v in p.values() for i in v) == list(range(24))
     loads = [sum(parallel.FLOPS_PER_IMAGE[s] * len(v) for s, v in p.items()) for p in plan]
     assert max(loads) / min(loads) < 1.35
+    # the stream above really exercised a packed multi-alpha message: the remote rank owned >= 3 requests of unequal shapes
+    remote = sorted(i for v in parallel.bucket_requests([r[2] for r in reqs], 2)[1].values() for i in v)
+    assert len(remote) >= 3 and len({tuple(reqs[i][0].shape[:2]) for i in remote}) >= 2
 
 
 def test_emu_other_prompt_types_match_oracle(pkg):
