@@ -85,6 +85,11 @@ def main():
     ap.add_argument("--dump-profile", type=str, default=None, help="write the per-launch profile CSV here")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="engine kernel-selection option for A/B runs (sdm_set_option; see sdm_option_name / sdm_option_help)")
+    ap.add_argument("--stream", action="store_true",
+                    help="BASELINE configs[4] instead of configs[1]: a step = one mixed-resolution request stream (inference sizes 512 / 768 / 1024 in turn, "
+                         "--stream-requests per GPU, matted_rgba output) through parallel.matte_stream - FLOP-balanced buckets per rank, one packed "
+                         "message per peer back to rank 0; same JSON line, metric and workload named accordingly")
+    ap.add_argument("--stream-requests", type=int, default=6, help="requests per GPU and step of the --stream leg")
     ap.add_argument("--dense-attention", action="store_true",
                     help="walk every key tile in the trimap-biased self-attention instead of skipping the tiles whose bias underflows the softmax")
     args = ap.parse_args()
@@ -174,12 +179,28 @@ def main():
         return step
 
     step = make_step(eng)
+    stream_sizes = None
+    if args.stream:
+        # configs[4]: every rank holds the whole request list (resident in its HBM), runs the buckets `bucket_requests` gives it, rank 0 receives
+        from comfyui_sdmatte_amd.parallel import matte_stream
+        cyc = (64, 128, 64) if args.emu else (512, 768, 1024)
+        stream_sizes = [cyc[i % 3] for i in range(args.stream_requests * world)]
+        reqs = []
+        for i, s_ in enumerate(stream_sizes):
+            im, tr = synthetic_inputs(1, s_, s_, seed=4321 + i)
+            reqs.append((im[0].to(dev), tr[0].to(dev)))
+
+        def step():      # noqa: F811 - the stream leg replaces the uniform-batch step
+            return matte_stream(eng, [r[0] for r in reqs], [r[1] for r in reqs], stream_sizes, micro_batch=B, dst=0, device=dev, output_mode="matted_rgba")
     for _ in range(args.warmup):
         step()
     elapsed = timed_steps(step, args.steps, world, dev)
     per_rank_s = list(PER_RANK_S)
     ms_per_step = elapsed * 1e3 / max(args.steps, 1)
     value = world * B * args.steps / elapsed
+    if args.stream:
+        value = len(stream_sizes) * args.steps / elapsed
+        args.timed_only = True      # (the companion legs below describe the uniform 1024^2 batch)
 
     if rank == 0:
         # ---- B = 1 latency (BASELINE configs[1] is quoted one image per call) ----
@@ -309,7 +330,7 @@ def main():
                             + (" (x_hi*w_hi on fp16 + the two residual terms on fp8 K=64 MFMAs at twice the rate)" if f8_res else ""),
                     "mfma_executed_frac": round(mfma_per_product * ach / MFMA_F16_PEAK_TFLOPS, 4), "mfma_busy_frac_pmc": mfma_busy,
                     "pmc_source": "profiles/pmc_traffic.json, profiles/pmc_sq.json (rocprofv3 --pmc passes of `bench.py --timed-only`, reduced by tools/pmc_*.py)",
-                    "pmc_stale": pmc_stale}
+                    "pmc_stale": pmc_stale, "pmc_measured_in_this_run": False}
             if pmc_stale:      # counters of another build say nothing about this one
                 roof["traffic"] = None
                 roof["mfma_busy_frac_pmc"] = None
@@ -372,12 +393,19 @@ def main():
         if eng_o is not None:
             eng_o.close()
         result = {
-            "metric": "alpha mattes/sec at 1024x1024", "value": round(value, 3), "unit": "images/s", "n_gpus": world,
-            "ranks_seen": len(per_rank_s), "per_rank_images_per_s": [round(B * args.steps / max(x, 1e-9), 3) for x in per_rank_s],
+            "metric": "alpha mattes/sec, mixed-resolution stream (512/768/1024)" if args.stream else "alpha mattes/sec at 1024x1024",
+            "value": round(value, 3), "unit": "images/s", "n_gpus": world,
+            "ranks_seen": len(per_rank_s),
+            "per_rank_images_per_s": None if args.stream else [round(B * args.steps / max(x, 1e-9), 3) for x in per_rank_s],
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16x3" if precision == "fp16x3" else "f16", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: {S}x{S} image+trimap -> alpha (alpha_only), SD-2.1/SDMatte architecture, "
-                                   f"synthetic weights, {B} images per GPU per step",
+            "config": {"workload": (f"BASELINE configs[4]: mixed-resolution request stream, inference sizes {sorted(set(stream_sizes))} in turn, "
+                                    f"{args.stream_requests} requests per GPU per step ({len(stream_sizes)} in all), FLOP-balanced buckets per rank, micro-batches "
+                                    f"of <= {B} equal-size images, matted_rgba output (node body incl. composition on the GPU), one packed message per peer to rank 0; "
+                                    "SD-2.1/SDMatte architecture, synthetic weights; kernel_breakdown_ms / roofline below describe ONE uniform 1024^2 batch, not the stream")
+                       if args.stream else
+                       f"BASELINE configs[1]: {S}x{S} image+trimap -> alpha (alpha_only), SD-2.1/SDMatte architecture, "
+                       f"synthetic weights, {B} images per GPU per step",
                        "inference_size": S, "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
                        "precision": precision,
                        "arithmetic": (("split MFMA operands x = hi + lo, fp32 accumulate, fp32 activations: x_hi*w_hi on fp16; the residual "
@@ -399,7 +427,8 @@ def main():
             # dense-equivalent algorithmic rate (28.89 TFLOP per 1024^2 image); the self-attention skips the key tiles
             # whose bias underflows the softmax, so the executed attention work depends on the trimap (kernel_breakdown_ms has
             # executed rates per kernel)
-            "tflops_per_gpu": round(FLOPS_PER_IMAGE.get(S, 0) * B / (ms_per_step * 1e-3) / 1e12, 1),
+            "tflops_per_gpu": round((sum(FLOPS_PER_IMAGE.get(x, 0) for x in stream_sizes) / world if args.stream else FLOPS_PER_IMAGE.get(S, 0) * B)
+                                    / (ms_per_step * 1e-3) / 1e12, 1),
             "tflops_per_gpu_basis": "dense-equivalent algorithmic FLOPs of the reference graph (not executed FLOPs)",
             "weight_load_s": round(load_s, 1),
             "roofline": roof, "cpu_baseline": cpu, "kernel_breakdown_ms": breakdown,

@@ -66,12 +66,18 @@ def bucket_requests(sizes, world: int):
     return plan
 
 
-def matte_stream(engine, images, trimaps, sizes, is_transparent: bool = False, micro_batch: int = 4, dst: int = 0, device=None):
+def matte_stream(engine, images, trimaps, sizes, is_transparent: bool = False, micro_batch: int = 4, dst: int = 0, device=None,
+                 output_mode=None, mask_refine: bool = False, trimap_constraint: float = 0.8):
     """Mixed-resolution request stream (BASELINE config #5): request i = (images[i] [H,W,3], trimaps[i] [H,W], sizes[i]).
     Every rank holds the request list; `bucket_requests` gives each rank whole same-size groups balanced by estimated FLOPs;
     a rank runs its groups in micro-batches of equal (H, W) and the alphas travel to `dst` point to point, one packed message per
     peer (shapes are known from the request list, so no size exchange and no padding).  Returns the list of alphas [H,W] in request order on `dst`,
-    None on the other ranks.  No collective besides these sends exists on the path."""
+    None on the other ranks.  With `output_mode` "matted_rgba" / "matted_rgb" (BASELINE config #5 asks for matted_rgba) every request goes through the
+    whole node body (`apply_matte_node`: mask_refine and the output composition on the GPU too) and what travels and is returned is the composed image
+    [H,W,4|3] (its last channel is the alpha for matted_rgba).  No collective besides these sends exists on the path."""
+    chans = None
+    if output_mode is not None and output_mode != "alpha_only":
+        chans = {"matted_rgba": 4, "matted_rgb": 3}[output_mode]
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     device = device if device is not None else torch.device("cuda", engine.device)
@@ -86,13 +92,17 @@ def matte_stream(engine, images, trimaps, sizes, is_transparent: bool = False, m
                 chunk = ids[k:k + micro_batch]
                 img = torch.stack([images[i] for i in chunk]).to(device)
                 tri = torch.stack([trimaps[i] for i in chunk]).to(device)
-                a = engine.apply_matte(img, tri, S, is_transparent)
+                if chans is None:
+                    a = engine.apply_matte(img, tri, S, is_transparent)
+                else:
+                    a = engine.apply_matte_node(img, tri, S, is_transparent, output_mode, mask_refine, trimap_constraint)[1]
                 for j, i in enumerate(chunk):
                     mine[i] = a[j]
     if world == 1:
         return [mine[i] for i in range(len(sizes))]
     order = lambda r: sorted(i for v in plan[r].values() for i in v)      # the same deterministic order on both ends
-    numel = lambda i: int(images[i].shape[0]) * int(images[i].shape[1])
+    shape = lambda i: (int(images[i].shape[0]), int(images[i].shape[1])) + (() if chans is None else (chans,))
+    numel = lambda i: int(images[i].shape[0]) * int(images[i].shape[1]) * (chans or 1)
     # ONE message per peer: a rank's alphas travel as one flat fp32 buffer (shapes are known on both ends from the request list), and `dst` posts the
     # receives of all peers as ONE batch (dist.batch_isend_irecv: a single grouped launch on the NCCL / RCCL backend - un-batched point-to-point
     # operations there may serialise per peer communicator), so the seven peers of an 8-GPU node drain concurrently over their own xGMI links
@@ -120,7 +130,7 @@ def matte_stream(engine, images, trimaps, sizes, is_transparent: bool = False, m
         off = 0
         for i in order(r):
             n = numel(i)
-            out[i] = flat[off:off + n].view(int(images[i].shape[0]), int(images[i].shape[1]))
+            out[i] = flat[off:off + n].view(*shape(i))
             off += n
     return out
 

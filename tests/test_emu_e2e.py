@@ -460,6 +460,14 @@ def test_bench_two_ranks_control_flow(pkg):
     assert d["config"]["global_batch"] == 2 and d["config"]["parallelism"] == "dp2"
     assert d["ranks_seen"] == 2 and len(d["per_rank_images_per_s"]) == 2      # the collective really spanned both ranks
     assert d["cpu_baseline"] is None
+    # the configs[4] leg (--stream): FLOP-balanced buckets per rank, matted_rgba through the node body, one packed message per peer
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--emu", "--gpus", "2", "--size", "64", "--batch", "2", "--steps", "1", "--warmup", "0",
+                        "--stream", "--stream-requests", "3"], capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "stream" in d["metric"] and "configs[4]" in d["config"]["workload"] and d["ranks_seen"] == 2
 
 
 def test_checkpoint_variants_load_to_identical_engines(pkg, tmp_path):
