@@ -45,6 +45,7 @@ struct AttnParams {
   // short blocks.  The ranges are ranges of KEY TILES, so a walk along the active-tile list and the dense walk split at the same keys.
   int nsplit; long part_stride; float* part_ml;
   int batch, heads, nq_blocks, q_chunks;   // XCD-aware 1-D grid (attn_d64): see attn_block_coords
+  int pp_flags; // attn_d64_pp_kernel: bit 0 = s_setprio 1 for the younger wave half
   int ablate;   // bench only (sdm_bench_attn): 1 skip softmax VALU, 2 skip PV MFMAs, 4 skip QK^T MFMAs, 8 skip K/V global prefetch; 0 in the engine
 };
 
@@ -753,6 +754,283 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_pipe_kernel(AttnParams p)
     iter(t, sa, sb);
     if (t + 1 < nwalk) iter(t + 1, sb, sa);
   }
+
+  // epilogue (fp32 output): per-wave staging [32 q][64 d] at pitch 272 B -> coalesced 16-byte row stores
+  constexpr int PS = 272;
+  unsigned char* stf = smem + wave * (32 * PS);
+  const float inv = p.nsplit > 1 ? 1.0f : 1.0f / ls[0];                 // key split: unnormalised partial sums (attn_combine_kernel divides)
+  float* obase = (float*)p.o + (p.nsplit > 1 ? (size_t)sp * p.part_stride : (size_t)0) + (size_t)b * p.o_bs;
+  if (p.nsplit > 1 && hi == 0 && q0 + l31 < p.Lq) {
+    float* ml = p.part_ml + ((((size_t)sp * p.batch + b) * p.heads + head) * p.Lq + q0 + l31) * 2;
+    ml[0] = m_i; ml[1] = ls[0];
+  }
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) h[e] = o[dt][4 * g + e] * inv;
+      *(f32x4*)(stf + l31 * PS + (dt * 32 + 8 * g + 4 * hi) * 4) = h;
+    }
+  SDM_WAVE_SYNC();
+  if (p.o_p3 && p.nsplit <= 1) { attn_store_p3(p, stf, PS, b, q0, head, lane); return; }
+#pragma unroll
+  for (int pass = 0; pass < 8; ++pass) {
+    const int row = pass * 4 + (lane >> 4), part = lane & 15;
+    const int qg = q0 + row;
+    if (qg < p.Lq)
+      *(f32x4*)(obase + (size_t)qg * p.ldo + head * 64 + part * 4) = *(const f32x4*)(stf + row * PS + part * 16);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same arithmetic as a PING-PONG of the block's two wave halves (round 6; engine option attn_pp, default): waves 0-3 ("A", one per SIMD) and waves
+// 4-7 ("B", their SIMD partners) run the SAME instruction sequence - [softmax of tile t] barrier [Q.K^T of tile t+1, P.V of tile t] barrier - with B one
+// barrier interval behind A, so that at any time every SIMD holds one wave in its matrix segment (24 back-to-back MFMAs = 896 pipe cycles, LDS fragment
+// reads, the staging of tile t+2) and one wave in its softmax segment (max / sub / 33 v_exp_f32 / pack: ~130 VALU issues).  In attn_d64_pipe_kernel both
+// waves of a SIMD are in the same phase (one barrier per tile): the SQ counters put the matrix pipe at 0.51 busy with the VALU equally half idle - the two
+// pipes ran in SUM, not in MAX (profiles/r06_attn_sq_counters.txt).  MI355X_MICROARCH.md "Two waves per SIMD": the matrix pipe and VALU issue of a SIMD
+// are shared by its two waves; complementary segments (matrix beside VALU / memory) are what nets.
+//   phase n:      0        1            2               3               4         ...
+//   A (0-3):    QK(0)   softmax(0)   QK(1) PV(0)     softmax(1)      QK(2) PV(1)
+//   B (4-7):     -       QK(0)       softmax(0)      QK(1) PV(0)     softmax(1)
+// Three whole tile buffers as in the 8-wave pipeline (tile t in slot t % 3).  A's matrix segment of tile t (phase 2t+2) and B's (2t+3) read K(t+1) and
+// V(t); the slot of tile t-1 was last read by B in phase 2t+1 and tile t+2 is first read by A in phase 2t+4, so BOTH halves write their share of tile t+2
+// at the head of their own matrix segment of tile t (phases 2t+2 / 2t+3) and request tile t+3 behind it.  Staging and prefetch are unconditional (indices
+// clamped to the last tile of the walk: a rewritten slot nobody reads any more), and Q.K^T of the tile behind the last one runs on stale bytes whose logits
+// nobody consumes - the matrix segment is ONE basic block.  Same operations in the same order per query row as attn_d64_pipe_kernel<8>: bit-identical.
+// pp_flags bit 0: s_setprio 1 for waves 4-7 (the second-dispatched half loses every arbitration at equal priority; item 4 of the guide's section)
+// ------------------------------------------------------------------------------------------------
+#define ATTN64PP_SMEM (3 * ATTN64P_BUF)
+__global__ void __launch_bounds__(512, 2) attn_d64_pp_kernel(AttnParams p) {
+  constexpr int NTH = 512;
+  SDM_DYN_SMEM(smem);
+  constexpr int PK = ATTN64_PK, PV = ATTN64_PV, BUF = ATTN64P_BUF;
+  constexpr int KLO = 64 * PK, VOFF = 2 * 64 * PK, BOFF = VOFF + 64 * PV;
+  const int tid = threadIdx.x, lane = tid & 63, wave = SDM_UNIFORM_I(tid >> 6);
+  const int grp = wave >> 2;
+  const int hi = lane >> 5, l31 = lane & 31;
+  int b, head, qblk;
+  if (!attn_block_coords(p, blockIdx.x, b, head, qblk)) return;
+  const int q0 = qblk * 256 + wave * 32;
+
+  f16x8 qf[4];
+  i32x8 q8p[2];
+  {
+    int qrow = q0 + l31;
+    if (qrow > p.Lq - 1) qrow = p.Lq - 1;
+    const half_t* qp = p.q + (size_t)b * p.q_bs + (size_t)qrow * p.ldq + head * 64 + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const f16x8*)(qp + ks * 16);
+    const half_t* qb = p.q + (size_t)b * p.q_bs + p.q_lo + (size_t)qrow * p.ldq + head * 64 + hi * 16;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const i32x4 r0 = *(const i32x4*)(qb + m * 32), r1 = *(const i32x4*)(qb + m * 32 + 8);
+      q8p[m] = i32x8{r0[1], r0[0], r0[3], r0[2], r1[1], r1[0], r1[3], r1[2]};
+    }
+  }
+  f32x16 o[2], ls;
+  float m_i = SDM_NEG_BIG;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { ls[r] = 0.0f; o[0][r] = 0.0f; o[1][r] = 0.0f; }
+  f16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (half_t)1.0f;
+
+  const half_t* kbase = p.k + (size_t)b * p.k_bs + head * 64;
+  const half_t* vbase = p.vt + (size_t)b * p.vt_bs + (size_t)head * p.vt_hs;
+  const float* bbase = p.bias ? p.bias + (size_t)b * p.bias_bs : nullptr;
+  const float* bsrc = bbase ? bbase : (const float*)(p.k + (size_t)b * p.k_bs);
+  const int ntiles = (p.Lk + 63) / 64;
+  const int* tl = p.tiles ? p.tiles + (size_t)b * p.tiles_bs : nullptr;
+  const int sp = p.nsplit > 1 ? (int)blockIdx.y : 0;
+  int i0, nwalk;
+  attn_split_range(p, tl, ntiles, tl ? tl[0] : ntiles, sp, i0, nwalk);
+  if (nwalk <= 0) { attn_write_empty_part(p, sp, b, head, q0, lane); return; }      // (key split only; block-uniform, before the first barrier)
+  // tile index of walk position i, clamped (see the header) and BRANCH-FREE: the list entry is always loaded (a dense walk reads a word of the K tensor -
+  // at least ntiles words long - and discards it), so that a matrix segment stays one basic block
+  const int* tlp = tl ? tl + 1 + i0 : (const int*)(p.k + (size_t)b * p.k_bs);
+  const int is_list = tl ? 1 : 0;
+  auto tile_at = [&](int i) { if (i > nwalk - 1) i = nwalk - 1; return (i0 + i) + is_list * (tlp[i] - (i0 + i)); };      // (arithmetic, not a select: a select lets the load sink back into a branch)
+
+  // one raw tile between global memory and LDS: one 16-byte vector of K_hi, of the K pair plane and of V^T per thread, one bias value per lane
+  f16x8 rk, rkl, rv;
+  float rb = 0.0f;
+  bool rin = true;
+  const int srow = tid >> 3, spart = tid & 7;
+  auto prefetch = [&](int t) {
+    const int k0 = t * 64;
+    int kr = k0 + srow;
+    if (kr > p.Lk - 1) kr = p.Lk - 1;
+    rk = *(const f16x8*)(kbase + (size_t)kr * p.ldk + spart * 8);
+    rv = *(const f16x8*)(vbase + (size_t)srow * p.ldvt + k0 + spart * 8);
+    rkl = *(const f16x8*)(kbase + p.k_lo + (size_t)kr * p.ldk + spart * 8);
+    int kb = k0 + (tid & 63);
+    rin = kb < p.Lk;
+    if (!rin) kb = p.Lk - 1;
+    rb = bsrc[kb];
+  };
+  auto stage = [&](int slot) {
+    unsigned char* kb_ = smem + slot * BUF;
+    *(f16x8*)(kb_ + srow * PK + spart * 16) = rk;
+    f16x4 lo, hi4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { lo[e] = rv[e]; hi4[e] = rv[4 + e]; }
+    *(f16x4*)(kb_ + VOFF + srow * PV + spart * 16) = lo;
+    *(f16x4*)(kb_ + VOFF + srow * PV + spart * 16 + 8) = hi4;
+    *(f16x8*)(kb_ + KLO + srow * PK + spart * 16) = rkl;
+    ((float*)(kb_ + BOFF))[lane] = rin ? (bbase ? rb : 0.0f) : SDM_NEG_BIG;      // every wave writes the same 64 values: no exec-masked region in the segment
+  };
+  // ---- the matrix segment, hand-pipelined: fragment reads are issued one group (6 MFMAs = 192-256 pipe cycles) ahead of the MFMAs that consume them, the
+  //      groups are fenced so that the scheduler cannot sink a read to its use (it did: ds_read / s_waitcnt lgkmcnt(0) / v_mfma triples, one exposed LDS round
+  //      trip per MFMA).  K fragments of both 32-key halves (16 b128), then V^T fragments per half (8 b64 pairs each) in the registers the K fragments leave.
+  struct KFrag { f16x8 h[4]; i32x8 f8[2]; };
+  auto load_bias = [&](int slot, f32x16 (&s)[2]) {
+    const float* Bs = (const float*)(smem + slot * BUF + BOFF);
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 b4 = *(const f32x4*)(Bs + kt * 32 + 8 * g + 4 * hi);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[kt][4 * g + e] = b4[e];
+      }
+  };
+  auto load_k = [&](int slot, int kt, KFrag& f) {
+    const unsigned char* Ks = smem + slot * BUF;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) f.h[ks] = *(const f16x8*)(Ks + (kt * 32 + l31) * PK + ks * 32 + hi * 16);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const unsigned char* kp = Ks + KLO + (kt * 32 + l31) * PK + m * 64 + hi * 32;
+      const i32x4 a0 = *(const i32x4*)kp, a1 = *(const i32x4*)(kp + 16);
+      f.f8[m] = i32x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    }
+  };
+  auto mma_k = [&](const KFrag& f, f32x16& sk) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) sk = SDM_MFMA_32x32x16_F16(f.h[ks], qf[ks], sk);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) sk = SDM_MFMA_32x32x64_BF8_BF8(f.f8[m], q8p[m], sk, 127 - 11, 127);
+  };
+  struct VFrag { f16x8 v[2][2]; };      // [u][dt]
+  auto load_v = [&](int slot, int kt, VFrag& f) {
+    const unsigned char* Vs = smem + slot * BUF + VOFF;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const unsigned char* vp = Vs + (dt * 32 + l31) * PV + (kt * 32 + 16 * u + 4 * hi) * 2;
+        const f16x4 v0 = *(const f16x4*)vp, v1 = *(const f16x4*)(vp + 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { f.v[u][dt][e] = v0[e]; f.v[u][dt][4 + e] = v1[e]; }
+      }
+  };
+  auto mma_v = [&](const VFrag& f, const f16x8 (&pk)[2]) {      // O^T[d][q] += V^T[d][key] . P^T[key][q], denominators on the same probabilities
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      ls = SDM_MFMA_32x32x16_F16(ones, pk[u], ls);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) o[dt] = SDM_MFMA_32x32x16_F16(f.v[u][dt], pk[u], o[dt]);
+    }
+  };
+  // logits of one key tile alone (prologue)
+  auto qk = [&](int slot, f32x16 (&s)[2]) {
+    KFrag k0, k1;
+    load_bias(slot, s);
+    load_k(slot, 0, k0);
+    load_k(slot, 1, k1);
+    mma_k(k0, s[0]);
+    mma_k(k1, s[1]);
+  };
+  // softmax of one tile: logits -> fp16 probabilities in B-operand layout; running maximum, rescale of O^T / the denominators when it moved.  Everything is
+  // pinned inside the segment (the probabilities are only consumed by the NEXT segment's MFMAs: left alone, the sub / exp / pack stream sinks behind the barrier)
+  auto softmax = [&](f32x16 (&s)[2], f16x8 (&pf)[2][2]) {
+    float mx = SDM_NEG_BIG;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s[kt][r]), s[kt][r + 1]);
+    {      // the other key half of this query sits in lane ^ 32: one v_permlane32_swap instead of a trip through the LDS crossbar
+      unsigned int xa = __builtin_bit_cast(unsigned int, mx), xb = xa;
+      sdm_permlane32_swap(xa, xb);
+      mx = fmaxf(__builtin_bit_cast(float, xa), __builtin_bit_cast(float, xb));
+    }
+    const float mnew = fmaxf(m_i, mx);
+    const float alpha = sdm_exp2(m_i - mnew);
+    m_i = mnew;
+    if (__any(alpha != 1.0f)) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ls[r] *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kt][r] = sdm_exp2(s[kt][r] - mnew);
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[kt][u][j] = (half_t)s[kt][8 * u + j];
+    SDM_PIN_HERE_V4(pf[0][0], pf[0][1], pf[1][0], pf[1][1]);
+  };
+  auto lds_barrier = [&]() { SDM_SCHED_FENCE(); SDM_WAIT_LGKMCNT0(); SDM_RAW_BARRIER(); SDM_SCHED_FENCE(); };
+
+  // ---- prologue: tiles 0 and 1 in LDS, tile 2 on its way; A computes the logits of tile 0 while B waits one interval ----
+  prefetch(tile_at(0));
+  stage(0);
+  prefetch(tile_at(1));
+  stage(1);
+  prefetch(tile_at(2));
+  lds_barrier();
+  if (grp) {
+    if (p.pp_flags & 1) SDM_SETPRIO(1);
+    lds_barrier();
+  }
+  f32x16 s[2];
+  f16x8 pf[2][2];
+  qk(0, s);
+  lds_barrier();
+  int bt = 0;
+  int tnext = tile_at(3);                                              // index of the tile requested in the coming matrix segment (list walks: fetched one segment ahead)
+  for (int t = 0; t < nwalk; ++t) {
+    // ---- softmax segment of tile t; the V^T fragments of the same tile (staged two tiles ago) are read at its end, so that the matrix segment opens with
+    //      MFMAs instead of an LDS round trip ----
+    const int tcur = tnext;
+    tnext = tile_at(t + 4);                                            // lands under this segment and the next one's first half
+    softmax(s, pf);
+    VFrag v0, v1;
+    load_v(bt, 0, v0);
+    load_v(bt, 1, v1);
+    lds_barrier();
+    // ---- matrix segment: P.V of tile t (operands in registers) while the K fragments / biases of tile t+1 arrive, tile t+2 is written to the slot tile t-1
+    //      has left and tile t+3 is requested; then Q.K^T of tile t+1.  One scheduling region per half, MFMAs interleaved with the rest ----
+    const int b1 = bt == 2 ? 0 : bt + 1, b2 = b1 == 2 ? 0 : b1 + 1;
+    KFrag k0, k1;
+    mma_v(v0, pf[0]);
+    mma_v(v1, pf[1]);
+    stage(b2);
+    load_bias(b1, s);
+    load_k(b1, 0, k0);
+    load_k(b1, 1, k1);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { SDM_SCHED_GROUP(0x008, 1, 0); SDM_SCHED_GROUP(0x100, 2, 0); SDM_SCHED_GROUP(0x202, 1, 0); }
+    SDM_SCHED_FENCE();
+    prefetch(tcur);
+    mma_k(k0, s[0]);
+    mma_k(k1, s[1]);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { SDM_SCHED_GROUP(0x008, 1, 1); SDM_SCHED_GROUP(0x022, 2, 1); }
+    lds_barrier();
+    bt = b1;
+  }
+  if (!grp) lds_barrier();                                             // B's last matrix segment still reads V^T: the epilogue reuses the buffers
 
   // epilogue (fp32 output): per-wave staging [32 q][64 d] at pitch 272 B -> coalesced 16-byte row stores
   constexpr int PS = 272;

@@ -40,6 +40,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define SDM_SCHED_FENCE() ((void)0)
 #define SDM_PIN_STORE_DATA(v) ((void)(v))
 #define SDM_SCHED_GROUP(mask, n, id) ((void)0)
+#define SDM_SETPRIO(n) ((void)0)
 static inline float sdm_exp2(float x) { return exp2f(x); }
 static inline float sdm_rcp(float x) { return 1.0f / x; }
 #define SDM_MED3(x, lo, hi) fminf(fmaxf((x), (lo)), (hi))
@@ -79,6 +80,8 @@ static inline float sdm_rcp(float x) { return 1.0f / x; }
 #define SDM_PIN_STORE_DATA(v) asm volatile("s_nop 3" ::"v"(v))
 // compile-time interleave request: the next `n` instructions of class `mask` (0x8 MFMA, 0x2 VALU, 0x400 TRANS, 0x100 DS read)
 #define SDM_SCHED_GROUP(mask, n, id) __builtin_amdgcn_sched_group_barrier((mask), (n), (id))
+// wave priority for the SIMD's issue arbitration (0 default .. 3): static, set once in front of a main loop
+#define SDM_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 __device__ __forceinline__ float sdm_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float sdm_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 #define SDM_MED3(x, lo, hi) __builtin_amdgcn_fmed3f((x), (lo), (hi))      // clamp in one instruction (lo <= hi)

@@ -248,6 +248,18 @@ def test_attention_d64_split_precision(emu_engine, engine_option):
             engine_option(emu_engine, "attn_pipe", 1)
             rp = emu_engine.op_attention_split(q, kk, vv, 2, bias=bb)
             assert torch.equal(rp, r8), (lk, bb is not None, (rp - r8).abs().max().item())
+            # the ping-pong of the block's two wave halves (attn_d64_pp_kernel: what runs by default when no wave count is forced; the halves execute the
+            # same sequence one barrier interval apart, staging and prefetch unconditional with clamped tile indices): same arithmetic again
+            engine_option(emu_engine, "attn_nw", 0)
+            engine_option(emu_engine, "attn_pp", 1)
+            emu_engine.lib.kernel_counts(reset=True)
+            rpp = emu_engine.op_attention_split(q, kk, vv, 2, bias=bb)
+            assert emu_engine.lib.kernel_counts().get("attn_d64_pp", 0) == 1
+            assert torch.equal(rpp, r8), (lk, bb is not None, (rpp - r8).abs().max().item())
+            engine_option(emu_engine, "attn_pp", 0)
+            emu_engine.lib.kernel_counts(reset=True)
+            emu_engine.op_attention_split(q, kk, vv, 2, bias=bb)
+            assert emu_engine.lib.kernel_counts().get("attn_d64_pp", 0) == 0
     engine_option(emu_engine, "attn_nw", 0)
 
 

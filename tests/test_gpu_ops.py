@@ -280,14 +280,15 @@ def test_gemm_fp8_residual_terms(eng, M_hw, cin, cout, geglu, res):
     print(f"[F8 gemm {cin}->{cout}] max|d|={err:.2e}")
 
 
-@pytest.mark.parametrize("nw,kern", [(8, "attn_d64_pipe<8>"), (4, "attn_d64_pipe<4>")])
+@pytest.mark.parametrize("nw,kern", [(0, "attn_d64_pp"), (8, "attn_d64_pipe<8>"), (4, "attn_d64_pipe<4>")])
 def test_attention_pipeline_kernels_with_trimap_bias_and_skipped_tiles(eng, engine_option, golden_dir, nw, kern):
-    """The kernels the default precision SHIPS for the d=64 attention cores - the two-tile software pipelines (8-wave: the level-0
-    launches of the timed B=4 step; 4-wave: every other launch) - against un-rounded fp64 attention with what the engine feeds them: a
+    """The kernels the default precision SHIPS for the d=64 attention cores - the ping-pong of the block's wave halves (round 6: every launch when no
+    wave count is forced) and the two-tile software pipelines behind it (options attn_pp = 0 / attn_nw) - against un-rounded fp64 attention with what the engine feeds them: a
     trimap-style key bias whose -10000 / -5000 tiles are skipped (tile lists), ragged query / key counts, >= 5 key tiles; and the
     reference's own scores fixture G3 through the same kernel.  sdm_kernel_counts proves which variant ran."""
     import numpy as np
     engine_option(eng, "attn_nw", nw)
+    engine_option(eng, "attn_pp", 1 if nw == 0 else 0)
     eng.lib.kernel_counts(reset=True)
     e_blocks = S.check_attention(eng, DEV, 2, 5, 700, 333, 64, use_bias=True, split=True, blocks=True, seed=11, atol=1e-3)       # 6 key tiles, ragged
     e_rand = S.check_attention(eng, DEV, 1, 2, 2100, 1500, 64, use_bias=True, split=True, seed=12, atol=1e-3)                    # 24 key tiles, random -10000 keys

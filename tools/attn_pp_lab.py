@@ -1,0 +1,70 @@
+"""Ping-pong d=64 attention kernel (attn_d64_pp_kernel, option attn_pp) against the two-tile pipelines it replaces: bit-identity on the engine's launch
+shapes (dense, trimap-like bias, masked tiles; repeated to expose races), then per-shape timings of the three variants (torch events around
+op_attention_split: includes the V transpose and the operand split on both sides equally), then the whole step.  usage: python tools/attn_pp_lab.py [--no-step]"""
+import json
+import os
+import subprocess
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package
+load_package()
+import torch
+from comfyui_sdmatte_amd.engine import Engine
+from comfyui_sdmatte_amd.config import SDMatteConfig
+eng = Engine(SDMatteConfig.tiny(), 0, precision="fp16x3")
+g = torch.Generator(device="cuda").manual_seed(3)
+ok = True
+for (B, h, Lq, Lk) in ((2, 5, 16384, 16384), (1, 10, 1000, 4096 + 37), (2, 20, 256, 16384), (1, 10, 4096, 4096)):
+    q = torch.randn(B, Lq, h * 64, generator=g, device="cuda") * 1.5
+    k = torch.randn(B, Lk, h * 64, generator=g, device="cuda") * 1.5
+    v = torch.randn(B, Lk, h * 64, generator=g, device="cuda")
+    bias = torch.where(torch.rand(B, Lk, generator=g, device="cuda") < 0.4, torch.tensor(-10000.0, device="cuda"), torch.tensor(0.0, device="cuda"))
+    blocks = bias.clone(); blocks[:, : Lk // 3] = -10000.0
+    for name, bb in (("dense", None), ("bias", bias), ("masked tiles", blocks)):
+        eng.lib.set_option("attn_pp", 0)
+        ref = eng.op_attention_split(q, k, v, h, bias=bb)
+        for mode in (1, 2):
+            eng.lib.set_option("attn_pp", mode)
+            outs = [eng.op_attention_split(q, k, v, h, bias=bb) for _ in range(3)]
+            same = all(torch.equal(o, ref) for o in outs)
+            ok &= same
+            print(f"B={B} h={h} Lq={Lq} Lk={Lk} {name:12s} attn_pp={mode} == pipelines (3 runs): {same}" + ("" if same else f"  max|d|={max((o - ref).abs().max().item() for o in outs):.3e} nan={any(torch.isnan(o).any().item() for o in outs)}"), flush=True)
+print("ping-pong kernel bit-identical:", ok)
+
+
+def timed(fn, n=10):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+print("shape (B h Lq Lk)            pipelines   pp(prio)   pp(noprio)   [ms per op_attention_split call; TF/s of the dense-equivalent flops for pp(prio)]")
+for (B, h, Lq, Lk, masked) in ((4, 5, 16384, 16384, False), (4, 5, 16384, 16384, True), (4, 10, 4096, 16384, False), (4, 10, 4096, 4096, True), (4, 20, 1024, 16384, False),
+                                (4, 20, 256, 16384, False), (1, 5, 16384, 16384, False), (1, 10, 4096, 16384, False)):
+    q = torch.randn(B, Lq, h * 64, generator=g, device="cuda") * 1.5
+    k = torch.randn(B, Lk, h * 64, generator=g, device="cuda") * 1.5
+    v = torch.randn(B, Lk, h * 64, generator=g, device="cuda")
+    bb = None
+    if masked:
+        bb = torch.zeros(B, Lk, device="cuda"); bb[:, : int(Lk * 0.4)] = -10000.0
+    t = []
+    for mode in (0, 1, 2):
+        eng.lib.set_option("attn_pp", mode)
+        t.append(timed(lambda: eng.op_attention_split(q, k, v, h, bias=bb)))
+    fl = 4.0 * B * h * Lq * Lk * 64
+    print(f"{B} {h:2d} {Lq:5d} {Lk:5d} {'masked' if masked else 'dense ':6s}   {t[0]:8.3f}   {t[1]:8.3f}   {t[2]:8.3f}    {fl / t[1] / 1e9:7.1f} TF/s", flush=True)
+eng.lib.set_option("attn_pp", 1)
+eng.close()
+if "--no-step" not in sys.argv:
+    for name, opts in (("attn_pp=0 (pipelines)", ["attn_pp=0"]), ("attn_pp=2 (no priority)", ["attn_pp=2"]), ("default (attn_pp=1)", [])):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--timed-only", "--steps", "4", "--warmup", "2"] + [x for o in opts for x in ("--opt", o)], capture_output=True, text=True)
+        try:
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            print(f"{name}: {d['value']} img/s {d['ms_per_step']} ms/step", {k: x["ms"] for k, x in list(d["kernel_breakdown_ms"].items())[:5]}, flush=True)
+        except Exception as e:
+            print("bench failed", e, r.stderr[-400:])
