@@ -803,6 +803,10 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_pipe_kernel(AttnParams p)
 // pp_flags bit 0: s_setprio 1 for waves 4-7 (the second-dispatched half loses every arbitration at equal priority; item 4 of the guide's section)
 // ------------------------------------------------------------------------------------------------
 #define ATTN64PP_SMEM (3 * ATTN64P_BUF)
+// ABL (bench only, sdm_bench_attn; 0 in the engine): 1 no softmax VALU, 2 no P.V MFMAs, 4 no Q.K^T MFMAs, 8 no global prefetch, 16 no LDS staging writes, 32 no fragment reads
+// BIAS = 0: no key bias and Lk % 64 == 0 (every cross-attention of the engine): the logit accumulators start from 0 and the bias row is neither loaded, staged
+// nor read (8 of a segment's 40 fragment reads).  LIST = 0: dense walk, tile indices are arithmetic (no list loads in the loop).
+template <int ABL = 0, int BIAS = 1, int LIST = 1>
 __global__ void __launch_bounds__(512, 2) attn_d64_pp_kernel(AttnParams p) {
   constexpr int NTH = 512;
   SDM_DYN_SMEM(smem);
@@ -848,45 +852,57 @@ __global__ void __launch_bounds__(512, 2) attn_d64_pp_kernel(AttnParams p) {
   int i0, nwalk;
   attn_split_range(p, tl, ntiles, tl ? tl[0] : ntiles, sp, i0, nwalk);
   if (nwalk <= 0) { attn_write_empty_part(p, sp, b, head, q0, lane); return; }      // (key split only; block-uniform, before the first barrier)
-  // tile index of walk position i, clamped (see the header) and BRANCH-FREE: the list entry is always loaded (a dense walk reads a word of the K tensor -
-  // at least ntiles words long - and discards it), so that a matrix segment stays one basic block
-  const int* tlp = tl ? tl + 1 + i0 : (const int*)(p.k + (size_t)b * p.k_bs);
-  const int is_list = tl ? 1 : 0;
-  auto tile_at = [&](int i) { if (i > nwalk - 1) i = nwalk - 1; return (i0 + i) + is_list * (tlp[i] - (i0 + i)); };      // (arithmetic, not a select: a select lets the load sink back into a branch)
+  // tile index of walk position i, clamped (see the header).  List walks load the entry one iteration before it is needed (loop below); here: prologue only
+  const int* tlp = tl ? tl + 1 + i0 : nullptr;
+  auto tile_at = [&](int i) { if (i > nwalk - 1) i = nwalk - 1; return LIST ? tlp[i] : i0 + i; };
 
-  // one raw tile between global memory and LDS: one 16-byte vector of K_hi, of the K pair plane and of V^T per thread, one bias value per lane
-  f16x8 rk, rkl, rv;
-  float rb = 0.0f;
-  bool rin = true;
+  // one raw tile between global memory and LDS: one 16-byte vector of K_hi, of the K pair plane and of V^T per thread, one bias value per lane.  TWO sets
+  // alternate: the loads of tile t+4 are requested in the matrix segment of tile t and written to LDS in that of tile t+2 - two tile periods to land (with one
+  // set and one period the staging wait of every segment sat on loads still in flight: the ablation without global loads ran 21 % faster)
+  struct Raw { f16x8 k, kl, v; float b; bool in; };
+  Raw ra, rb2;
+  ra.b = 0.0f; ra.in = true; rb2.b = 0.0f; rb2.in = true;
   const int srow = tid >> 3, spart = tid & 7;
-  auto prefetch = [&](int t) {
+  auto prefetch = [&](int t, Raw& r) {
+    if (ABL & 8) return;
     const int k0 = t * 64;
     int kr = k0 + srow;
     if (kr > p.Lk - 1) kr = p.Lk - 1;
-    rk = *(const f16x8*)(kbase + (size_t)kr * p.ldk + spart * 8);
-    rv = *(const f16x8*)(vbase + (size_t)srow * p.ldvt + k0 + spart * 8);
-    rkl = *(const f16x8*)(kbase + p.k_lo + (size_t)kr * p.ldk + spart * 8);
-    int kb = k0 + (tid & 63);
-    rin = kb < p.Lk;
-    if (!rin) kb = p.Lk - 1;
-    rb = bsrc[kb];
+    r.k = *(const f16x8*)(kbase + (size_t)kr * p.ldk + spart * 8);
+    r.v = *(const f16x8*)(vbase + (size_t)srow * p.ldvt + k0 + spart * 8);
+    r.kl = *(const f16x8*)(kbase + p.k_lo + (size_t)kr * p.ldk + spart * 8);
+    if (BIAS) {
+      int kb = k0 + (tid & 63);
+      r.in = kb < p.Lk;
+      if (!r.in) kb = p.Lk - 1;
+      r.b = bsrc[kb];
+    }
   };
-  auto stage = [&](int slot) {
+  auto stage = [&](int slot, const Raw& r) {
+    if (ABL & 16) return;
     unsigned char* kb_ = smem + slot * BUF;
-    *(f16x8*)(kb_ + srow * PK + spart * 16) = rk;
+    *(f16x8*)(kb_ + srow * PK + spart * 16) = r.k;
     f16x4 lo, hi4;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { lo[e] = rv[e]; hi4[e] = rv[4 + e]; }
+    for (int e = 0; e < 4; ++e) { lo[e] = r.v[e]; hi4[e] = r.v[4 + e]; }
     *(f16x4*)(kb_ + VOFF + srow * PV + spart * 16) = lo;
     *(f16x4*)(kb_ + VOFF + srow * PV + spart * 16 + 8) = hi4;
-    *(f16x8*)(kb_ + KLO + srow * PK + spart * 16) = rkl;
-    ((float*)(kb_ + BOFF))[lane] = rin ? (bbase ? rb : 0.0f) : SDM_NEG_BIG;      // every wave writes the same 64 values: no exec-masked region in the segment
+    *(f16x8*)(kb_ + KLO + srow * PK + spart * 16) = r.kl;
+    if (BIAS) ((float*)(kb_ + BOFF))[lane] = r.in ? (bbase ? r.b : 0.0f) : SDM_NEG_BIG;      // every wave writes the same 64 values: no exec-masked region in the segment
   };
   // ---- the matrix segment, hand-pipelined: fragment reads are issued one group (6 MFMAs = 192-256 pipe cycles) ahead of the MFMAs that consume them, the
   //      groups are fenced so that the scheduler cannot sink a read to its use (it did: ds_read / s_waitcnt lgkmcnt(0) / v_mfma triples, one exposed LDS round
   //      trip per MFMA).  K fragments of both 32-key halves (16 b128), then V^T fragments per half (8 b64 pairs each) in the registers the K fragments leave.
   struct KFrag { f16x8 h[4]; i32x8 f8[2]; };
   auto load_bias = [&](int slot, f32x16 (&s)[2]) {
+    if (!BIAS) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kt][r] = 0.0f;
+      return;
+    }
+    if (ABL & 32) return;
     const float* Bs = (const float*)(smem + slot * BUF + BOFF);
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
@@ -898,6 +914,7 @@ __global__ void __launch_bounds__(512, 2) attn_d64_pp_kernel(AttnParams p) {
       }
   };
   auto load_k = [&](int slot, int kt, KFrag& f) {
+    if (ABL & 32) { SDM_PIN_HERE_V4(f.h[0], f.h[1], f.h[2], f.h[3]); SDM_PIN_HERE_V4(f.f8[0], f.f8[1], f.h[0], f.h[1]); return; }
     const unsigned char* Ks = smem + slot * BUF;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) f.h[ks] = *(const f16x8*)(Ks + (kt * 32 + l31) * PK + ks * 32 + hi * 16);
@@ -909,6 +926,7 @@ __global__ void __launch_bounds__(512, 2) attn_d64_pp_kernel(AttnParams p) {
     }
   };
   auto mma_k = [&](const KFrag& f, f32x16& sk) {
+    if (ABL & 4) return;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) sk = SDM_MFMA_32x32x16_F16(f.h[ks], qf[ks], sk);
 #pragma unroll
@@ -916,6 +934,7 @@ __global__ void __launch_bounds__(512, 2) attn_d64_pp_kernel(AttnParams p) {
   };
   struct VFrag { f16x8 v[2][2]; };      // [u][dt]
   auto load_v = [&](int slot, int kt, VFrag& f) {
+    if (ABL & 32) { SDM_PIN_HERE_V4(f.v[0][0], f.v[0][1], f.v[1][0], f.v[1][1]); return; }
     const unsigned char* Vs = smem + slot * BUF + VOFF;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -928,6 +947,7 @@ __global__ void __launch_bounds__(512, 2) attn_d64_pp_kernel(AttnParams p) {
       }
   };
   auto mma_v = [&](const VFrag& f, const f16x8 (&pk)[2]) {      // O^T[d][q] += V^T[d][key] . P^T[key][q], denominators on the same probabilities
+    if (ABL & 2) return;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       ls = SDM_MFMA_32x32x16_F16(ones, pk[u], ls);
@@ -947,6 +967,16 @@ __global__ void __launch_bounds__(512, 2) attn_d64_pp_kernel(AttnParams p) {
   // softmax of one tile: logits -> fp16 probabilities in B-operand layout; running maximum, rescale of O^T / the denominators when it moved.  Everything is
   // pinned inside the segment (the probabilities are only consumed by the NEXT segment's MFMAs: left alone, the sub / exp / pack stream sinks behind the barrier)
   auto softmax = [&](f32x16 (&s)[2], f16x8 (&pf)[2][2]) {
+    if (ABL & 1) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int j = 0; j < 8; j += 2) { pf[kt][u][j] = (half_t)s[kt][8 * u + j]; pf[kt][u][j + 1] = pf[kt][u][j]; }
+      SDM_PIN_HERE_V4(pf[0][0], pf[0][1], pf[1][0], pf[1][1]);
+      return;
+    }
     float mx = SDM_NEG_BIG;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
@@ -982,12 +1012,14 @@ __global__ void __launch_bounds__(512, 2) attn_d64_pp_kernel(AttnParams p) {
   };
   auto lds_barrier = [&]() { SDM_SCHED_FENCE(); SDM_WAIT_LGKMCNT0(); SDM_RAW_BARRIER(); SDM_SCHED_FENCE(); };
 
-  // ---- prologue: tiles 0 and 1 in LDS, tile 2 on its way; A computes the logits of tile 0 while B waits one interval ----
-  prefetch(tile_at(0));
-  stage(0);
-  prefetch(tile_at(1));
-  stage(1);
-  prefetch(tile_at(2));
+  // ---- prologue: tiles 0 and 1 in LDS, tiles 2 and 3 on their way; A computes the logits of tile 0 while B waits one interval ----
+  prefetch(tile_at(0), ra);
+  stage(0, ra);
+  prefetch(tile_at(1), rb2);
+  stage(1, rb2);
+  prefetch(tile_at(2), ra);
+  prefetch(tile_at(3), rb2);
+  int tq = LIST ? tile_at(4) : 0;                                      // list walks: index of the tile the coming matrix segment requests
   lds_barrier();
   if (grp) {
     if (p.pp_flags & 1) SDM_SETPRIO(1);
@@ -998,37 +1030,47 @@ __global__ void __launch_bounds__(512, 2) attn_d64_pp_kernel(AttnParams p) {
   qk(0, s);
   lds_barrier();
   int bt = 0;
-  int tnext = tile_at(3);                                              // index of the tile requested in the coming matrix segment (list walks: fetched one segment ahead)
-  for (int t = 0; t < nwalk; ++t) {
+  auto iter = [&](const int t, Raw& cur) {
     // ---- softmax segment of tile t; the V^T fragments of the same tile (staged two tiles ago) are read at its end, so that the matrix segment opens with
     //      MFMAs instead of an LDS round trip ----
-    const int tcur = tnext;
-    tnext = tile_at(t + 4);                                            // lands under this segment and the next one's first half
     softmax(s, pf);
     VFrag v0, v1;
     load_v(bt, 0, v0);
     load_v(bt, 1, v1);
     lds_barrier();
-    // ---- matrix segment: P.V of tile t (operands in registers) while the K fragments / biases of tile t+1 arrive, tile t+2 is written to the slot tile t-1
-    //      has left and tile t+3 is requested; then Q.K^T of tile t+1.  One scheduling region per half, MFMAs interleaved with the rest ----
+    // ---- matrix segment: P.V of tile t (operands in registers) while the K fragments / biases of tile t+1 arrive and tile t+2 (requested two tiles ago) is
+    //      written to the slot tile t-1 has left; then Q.K^T of tile t+1 while tile t+4 is requested.  One scheduling region per half ----
     const int b1 = bt == 2 ? 0 : bt + 1, b2 = b1 == 2 ? 0 : b1 + 1;
     KFrag k0, k1;
     mma_v(v0, pf[0]);
     mma_v(v1, pf[1]);
-    stage(b2);
+    stage(b2, cur);
     load_bias(b1, s);
     load_k(b1, 0, k0);
     load_k(b1, 1, k1);
 #pragma unroll
     for (int i = 0; i < 12; ++i) { SDM_SCHED_GROUP(0x008, 1, 0); SDM_SCHED_GROUP(0x100, 2, 0); SDM_SCHED_GROUP(0x202, 1, 0); }
     SDM_SCHED_FENCE();
-    prefetch(tcur);
+    int treq;
+    if (LIST) {      // the entry for the NEXT segment's request is loaded here, in front of this segment's four tile loads: by the time it is needed the staging
+      treq = tq;     // wait of that segment has long covered it (a load placed in the softmax segment put a vmcnt(0) - i.e. the tile loads - in front of the barrier)
+      int i5 = t + 5; if (i5 > nwalk - 1) i5 = nwalk - 1;
+      tq = tlp[i5];
+    } else {
+      int i4 = t + 4; if (i4 > nwalk - 1) i4 = nwalk - 1;
+      treq = i0 + i4;
+    }
+    prefetch(treq, cur);
     mma_k(k0, s[0]);
     mma_k(k1, s[1]);
 #pragma unroll
     for (int i = 0; i < 12; ++i) { SDM_SCHED_GROUP(0x008, 1, 1); SDM_SCHED_GROUP(0x022, 2, 1); }
     lds_barrier();
     bt = b1;
+  };
+  for (int t = 0; t < nwalk; t += 2) {
+    iter(t, ra);
+    if (t + 1 < nwalk) iter(t + 1, rb2);
   }
   if (!grp) lds_barrier();                                             // B's last matrix segment still reads V^T: the epilogue reuses the buffers
 

@@ -1386,7 +1386,10 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
         // 8-wave blocks with fp32 output (the engine's level-0 attentions): the two-tile software pipeline of the kernel (k_attn.h,
         // attn_d64_pipe_kernel: same arithmetic, bit-identical results, -9 % kernel time); option attn_pipe = 0 selects the plain form.
         const bool pipe8 = opt("attn_pipe") != 0, pipe4 = opt("attn_pipe4") != 0;
-        if (pp) { count_kernel("attn_d64_pp"); p.pp_flags = opt("attn_pp") == 1 ? 1 : 0; auto kp = attn_d64_pp_kernel; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, gy, 1), dim3(512), ATTN64PP_SMEM, e->stream, p); }
+        if (pp) { count_kernel("attn_d64_pp"); p.pp_flags = opt("attn_pp") == 1 ? 1 : 0; const bool pb = p.bias || (Lk % 64) != 0;
+          if (p.tiles) { auto kp = attn_d64_pp_kernel<0, 1, 1>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, gy, 1), dim3(512), ATTN64PP_SMEM, e->stream, p); }
+          else if (pb) { auto kp = attn_d64_pp_kernel<0, 1, 0>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, gy, 1), dim3(512), ATTN64PP_SMEM, e->stream, p); }
+          else { auto kp = attn_d64_pp_kernel<0, 0, 0>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, gy, 1), dim3(512), ATTN64PP_SMEM, e->stream, p); } }
         else if (nw8 && pipe8 && p.o_f32) { count_kernel("attn_d64_pipe<8>"); auto kp = attn_d64_pipe_kernel<8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, gy, 1), dim3(512), ATTN64PIPE_SMEM, e->stream, p); }
         else if (!nw8 && pipe4 && p.o_f32) { count_kernel("attn_d64_pipe<4>"); auto kp = attn_d64_pipe_kernel<4>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, gy, 1), dim3(256), ATTN64PIPE4_SMEM, e->stream, p); }
         else if (nw8) { count_kernel("attn_d64<prec3,8>"); auto kp = attn_d64_kernel<1, 3, 8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, gy, 1), dim3(512), ATTN64P_SMEM, e->stream, p); }
@@ -3018,6 +3021,10 @@ float sdm_bench_attn(sdm_ctx* e, int B, int heads, int Lq, int Lk, int qt, int a
     SDM_LAUNCH(fill_random_f16_kernel, dim3(4096), dim3(256), 0, e->stream, (half_t*)k + (size_t)B * Lk * C, (long)B * Lk * C, 17u, 0.0003f);
     SDM_LAUNCH(fill_random_f16_kernel, dim3(4096), dim3(256), 0, e->stream, (half_t*)vt + (size_t)B * heads * 64 * ldvt, (long)B * heads * 64 * ldvt, 19u, 0.0003f);
   }
+  if (prec && (qt & 16)) {      // pair planes: random fp16 bit patterns would hold e5m2 NaNs; zero residual pairs time the same instructions
+    (void)hipMemsetAsync((half_t*)q + (size_t)B * Lq * C, 0, (size_t)B * Lq * C * 2, (hipStream_t)e->stream);
+    (void)hipMemsetAsync((half_t*)k + (size_t)B * Lk * C, 0, (size_t)B * Lk * C * 2, (hipStream_t)e->stream);
+  }
   SDM_LAUNCH(fill_random_f16_kernel, dim3(4096), dim3(256), 0, e->stream, (half_t*)q, (long)B * Lq * C, 3u, 1.0f);
   SDM_LAUNCH(fill_random_f16_kernel, dim3(4096), dim3(256), 0, e->stream, (half_t*)k, (long)B * Lk * C, 7u, 1.0f);
   SDM_LAUNCH(fill_random_f16_kernel, dim3(4096), dim3(256), 0, e->stream, (half_t*)vt, (long)B * heads * 64 * ldvt, 11u, 1.0f);
@@ -3033,7 +3040,13 @@ float sdm_bench_attn(sdm_ctx* e, int B, int heads, int Lq, int Lk, int qt, int a
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   for (int i = 0; i <= iters; ++i) {
     if (i == 1) (void)hipEventRecord(e0, (hipStream_t)e->stream);
-    if (prec && (qt & 8) && nw8) { auto kp = attn_d64_kernel<1, 2, 8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk), dim3(512), ATTN64P_SMEM, e->stream, p); }      // bit 8: P.V on plain fp16
+    if (qt & 16) {      // bit 16: the ping-pong kernel (pair planes as the engine's self- and cross-attentions), ablate = its compile-time ABL mask
+      p.pp_flags = (qt & 32) ? 0 : 1;
+#define SDM_PP_ABL(A) case A: { auto kp = attn_d64_pp_kernel<A, 0, 0>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk), dim3(512), ATTN64PP_SMEM, e->stream, p); } break;
+      switch (ablate) { SDM_PP_ABL(0) SDM_PP_ABL(1) SDM_PP_ABL(6) SDM_PP_ABL(7) SDM_PP_ABL(8) SDM_PP_ABL(24) SDM_PP_ABL(32) SDM_PP_ABL(56) SDM_PP_ABL(63) default: break; }
+#undef SDM_PP_ABL
+    }
+    else if (prec && (qt & 8) && nw8) { auto kp = attn_d64_kernel<1, 2, 8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk), dim3(512), ATTN64P_SMEM, e->stream, p); }      // bit 8: P.V on plain fp16
     else if (prec && (qt & 8)) { auto kp = attn_d64_kernel<1, 2, 4>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk), dim3(256), ATTN64P_SMEM, e->stream, p); }
     else if (prec && nw8) { auto kp = attn_d64_kernel<1, 1, 8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk), dim3(512), ATTN64P_SMEM, e->stream, p); }
     else if (prec) { auto kp = attn_d64_kernel<1, 1, 4>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk), dim3(256), ATTN64P_SMEM, e->stream, p); }
