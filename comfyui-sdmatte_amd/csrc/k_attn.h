@@ -785,33 +785,39 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_pipe_kernel(AttnParams p)
 }
 
 // ------------------------------------------------------------------------------------------------
-// The same arithmetic as a PING-PONG of the block's two wave halves (round 6; engine option attn_pp, default): waves 0-3 ("A", one per SIMD) and waves
-// 4-7 ("B", their SIMD partners) run the SAME instruction sequence - [softmax of tile t] barrier [Q.K^T of tile t+1, P.V of tile t] barrier - with B one
-// barrier interval behind A, so that at any time every SIMD holds one wave in its matrix segment (24 back-to-back MFMAs = 896 pipe cycles, LDS fragment
-// reads, the staging of tile t+2) and one wave in its softmax segment (max / sub / 33 v_exp_f32 / pack: ~130 VALU issues).  In attn_d64_pipe_kernel both
-// waves of a SIMD are in the same phase (one barrier per tile): the SQ counters put the matrix pipe at 0.51 busy with the VALU equally half idle - the two
-// pipes ran in SUM, not in MAX (profiles/r06_attn_sq_counters.txt).  MI355X_MICROARCH.md "Two waves per SIMD": the matrix pipe and VALU issue of a SIMD
-// are shared by its two waves; complementary segments (matrix beside VALU / memory) are what nets.
+// PING-PONG of the block's two wave halves (round 6; engine option attn_pp): waves 0-3 ("A", one per SIMD) and waves 4-7 ("B", their SIMD partners) run
+// the SAME instruction sequence - [softmax of tile t] barrier [P.V of tile t, Q.K^T of tile t+1] barrier - with B one barrier interval behind A, so that at
+// any time every SIMD holds one wave in its matrix segment (24 back-to-back MFMAs = 896 pipe cycles) and one wave in its softmax segment (max / sub / 33
+// v_exp_f32 / pack: ~100 VALU issues).  In attn_d64_pipe_kernel both waves of a SIMD are in the same phase (one barrier per tile): the SQ counters put the
+// matrix pipe at 0.53 busy with VALU issue active 0.48 of the time - the two pipes ran in SUM, not in MAX (profiles/r06_attn_sq_counters.txt).
+// MI355X_MICROARCH.md "Two waves per SIMD": complementary segments (matrix beside VALU / memory) are what nets.
 //   phase n:      0        1            2               3               4         ...
-//   A (0-3):    QK(0)   softmax(0)   QK(1) PV(0)     softmax(1)      QK(2) PV(1)
-//   B (4-7):     -       QK(0)       softmax(0)      QK(1) PV(0)     softmax(1)
-// Three whole tile buffers as in the 8-wave pipeline (tile t in slot t % 3).  A's matrix segment of tile t (phase 2t+2) and B's (2t+3) read K(t+1) and
-// V(t); the slot of tile t-1 was last read by B in phase 2t+1 and tile t+2 is first read by A in phase 2t+4, so BOTH halves write their share of tile t+2
-// at the head of their own matrix segment of tile t (phases 2t+2 / 2t+3) and request tile t+3 behind it.  Staging and prefetch are unconditional (indices
-// clamped to the last tile of the walk: a rewritten slot nobody reads any more), and Q.K^T of the tile behind the last one runs on stale bytes whose logits
-// nobody consumes - the matrix segment is ONE basic block.  Same operations in the same order per query row as attn_d64_pipe_kernel<8>: bit-identical.
+//   A (0-3):    QK(0)   softmax(0)   PV(0) QK(1)     softmax(1)      PV(1) QK(2)
+//   B (4-7):     -       QK(0)       softmax(0)      PV(0) QK(1)     softmax(1)
+// Compile-time ablations of the first build (register-staged tiles; profiles/r06_attn_pp_ablation.txt): MFMAs + softmax + barriers alone take 1837 cycles per
+// tile pair - the matrix-pipe floor is 1792 - but the full kernel 3550: global loads into registers 750, LDS staging writes 370, fragment reads 520.  Hence:
+// * K, the K pair plane, V^T (and the bias row) travel by LDS-DMA - no staging registers, no ds_write, no compiler-placed vmcnt in the loop - into a ring of
+//   FOUR unpadded tile slots: the DMAs of tile t+3 are issued at the head of a wave's matrix segment of tile t (the slot of tile t-1: last read by B in phase
+//   2t+1), every matrix segment ends with a counted vmcnt that leaves only its own DMAs in flight, so a DMA has three phases to land and tile t+2 is complete,
+//   for both halves, behind the barrier that closes phase 2t+3 - A reads it from phase 2t+4 on;
+// * images are [64 rows][8 chunks of 16 B], chunk c of row r at position c ^ ((r >> 1) & 7): the 16 lanes of a ds_read_b128 group read 16 different
+//   (row parity, position) pairs - conflict-free without padding (the DMA writes 1 KB runs: rows cannot be padded);
+// * K row rho of a 32-key half holds key pi(rho) (bits 2 and 3 swapped, as in attn_d512_kernel): the 8 probabilities a lane owns per 16-key step are then 8
+//   CONSECUTIVE keys and a V^T fragment is ONE ds_read_b128 (was two ds_read_b64 at a 136-byte pitch).  This permutes the k-slots of the P.V MFMAs: results
+//   equal the pipelines' up to the order of the fp32 sums inside an MFMA (not bit-identical; dense and tile-list walks of THIS kernel stay bit-identical);
+// * BIAS = 0 (no key bias: every cross-attention): accumulators start from 0, no bias row at all (8 of 40 fragment reads).  LIST = 0: dense walk.
+// Needs Lk % 64 == 0 (no masked tail rows); other launches keep the pipelines.  DMAs and tile indices are unconditional with clamped indices (a rewritten slot
+// nobody reads any more); Q.K^T of the tile behind the last one runs on stale bytes whose logits nobody consumes - a matrix segment is ONE basic block.
 // pp_flags bit 0: s_setprio 1 for waves 4-7 (the second-dispatched half loses every arbitration at equal priority; item 4 of the guide's section)
+// ABL (bench only, sdm_bench_attn; 0 in the engine): 1 no softmax VALU, 2 no P.V MFMAs, 4 no Q.K^T MFMAs, 8 no DMAs, 32 no fragment reads
 // ------------------------------------------------------------------------------------------------
-#define ATTN64PP_SMEM (3 * ATTN64P_BUF)
-// ABL (bench only, sdm_bench_attn; 0 in the engine): 1 no softmax VALU, 2 no P.V MFMAs, 4 no Q.K^T MFMAs, 8 no global prefetch, 16 no LDS staging writes, 32 no fragment reads
-// BIAS = 0: no key bias and Lk % 64 == 0 (every cross-attention of the engine): the logit accumulators start from 0 and the bias row is neither loaded, staged
-// nor read (8 of a segment's 40 fragment reads).  LIST = 0: dense walk, tile indices are arithmetic (no list loads in the loop).
+#define ATTN64PP_SLOT (3 * 8192 + 256)
+#define ATTN64PP_SMEM (4 * ATTN64PP_SLOT)
 template <int ABL = 0, int BIAS = 1, int LIST = 1>
 __global__ void __launch_bounds__(512, 2) attn_d64_pp_kernel(AttnParams p) {
-  constexpr int NTH = 512;
   SDM_DYN_SMEM(smem);
-  constexpr int PK = ATTN64_PK, PV = ATTN64_PV, BUF = ATTN64P_BUF;
-  constexpr int KLO = 64 * PK, VOFF = 2 * 64 * PK, BOFF = VOFF + 64 * PV;
+  constexpr int SLOT = ATTN64PP_SLOT, KLO = 8192, VOFF = 16384, BOFF = 24576;
+  constexpr int NDMA = BIAS ? 4 : 3;                                  // DMAs a wave issues per tile
   const int tid = threadIdx.x, lane = tid & 63, wave = SDM_UNIFORM_I(tid >> 6);
   const int grp = wave >> 2;
   const int hi = lane >> 5, l31 = lane & 31;
@@ -844,55 +850,43 @@ __global__ void __launch_bounds__(512, 2) attn_d64_pp_kernel(AttnParams p) {
 
   const half_t* kbase = p.k + (size_t)b * p.k_bs + head * 64;
   const half_t* vbase = p.vt + (size_t)b * p.vt_bs + (size_t)head * p.vt_hs;
-  const float* bbase = p.bias ? p.bias + (size_t)b * p.bias_bs : nullptr;
-  const float* bsrc = bbase ? bbase : (const float*)(p.k + (size_t)b * p.k_bs);
-  const int ntiles = (p.Lk + 63) / 64;
-  const int* tl = p.tiles ? p.tiles + (size_t)b * p.tiles_bs : nullptr;
+  const int ntiles = p.Lk / 64;                                        // (Lk % 64 == 0: launcher's condition)
+  const int* tl = (LIST && p.tiles) ? p.tiles + (size_t)b * p.tiles_bs : nullptr;
   const int sp = p.nsplit > 1 ? (int)blockIdx.y : 0;
   int i0, nwalk;
   attn_split_range(p, tl, ntiles, tl ? tl[0] : ntiles, sp, i0, nwalk);
   if (nwalk <= 0) { attn_write_empty_part(p, sp, b, head, q0, lane); return; }      // (key split only; block-uniform, before the first barrier)
-  // tile index of walk position i, clamped (see the header).  List walks load the entry one iteration before it is needed (loop below); here: prologue only
   const int* tlp = tl ? tl + 1 + i0 : nullptr;
-  auto tile_at = [&](int i) { if (i > nwalk - 1) i = nwalk - 1; return LIST ? tlp[i] : i0 + i; };
+  auto tile_at = [&](int i) { if (i > nwalk - 1) i = nwalk - 1; return LIST ? tlp[i] : i0 + i; };      // clamped: see the header
 
-  // one raw tile between global memory and LDS: one 16-byte vector of K_hi, of the K pair plane and of V^T per thread, one bias value per lane.  TWO sets
-  // alternate: the loads of tile t+4 are requested in the matrix segment of tile t and written to LDS in that of tile t+2 - two tile periods to land (with one
-  // set and one period the staging wait of every segment sat on loads still in flight: the ablation without global loads ran 21 % faster)
-  struct Raw { f16x8 k, kl, v; float b; bool in; };
-  Raw ra, rb2;
-  ra.b = 0.0f; ra.in = true; rb2.b = 0.0f; rb2.in = true;
-  const int srow = tid >> 3, spart = tid & 7;
-  auto prefetch = [&](int t, Raw& r) {
+  // ---- DMA side.  Wave w fills rows 8w .. 8w+7 of each image: lane L -> row rho = 8w + (L >> 3), position L & 7 = source chunk (L & 7) ^ ((rho >> 1) & 7);
+  //      K rows: key = 32 * (rho >> 5) + pi(rho & 31).  Per-lane byte offsets are loop invariants; the tile advances through the uniform offset.
+  const sdm_rsrc rsK = sdm_make_rsrc(kbase, (unsigned int)(((size_t)(p.Lk - 1) * p.ldk + 64) * 2));
+  const sdm_rsrc rsK8 = sdm_make_rsrc(kbase + p.k_lo, (unsigned int)(((size_t)(p.Lk - 1) * p.ldk + 64) * 2));
+  const sdm_rsrc rsV = sdm_make_rsrc(vbase, (unsigned int)(((size_t)63 * p.ldvt + p.Lk) * 2));
+  const sdm_rsrc rsB = sdm_make_rsrc(BIAS ? p.bias + (size_t)b * p.bias_bs : (const float*)kbase, (unsigned int)p.Lk * 4u);
+  const int rho = 8 * wave + (lane >> 3), cpos = lane & 7;
+  const int csrc = cpos ^ ((rho >> 1) & 7);
+  const int rr = rho & 31;
+  const int pir = (rr & 0x13) | (((rr >> 2) & 1) << 3) | (((rr >> 3) & 1) << 2);
+  const unsigned int voffK = (unsigned int)(((rho & 32) + pir) * p.ldk * 2 + csrc * 16);
+  const unsigned int voffV = (unsigned int)(rho * p.ldvt * 2 + csrc * 16);
+  const int lr = lane & 31;
+  const unsigned int voffB = (unsigned int)(((lane & 32) + ((lr & 0x13) | (((lr >> 2) & 1) << 3) | (((lr >> 3) & 1) << 2))) * 4);
+  auto dma = [&](int tile, int slot) {
     if (ABL & 8) return;
-    const int k0 = t * 64;
-    int kr = k0 + srow;
-    if (kr > p.Lk - 1) kr = p.Lk - 1;
-    r.k = *(const f16x8*)(kbase + (size_t)kr * p.ldk + spart * 8);
-    r.v = *(const f16x8*)(vbase + (size_t)srow * p.ldvt + k0 + spart * 8);
-    r.kl = *(const f16x8*)(kbase + p.k_lo + (size_t)kr * p.ldk + spart * 8);
-    if (BIAS) {
-      int kb = k0 + (tid & 63);
-      r.in = kb < p.Lk;
-      if (!r.in) kb = p.Lk - 1;
-      r.b = bsrc[kb];
-    }
+    unsigned char* sb = smem + slot * SLOT + wave * 1024;
+    const unsigned int k0 = (unsigned int)tile * 64u;
+    sdm_glds16_buf(rsK, voffK, k0 * (unsigned int)(p.ldk * 2), sb);
+    sdm_glds16_buf(rsK8, voffK, k0 * (unsigned int)(p.ldk * 2), sb + KLO);
+    sdm_glds16_buf(rsV, voffV, k0 * 2u, sb + VOFF);
+    if (BIAS) sdm_glds4_buf(rsB, voffB, k0 * 4u, smem + slot * SLOT + BOFF);      // (every wave writes the same 256 bytes: one DMA count for all waves)
   };
-  auto stage = [&](int slot, const Raw& r) {
-    if (ABL & 16) return;
-    unsigned char* kb_ = smem + slot * BUF;
-    *(f16x8*)(kb_ + srow * PK + spart * 16) = r.k;
-    f16x4 lo, hi4;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { lo[e] = r.v[e]; hi4[e] = r.v[4 + e]; }
-    *(f16x4*)(kb_ + VOFF + srow * PV + spart * 16) = lo;
-    *(f16x4*)(kb_ + VOFF + srow * PV + spart * 16 + 8) = hi4;
-    *(f16x8*)(kb_ + KLO + srow * PK + spart * 16) = r.kl;
-    if (BIAS) ((float*)(kb_ + BOFF))[lane] = r.in ? (bbase ? r.b : 0.0f) : SDM_NEG_BIG;      // every wave writes the same 64 values: no exec-masked region in the segment
-  };
-  // ---- the matrix segment, hand-pipelined: fragment reads are issued one group (6 MFMAs = 192-256 pipe cycles) ahead of the MFMAs that consume them, the
-  //      groups are fenced so that the scheduler cannot sink a read to its use (it did: ds_read / s_waitcnt lgkmcnt(0) / v_mfma triples, one exposed LDS round
-  //      trip per MFMA).  K fragments of both 32-key halves (16 b128), then V^T fragments per half (8 b64 pairs each) in the registers the K fragments leave.
+  // ---- fragment side: row l31 of a 32-row half, chunk (2 ks + hi) etc. at position chunk ^ ((l31 >> 1) & 7) - the XOR folds into the lane's base offset
+  const int kxor = (l31 >> 1) & 7;
+  const int kx = l31 * 128 + ((hi ^ kxor) << 4);                       // K_hi: ^ (ks * 32), + kt * 4096
+  const int k8x = l31 * 128 + (((2 * hi) ^ kxor) << 4);                // pair plane: ^ (m * 64), second half ^ 16
+  const int vx = l31 * 128 + ((hi ^ kxor) << 4);                       // V^T: ^ ((4 kt + 2 u) * 16), + dt * 4096
   struct KFrag { f16x8 h[4]; i32x8 f8[2]; };
   auto load_bias = [&](int slot, f32x16 (&s)[2]) {
     if (!BIAS) {
@@ -903,7 +897,7 @@ __global__ void __launch_bounds__(512, 2) attn_d64_pp_kernel(AttnParams p) {
       return;
     }
     if (ABL & 32) return;
-    const float* Bs = (const float*)(smem + slot * BUF + BOFF);
+    const float* Bs = (const float*)(smem + slot * SLOT + BOFF);
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -915,13 +909,12 @@ __global__ void __launch_bounds__(512, 2) attn_d64_pp_kernel(AttnParams p) {
   };
   auto load_k = [&](int slot, int kt, KFrag& f) {
     if (ABL & 32) { SDM_PIN_HERE_V4(f.h[0], f.h[1], f.h[2], f.h[3]); SDM_PIN_HERE_V4(f.f8[0], f.f8[1], f.h[0], f.h[1]); return; }
-    const unsigned char* Ks = smem + slot * BUF;
+    const unsigned char* Ks = smem + slot * SLOT + kt * 4096;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) f.h[ks] = *(const f16x8*)(Ks + (kt * 32 + l31) * PK + ks * 32 + hi * 16);
+    for (int ks = 0; ks < 4; ++ks) f.h[ks] = *(const f16x8*)(Ks + (kx ^ (ks * 32)));
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-      const unsigned char* kp = Ks + KLO + (kt * 32 + l31) * PK + m * 64 + hi * 32;
-      const i32x4 a0 = *(const i32x4*)kp, a1 = *(const i32x4*)(kp + 16);
+      const i32x4 a0 = *(const i32x4*)(Ks + KLO + (k8x ^ (m * 64))), a1 = *(const i32x4*)(Ks + KLO + ((k8x ^ (m * 64)) ^ 16));
       f.f8[m] = i32x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
     }
   };
@@ -935,16 +928,11 @@ __global__ void __launch_bounds__(512, 2) attn_d64_pp_kernel(AttnParams p) {
   struct VFrag { f16x8 v[2][2]; };      // [u][dt]
   auto load_v = [&](int slot, int kt, VFrag& f) {
     if (ABL & 32) { SDM_PIN_HERE_V4(f.v[0][0], f.v[0][1], f.v[1][0], f.v[1][1]); return; }
-    const unsigned char* Vs = smem + slot * BUF + VOFF;
+    const unsigned char* Vs = smem + slot * SLOT + VOFF;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        const unsigned char* vp = Vs + (dt * 32 + l31) * PV + (kt * 32 + 16 * u + 4 * hi) * 2;
-        const f16x4 v0 = *(const f16x4*)vp, v1 = *(const f16x4*)(vp + 16);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { f.v[u][dt][e] = v0[e]; f.v[u][dt][4 + e] = v1[e]; }
-      }
+      for (int dt = 0; dt < 2; ++dt) f.v[u][dt] = *(const f16x8*)(Vs + dt * 4096 + (vx ^ ((4 * kt + 2 * u) * 16)));
   };
   auto mma_v = [&](const VFrag& f, const f16x8 (&pk)[2]) {      // O^T[d][q] += V^T[d][key] . P^T[key][q], denominators on the same probabilities
     if (ABL & 2) return;
@@ -1012,14 +1000,11 @@ __global__ void __launch_bounds__(512, 2) attn_d64_pp_kernel(AttnParams p) {
   };
   auto lds_barrier = [&]() { SDM_SCHED_FENCE(); SDM_WAIT_LGKMCNT0(); SDM_RAW_BARRIER(); SDM_SCHED_FENCE(); };
 
-  // ---- prologue: tiles 0 and 1 in LDS, tiles 2 and 3 on their way; A computes the logits of tile 0 while B waits one interval ----
-  prefetch(tile_at(0), ra);
-  stage(0, ra);
-  prefetch(tile_at(1), rb2);
-  stage(1, rb2);
-  prefetch(tile_at(2), ra);
-  prefetch(tile_at(3), rb2);
-  int tq = LIST ? tile_at(4) : 0;                                      // list walks: index of the tile the coming matrix segment requests
+  // ---- prologue: tiles 0, 1, 2 in LDS; A computes the logits of tile 0 while B waits one interval ----
+  dma(tile_at(0), 0);
+  dma(tile_at(1), 1);
+  dma(tile_at(2), 2);
+  SDM_WAIT_VMCNT0();
   lds_barrier();
   if (grp) {
     if (p.pp_flags & 1) SDM_SETPRIO(1);
@@ -1029,50 +1014,43 @@ __global__ void __launch_bounds__(512, 2) attn_d64_pp_kernel(AttnParams p) {
   f16x8 pf[2][2];
   qk(0, s);
   lds_barrier();
-  int bt = 0;
-  auto iter = [&](const int t, Raw& cur) {
-    // ---- softmax segment of tile t; the V^T fragments of the same tile (staged two tiles ago) are read at its end, so that the matrix segment opens with
-    //      MFMAs instead of an LDS round trip ----
+  for (int t = 0; t < nwalk; ++t) {
+    const int bt = t & 3, b1 = (t + 1) & 3, b3 = (t + 3) & 3;
+    // ---- softmax segment of tile t; the V^T fragments of the same tile (in LDS since the tile before last) are read at its end, so that the matrix segment
+    //      opens with MFMAs instead of an LDS round trip ----
+    int tq;                                                            // index of the tile this iteration's matrix segment requests
+    {
+      int i3 = t + 3; if (i3 > nwalk - 1) i3 = nwalk - 1;
+      if (LIST) SDM_SLOAD_I32(tq, tlp + i3);                           // list walks: a scalar load that lands under the softmax (never a vector load: header)
+      else tq = i0 + i3;
+    }
     softmax(s, pf);
     VFrag v0, v1;
     load_v(bt, 0, v0);
     load_v(bt, 1, v1);
+    if (LIST) SDM_SLOAD_WAIT(tq);
     lds_barrier();
-    // ---- matrix segment: P.V of tile t (operands in registers) while the K fragments / biases of tile t+1 arrive and tile t+2 (requested two tiles ago) is
-    //      written to the slot tile t-1 has left; then Q.K^T of tile t+1 while tile t+4 is requested.  One scheduling region per half ----
-    const int b1 = bt == 2 ? 0 : bt + 1, b2 = b1 == 2 ? 0 : b1 + 1;
+    // ---- matrix segment: tile t+3 requested into the slot tile t-1 has left; P.V of tile t (operands in registers) while the K fragments / biases of tile
+    //      t+1 arrive; then Q.K^T of tile t+1.  One scheduling region per half ----
+    dma(tq, b3);
     KFrag k0, k1;
     mma_v(v0, pf[0]);
     mma_v(v1, pf[1]);
-    stage(b2, cur);
     load_bias(b1, s);
     load_k(b1, 0, k0);
     load_k(b1, 1, k1);
 #pragma unroll
-    for (int i = 0; i < 12; ++i) { SDM_SCHED_GROUP(0x008, 1, 0); SDM_SCHED_GROUP(0x100, 2, 0); SDM_SCHED_GROUP(0x202, 1, 0); }
+    for (int i = 0; i < 12; ++i) { SDM_SCHED_GROUP(0x008, 1, 0); SDM_SCHED_GROUP(0x100, 2, 0); SDM_SCHED_GROUP(0x002, 1, 0); }
     SDM_SCHED_FENCE();
-    int treq;
-    if (LIST) {      // the entry for the NEXT segment's request is loaded here, in front of this segment's four tile loads: by the time it is needed the staging
-      treq = tq;     // wait of that segment has long covered it (a load placed in the softmax segment put a vmcnt(0) - i.e. the tile loads - in front of the barrier)
-      int i5 = t + 5; if (i5 > nwalk - 1) i5 = nwalk - 1;
-      tq = tlp[i5];
-    } else {
-      int i4 = t + 4; if (i4 > nwalk - 1) i4 = nwalk - 1;
-      treq = i0 + i4;
-    }
-    prefetch(treq, cur);
     mma_k(k0, s[0]);
     mma_k(k1, s[1]);
-#pragma unroll
-    for (int i = 0; i < 12; ++i) { SDM_SCHED_GROUP(0x008, 1, 1); SDM_SCHED_GROUP(0x022, 2, 1); }
+    SDM_SCHED_FENCE();
+    if (!(ABL & 8)) { if (BIAS) SDM_WAIT_VMCNT(4); else SDM_WAIT_VMCNT(3); }      // only this segment's own DMAs stay in flight: tile t+2 has landed
     lds_barrier();
-    bt = b1;
-  };
-  for (int t = 0; t < nwalk; t += 2) {
-    iter(t, ra);
-    if (t + 1 < nwalk) iter(t + 1, rb2);
   }
   if (!grp) lds_barrier();                                             // B's last matrix segment still reads V^T: the epilogue reuses the buffers
+  SDM_WAIT_VMCNT0();                                                   // (the clamped DMAs of the last segments still write their slots)
+  lds_barrier();
 
   // epilogue (fp32 output): per-wave staging [32 q][64 d] at pitch 272 B -> coalesced 16-byte row stores
   constexpr int PS = 272;

@@ -179,6 +179,8 @@ static inline void sdm_glds4_buf(sdm_rsrc r, unsigned int voff, unsigned int sof
 #define SDM_WAIT_VMCNT0() ((void)0)
 #define SDM_WAIT_VMCNT(n) ((void)0)
 #define SDM_WAIT_LGKMCNT0() ((void)0)
+#define SDM_SLOAD_I32(dst, ptr) (dst) = *(ptr)
+#define SDM_SLOAD_WAIT(dst) ((void)0)
 #define SDM_RAW_BARRIER() __syncthreads()
 #else
 __device__ __forceinline__ void sdm_glds16(const void* gsrc, unsigned char* lds_base) {
@@ -204,6 +206,11 @@ __device__ __forceinline__ void sdm_glds4_buf(sdm_rsrc r, unsigned int voff, uns
 // counted wait: at most n vector-memory operations of this wave (loads, LDS-DMAs, stores) may still be outstanding afterwards
 #define SDM_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define SDM_WAIT_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// one wave-uniform 32-bit word through the scalar cache, counted on lgkmcnt - NOT on vmcnt: a kernel that keeps LDS-DMAs in flight cannot afford a compiler-
+// visible vector load (its wait would be a vmcnt that drains the DMA queue, see above).  The result is not valid before SDM_SLOAD_WAIT(dst), which also
+// carries the value (so that no use can be scheduled above the wait); issue and wait inside one straight-line region (no loop-carried in-flight register)
+#define SDM_SLOAD_I32(dst, ptr) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(dst) : "s"(ptr) : "memory")
+#define SDM_SLOAD_WAIT(dst) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(dst) :: "memory")
 #define SDM_RAW_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 #endif
 

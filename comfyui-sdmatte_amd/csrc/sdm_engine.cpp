@@ -122,7 +122,7 @@ static OptEntry g_opts[] = {
   {"attn_nw", 0, 0, "waves per d=64 attention block: 0 by launch size, 4, 8"},
   {"attn_pipe", 1, 1, "8-wave split-precision d=64 attention: two-tile software pipeline"},
   {"attn_pipe4", 1, 1, "the same pipeline for the 4-wave launches (two K / three V^T buffers)"},
-  {"attn_pp", 0, 0, "split-precision d=64 attention with fp32 output as a ping-pong of the block's wave halves (attn_d64_pp_kernel, 256 query rows per block): 0 off, 1 on, 2 on without the static priority of the younger half"},
+  {"attn_pp", 1, 1, "split-precision d=64 attention with fp32 output as a ping-pong of the block's wave halves (attn_d64_pp_kernel, 256 query rows per block): 0 off, 1 on, 2 on without the static priority of the younger half"},
   {"attn_ksplit", 0, 0, "key split of the d=64 split-precision attention: 0 by launch size (blocks that do not fill the chip's block slots a whole number of times), 1 off, 2 / 4 forced"},
   {"precise_mask", -1, -1, "stages in split precision (-1 = the config's own mask; per-stage attribution experiments; read at sdm_create)"},
 };
@@ -1305,15 +1305,15 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
   T part_o, part_ml;
   if (D == 64 && ap.prec && ap.out_f32 && !(ap.prec == 1 && opt("attn_pv_split"))) {
     const int force_nw = opt("attn_nw");
-    const bool pp = ap.prec == 2 && opt("attn_pp") != 0 && !force_nw;      // ping-pong kernel: always 256-row blocks, one per CU
+    const bool pp = ap.prec == 2 && opt("attn_pp") != 0 && !force_nw && Lk % 64 == 0;      // ping-pong kernel: always 256-row blocks, one per CU
     const bool nw8 = pp || (force_nw ? (force_nw == 8) : ((long)B * heads * sdm_cdiv(Lq, 256) >= 1024));
     const long blocks = (long)B * heads * 8 * sdm_cdiv(sdm_cdiv(Lq, nw8 ? 256 : 128), 8), slots = (long)device_cus() * (nw8 ? 1 : 2);
     const int o = opt("attn_ksplit");
     if (o >= 2) nsplit = (o == 2 || o == 4) ? o : 1;
     else if (o == 0) {
       auto rounds = [&](int s) { return (double)((blocks * s + slots - 1) / slots) / s; };
-      for (int s = 2; s <= 4; s *= 2)
-        if (ntiles64 / s >= 32 && rounds(s) < 0.85 * rounds(nsplit)) nsplit = s;
+      for (int s = 2; s <= 4; ++s)      // (3: 80 one-per-CU blocks - the 16^2 level's cross-attentions - become 240 of a third of the length)
+        if ((s != 3 || pp) && ntiles64 / s >= 32 && rounds(s) < 0.85 * rounds(nsplit)) nsplit = s;
     }
     if (nsplit > 1) {
       part_o = talloc(e, nsplit * B, Lq, 1, ldo, 1);
@@ -1376,7 +1376,7 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
       // where they measured faster: the split-precision variant with >= 4 such blocks per CU (B=4 h=5 L=16384: 4.01 vs 4.25 ms;
       // h=10 Lq=4096: 2.39 vs 2.24 ms, i.e. slower; the fp16 variant is neutral to -10 %) - profiles/r02_ablate_attn_nw8.txt
       const int force_nw = opt("attn_nw");                          // A/B / test option: 4 or 8
-      const bool pp = ap.prec == 2 && ap.out_f32 && opt("attn_pp") != 0 && !force_nw;
+      const bool pp = ap.prec == 2 && ap.out_f32 && opt("attn_pp") != 0 && !force_nw && Lk % 64 == 0;      // (LDS-DMA tiles: no masked tail rows)
       const bool nw8 = pp || (force_nw ? (force_nw == 8) : (ap.prec && (long)B * heads * sdm_cdiv(Lq, 256) >= 1024));
       const int qrows = nw8 ? 256 : 128;
       p.batch = B; p.heads = heads; p.nq_blocks = sdm_cdiv(Lq, qrows); p.q_chunks = 8;     // B*heads*8 units: always a multiple of 8
@@ -1386,8 +1386,8 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
         // 8-wave blocks with fp32 output (the engine's level-0 attentions): the two-tile software pipeline of the kernel (k_attn.h,
         // attn_d64_pipe_kernel: same arithmetic, bit-identical results, -9 % kernel time); option attn_pipe = 0 selects the plain form.
         const bool pipe8 = opt("attn_pipe") != 0, pipe4 = opt("attn_pipe4") != 0;
-        if (pp) { count_kernel("attn_d64_pp"); p.pp_flags = opt("attn_pp") == 1 ? 1 : 0; const bool pb = p.bias || (Lk % 64) != 0;
-          if (p.tiles) { auto kp = attn_d64_pp_kernel<0, 1, 1>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, gy, 1), dim3(512), ATTN64PP_SMEM, e->stream, p); }
+        if (pp) { count_kernel("attn_d64_pp"); p.pp_flags = opt("attn_pp") == 1 ? 1 : 0; const bool pb = p.bias != nullptr;
+          if (p.tiles && pb) { auto kp = attn_d64_pp_kernel<0, 1, 1>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, gy, 1), dim3(512), ATTN64PP_SMEM, e->stream, p); }
           else if (pb) { auto kp = attn_d64_pp_kernel<0, 1, 0>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, gy, 1), dim3(512), ATTN64PP_SMEM, e->stream, p); }
           else { auto kp = attn_d64_pp_kernel<0, 0, 0>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, gy, 1), dim3(512), ATTN64PP_SMEM, e->stream, p); } }
         else if (nw8 && pipe8 && p.o_f32) { count_kernel("attn_d64_pipe<8>"); auto kp = attn_d64_pipe_kernel<8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, gy, 1), dim3(512), ATTN64PIPE_SMEM, e->stream, p); }

@@ -230,7 +230,7 @@ def test_attention_d64_split_precision(emu_engine, engine_option):
     engine_option(emu_engine, "attn_f8", 1)
     # the 8-wave form of the same kernel (level-0 attentions; global loads two key tiles ahead through two raw-tile register sets): same
     # arithmetic per query row as the 4-wave form -> bit-identical, for 1, 2, 3 and 5 key tiles and the trimap-style tile list
-    for lk in (40, 128, 130, 300, 450):
+    for lk in (40, 64, 128, 130, 320, 450, 448):
         kk, vv = torch.randn(1, lk, 128, generator=g) * 1.5, torch.randn(1, lk, 128, generator=g)
         bias = torch.where(torch.rand(1, lk, generator=g) < 0.3, torch.tensor(-10000.0), torch.tensor(0.0))
         for bb in (None, bias):
@@ -248,18 +248,16 @@ def test_attention_d64_split_precision(emu_engine, engine_option):
             engine_option(emu_engine, "attn_pipe", 1)
             rp = emu_engine.op_attention_split(q, kk, vv, 2, bias=bb)
             assert torch.equal(rp, r8), (lk, bb is not None, (rp - r8).abs().max().item())
-            # the ping-pong of the block's two wave halves (attn_d64_pp_kernel: what runs by default when no wave count is forced; the halves execute the
-            # same sequence one barrier interval apart, staging and prefetch unconditional with clamped tile indices): same arithmetic again
+            # the ping-pong of the block's two wave halves (attn_d64_pp_kernel; Lk % 64 == 0 only: tiles by LDS-DMA into unpadded, swizzled slots, K rows
+            # permuted so that a V^T fragment is one 16-byte read - the k-slots of the P.V MFMAs are permuted with them): the same products, summed in another
+            # order inside the MFMAs -> equal to the pipelines to fp32 rounding, not bit for bit
             engine_option(emu_engine, "attn_nw", 0)
             engine_option(emu_engine, "attn_pp", 1)
             emu_engine.lib.kernel_counts(reset=True)
             rpp = emu_engine.op_attention_split(q, kk, vv, 2, bias=bb)
-            assert emu_engine.lib.kernel_counts().get("attn_d64_pp", 0) == 1
-            assert torch.equal(rpp, r8), (lk, bb is not None, (rpp - r8).abs().max().item())
+            assert emu_engine.lib.kernel_counts().get("attn_d64_pp", 0) == (1 if lk % 64 == 0 else 0)
+            assert (rpp - r8).abs().max().item() <= 2e-6, (lk, bb is not None, (rpp - r8).abs().max().item())
             engine_option(emu_engine, "attn_pp", 0)
-            emu_engine.lib.kernel_counts(reset=True)
-            emu_engine.op_attention_split(q, kk, vv, 2, bias=bb)
-            assert emu_engine.lib.kernel_counts().get("attn_d64_pp", 0) == 0
     engine_option(emu_engine, "attn_nw", 0)
 
 
@@ -278,6 +276,19 @@ def test_attention_d64_skips_underflowing_key_tiles(emu_engine, engine_option):
     engine_option(emu_engine, "attn_dense", 1)
     dense = emu_engine.op_attention(q, k, v, 1, bias)
     assert torch.equal(sparse, dense)
+    # the same property of the ping-pong kernel (split-precision operands; tile-list walk through scalar loads, dense walk by arithmetic), with and without a key split
+    engine_option(emu_engine, "attn_pp", 1)
+    for ns in (1, 2):
+        engine_option(emu_engine, "attn_ksplit", ns)
+        engine_option(emu_engine, "attn_dense", 0)
+        emu_engine.lib.kernel_counts(reset=True)
+        sp = emu_engine.op_attention_split(q.float(), k.float(), v.float(), 1, bias=bias)
+        assert emu_engine.lib.kernel_counts().get("attn_d64_pp", 0) == 1
+        engine_option(emu_engine, "attn_dense", 1)
+        de = emu_engine.op_attention_split(q.float(), k.float(), v.float(), 1, bias=bias)
+        assert torch.equal(sp, de), (ns, (sp - de).abs().max().item())
+    ref = torch.softmax((q.double() @ k.double().transpose(1, 2)) / 8.0 + bias.double()[:, None, :], -1) @ v.double()
+    assert (de.double() - ref).abs().max().item() < 1e-3
 
 
 def test_attention_d64_key_split(emu_engine, engine_option):

@@ -290,9 +290,11 @@ def test_attention_pipeline_kernels_with_trimap_bias_and_skipped_tiles(eng, engi
     engine_option(eng, "attn_nw", nw)
     engine_option(eng, "attn_pp", 1 if nw == 0 else 0)
     eng.lib.kernel_counts(reset=True)
-    e_blocks = S.check_attention(eng, DEV, 2, 5, 700, 333, 64, use_bias=True, split=True, blocks=True, seed=11, atol=1e-3)       # 6 key tiles, ragged
-    e_rand = S.check_attention(eng, DEV, 1, 2, 2100, 1500, 64, use_bias=True, split=True, seed=12, atol=1e-3)                    # 24 key tiles, random -10000 keys
-    e_one = S.check_attention(eng, DEV, 1, 2, 130, 40, 64, use_bias=True, split=True, seed=13, atol=1e-3)                        # a single (ragged) key tile
+    lk = (333, 1500, 40) if nw else (320, 1536, 64)      # (the ping-pong kernel takes whole 64-key tiles by LDS-DMA: ragged key counts stay on the pipelines)
+    e_blocks = S.check_attention(eng, DEV, 2, 5, 700, lk[0], 64, use_bias=True, split=True, blocks=True, seed=11, atol=1e-3)     # 5-6 key tiles, ragged queries
+    e_rand = S.check_attention(eng, DEV, 1, 2, 2100, lk[1], 64, use_bias=True, split=True, seed=12, atol=1e-3)                   # 24 key tiles, random -10000 keys
+    e_one = S.check_attention(eng, DEV, 1, 2, 130, lk[2], 64, use_bias=True, split=True, seed=13, atol=1e-3)                     # a single key tile
+    e_nobias = S.check_attention(eng, DEV, 2, 5, 300, 1024, 64, use_bias=False, split=True, seed=14, atol=1e-3)                  # no bias (the cross-attention form)
     g = np.load(os.path.join(golden_dir, "g3_attention_scores.npz"))
     q, k, v = (torch.from_numpy(g[n]) for n in ("q", "k", "v"))
     BH, Lq, d = q.shape
@@ -305,9 +307,12 @@ def test_attention_pipeline_kernels_with_trimap_bias_and_skipped_tiles(eng, engi
         out = eng.op_attention_split(tok(q).to(DEV), tok(k).to(DEV), tok(v).to(DEV), heads, bias.to(DEV) if use_bias else None)
         e_g3 = max(e_g3, (out.float().cpu() - tok(torch.from_numpy(g[key]))).abs().max().item())
     counts = eng.lib.kernel_counts()
-    print(f"[{kern}] blocks {e_blocks:.2e} random {e_rand:.2e} one tile {e_one:.2e} G3 {e_g3:.2e} {counts}")
+    print(f"[{kern}] blocks {e_blocks:.2e} random {e_rand:.2e} one tile {e_one:.2e} no bias {e_nobias:.2e} G3 {e_g3:.2e} {counts}")
     assert e_g3 < 1e-3
-    assert counts.get(kern, 0) >= 5 and all(c == 0 for n, c in counts.items() if n.startswith("attn_d64") and n != kern), counts
+    if nw:
+        assert counts.get(kern, 0) >= 6 and all(c == 0 for n, c in counts.items() if n.startswith("attn_d64") and n != kern), counts
+    else:
+        assert counts.get(kern, 0) >= 4, counts      # (the fixture's key count may be ragged: those launches fall back to a pipeline)
 
 
 def test_conv3x3_f8_forced_tiles_per_block(eng, engine_option):
