@@ -1104,6 +1104,8 @@ __global__ void __launch_bounds__(512, 2) attn_d64_pp_kernel(AttnParams p) {
 #define ATTN512P_X_OFF (2 * ATTN512P_K_BYTES + 2 * ATTN512P_V_BYTES)
 #define ATTN512P_SMEM (ATTN512P_X_OFF + ATTN512_X_BYTES)
 
+// ABL (bench only, sdm_bench_attn; 0 in the engine): 1 no exchange / softmax, 2 no P.V MFMAs, 4 no Q.K^T MFMAs, 8 no DMAs, 32 no fragment reads
+template <int ABL = 0>
 __global__ void __launch_bounds__(512) attn_d512_kernel(AttnParams p) {
   SDM_DYN_SMEM(smem);
   float* Xs = (float*)(smem + ATTN512P_X_OFF);
@@ -1139,6 +1141,7 @@ __global__ void __launch_bounds__(512) attn_d512_kernel(AttnParams p) {
   const sdm_rsrc rsV = sdm_make_rsrc(vbase, (unsigned int)((size_t)512 * p.ldvt * 2));
   const unsigned int v_voff = (unsigned int)((lane >> 2) * p.ldvt * 2 + (((lane & 3) ^ ((lane >> 4) & 3)) * 16));   // ((16g + (lane>>2)) >> 2) & 3 == (lane >> 4) & 3
   auto issue_tile = [&](int t, int buf) {
+    if (ABL & 8) return;
     const int k0 = t * 32;
     unsigned char* Kd = smem + buf * ATTN512P_K_BYTES;
     unsigned char* Vd = smem + 2 * ATTN512P_K_BYTES + buf * ATTN512P_V_BYTES;
@@ -1169,28 +1172,59 @@ __global__ void __launch_bounds__(512) attn_d512_kernel(AttnParams p) {
     const unsigned char* Vs = smem + 2 * ATTN512P_K_BYTES + cur * ATTN512P_V_BYTES;
     if (t + 1 < ntiles) issue_tile(t + 1, cur ^ 1);                  // in flight during everything below
     SDM_OPAQUE_I(kx);
+    SDM_OPAQUE_I(vx);
+    // Fragment reads run THREE MFMAs ahead of their use through four rotating registers (round 6): the compiler's own schedule issued each read one MFMA
+    // ahead and waited lgkmcnt(0) in front of every MFMA - an LDS round trip (~100+ cycles) per 32-cycle MFMA, covered only two-fold by the SIMD's other wave:
+    // matrix pipe 0.40 busy (profiles/r06_attn_sq_counters.txt).  The scheduling groups pin one read per MFMA.
+    f16x8 a[4];
+    auto rd_k = [&](int ks) -> f16x8 { if (ABL & 32) return qf[(ks + 1) & 15]; return *(const f16x8*)(Ks + (kx ^ (ks * 32))); };
+    auto rd_v = [&](int i) -> f16x8 { if (ABL & 32) return qf[i & 15]; return *(const f16x8*)(Vs + (vx ^ ((i >> 3) * 32)) + (i & 7) * 2048); };      // i = 8 u + dt
     f32x16 s;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = 0.0f;
 #pragma unroll
+    for (int ks = 0; ks < 3; ++ks) a[ks] = rd_k(ks);
+#pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
-      const f16x8 a = *(const f16x8*)(Ks + (kx ^ (ks * 32)));
-      s = SDM_MFMA_32x32x16_F16(a, qf[ks], s);
+      if (ks + 3 < 16) a[(ks + 3) & 3] = rd_k(ks + 3);
+      if (!(ABL & 4)) s = SDM_MFMA_32x32x16_F16(a[ks & 3], qf[ks], s);
     }
+    if (!(ABL & 36)) {
+      SDM_SCHED_GROUP(0x100, 3, 0);
+#pragma unroll
+      for (int i = 0; i < 13; ++i) { SDM_SCHED_GROUP(0x100, 1, 0); SDM_SCHED_GROUP(0x008, 1, 0); }
+      SDM_SCHED_GROUP(0x008, 3, 0);
+    }
+    SDM_SCHED_FENCE();
     float* xme = Xs + wave * (16 * 64);
     const float* xpt = Xs + (wave ^ 1) * (16 * 64);
+    if (!(ABL & 1)) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) xme[r * 64 + lane] = s[r];
+    }
     SDM_WAIT_LGKMCNT0();
     SDM_RAW_BARRIER();
-    float mx = SDM_NEG_BIG;
+    // the first V^T fragments are requested before the softmax: they land underneath it
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = k0 + 16 * (r >> 3) + 8 * hi + (r & 7);          // pi-permuted row -> actual key
-      float x = (s[r] + xpt[r * 64 + lane]) * p.scale_log2e;
-      if (key >= p.Lk) x = SDM_NEG_BIG;
-      s[r] = x;
-      mx = fmaxf(mx, x);
+    for (int i = 0; i < 3; ++i) a[i] = rd_v(i);
+    float mx = SDM_NEG_BIG;
+    if (!(ABL & 1)) {
+    if (k0 + 32 > p.Lk) {                                              // keys >= Lk: only the last tile can hold any (wave-uniform)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + 16 * (r >> 3) + 8 * hi + (r & 7);        // pi-permuted row -> actual key
+        float x = (s[r] + xpt[r * 64 + lane]) * p.scale_log2e;
+        if (key >= p.Lk) x = SDM_NEG_BIG;
+        s[r] = x;
+        mx = fmaxf(mx, x);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float x = (s[r] + xpt[r * 64 + lane]) * p.scale_log2e;
+        s[r] = x;
+        mx = fmaxf(mx, x);
+      }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float mnew = fmaxf(m_i, mx);
@@ -1210,17 +1244,24 @@ __global__ void __launch_bounds__(512) attn_d512_kernel(AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
     }
+    } else l_i = 1.0f;
+    f16x8 pf[2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      f16x8 pf;
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) pf[j] = (half_t)s[8 * u + j];
+      for (int j = 0; j < 8; ++j) pf[u][j] = (half_t)s[8 * u + j];
+    SDM_SCHED_FENCE();
 #pragma unroll
-      for (int dt = 0; dt < 8; ++dt) {
-        const f16x8 vf = *(const f16x8*)(Vs + (vx ^ (u * 32)) + dt * 2048);
-        o[dt] = SDM_MFMA_32x32x16_F16(vf, pf, o[dt]);
-      }
+    for (int i = 0; i < 16; ++i) {
+      if (i + 3 < 16) a[(i + 3) & 3] = rd_v(i + 3);
+      if (!(ABL & 2)) o[i & 7] = SDM_MFMA_32x32x16_F16(a[i & 3], pf[i >> 3], o[i & 7]);
     }
+    if (!(ABL & 34)) {
+#pragma unroll
+      for (int i = 0; i < 13; ++i) { SDM_SCHED_GROUP(0x100, 1, 1); SDM_SCHED_GROUP(0x008, 1, 1); }
+      SDM_SCHED_GROUP(0x008, 3, 1);
+    }
+    SDM_SCHED_FENCE();
     SDM_WAIT_VMCNT0();          // this wave's pieces of tile t+1 have landed ...
     SDM_RAW_BARRIER();          // ... and so have everyone else's; every wave is done with tile t and the exchange buffer
   }

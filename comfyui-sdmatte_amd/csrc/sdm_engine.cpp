@@ -1419,8 +1419,8 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
       prof_begin(e, "attn_d512", flops, bytes);
       p.batch = B; p.heads = 1; p.nq_blocks = sdm_cdiv(Lq, 128); p.q_chunks = 8;
       const unsigned nblk = (unsigned)(B * p.q_chunks * sdm_cdiv(p.nq_blocks, p.q_chunks));
-      SDM_SET_SMEM(attn_d512_kernel, ATTN512P_SMEM);
-      SDM_LAUNCH(attn_d512_kernel, dim3(nblk), dim3(512), ATTN512P_SMEM, e->stream, p);
+      SDM_SET_SMEM(attn_d512_kernel<0>, ATTN512P_SMEM);
+      SDM_LAUNCH(attn_d512_kernel<0>, dim3(nblk), dim3(512), ATTN512P_SMEM, e->stream, p);
       prof_end(e);
     }
   }
@@ -3011,6 +3011,36 @@ float sdm_bench_attn(sdm_ctx* e, int B, int heads, int Lq, int Lk, int qt, int a
 #ifdef SDM_EMU
   return -1.f;
 #else
+  if (qt & 64) {      // bit 64: the d = 512 single-head kernel (VAE mid-block), ablate = its compile-time ABL mask
+    const int ldvt5 = rup(Lk, 64);
+    void *q5 = nullptr, *k5 = nullptr, *v5 = nullptr, *o5 = nullptr;
+    if (dev_malloc(&q5, (size_t)B * Lq * 512 * 2) || dev_malloc(&k5, (size_t)B * Lk * 512 * 2) || dev_malloc(&v5, (size_t)B * 512 * ldvt5 * 2) || dev_malloc(&o5, (size_t)B * Lq * 512 * 4)) return -2.f;
+    SDM_LAUNCH(fill_random_f16_kernel, dim3(4096), dim3(256), 0, e->stream, (half_t*)q5, (long)B * Lq * 512, 3u, 0.3f);
+    SDM_LAUNCH(fill_random_f16_kernel, dim3(4096), dim3(256), 0, e->stream, (half_t*)k5, (long)B * Lk * 512, 7u, 0.3f);
+    SDM_LAUNCH(fill_random_f16_kernel, dim3(4096), dim3(256), 0, e->stream, (half_t*)v5, (long)B * 512 * ldvt5, 11u, 1.0f);
+    AttnParams p5;
+    memset(&p5, 0, sizeof(p5));
+    p5.q = (const half_t*)q5; p5.q_bs = (long)Lq * 512; p5.ldq = 512; p5.k = (const half_t*)k5; p5.k_bs = (long)Lk * 512; p5.ldk = 512;
+    p5.vt = (const half_t*)v5; p5.vt_hs = (long)512 * ldvt5; p5.vt_bs = p5.vt_hs; p5.ldvt = ldvt5; p5.o = (half_t*)o5; p5.o_bs = (long)Lq * 512; p5.ldo = 512; p5.o_f32 = 1;
+    p5.Lq = Lq; p5.Lk = Lk; p5.scale_log2e = 0.0441941738f * SDM_LOG2E;
+    p5.batch = B; p5.heads = 1; p5.nq_blocks = sdm_cdiv(Lq, 128); p5.q_chunks = 8;
+    const unsigned nb5 = (unsigned)(B * p5.q_chunks * sdm_cdiv(p5.nq_blocks, p5.q_chunks));
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int i = 0; i <= iters; ++i) {
+      if (i == 1) (void)hipEventRecord(e0, (hipStream_t)e->stream);
+#define SDM_D512_ABL(A) case A: { auto kp = attn_d512_kernel<A>; SDM_SET_SMEM(kp, ATTN512P_SMEM); SDM_LAUNCH(kp, dim3(nb5), dim3(512), ATTN512P_SMEM, e->stream, p5); } break;
+      switch (ablate) { SDM_D512_ABL(0) SDM_D512_ABL(1) SDM_D512_ABL(6) SDM_D512_ABL(7) SDM_D512_ABL(8) SDM_D512_ABL(32) SDM_D512_ABL(40) SDM_D512_ABL(41) default: break; }
+#undef SDM_D512_ABL
+    }
+    (void)hipEventRecord(e1, (hipStream_t)e->stream);
+    (void)hipStreamSynchronize((hipStream_t)e->stream);
+    float ms5 = 0.f;
+    (void)hipEventElapsedTime(&ms5, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    dev_free(q5); dev_free(k5); dev_free(v5); dev_free(o5);
+    return ms5 / (float)iters;
+  }
   const int C = heads * 64, ldvt = rup(Lk, 64);
   const int prec = (qt & 2) ? 1 : 0, nw8 = (qt & 4) ? 1 : 0;          // qt bits: 2 = split-precision variant (hi | lo planes, fp32 output), 4 = 8-wave blocks
   void *q = nullptr, *k = nullptr, *vt = nullptr, *o = nullptr;
