@@ -808,15 +808,23 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_pipe_kernel(AttnParams p)
 // * BIAS = 0 (no key bias: every cross-attention): accumulators start from 0, no bias row at all (8 of 40 fragment reads).  LIST = 0: dense walk.
 // Needs Lk % 64 == 0 (no masked tail rows); other launches keep the pipelines.  DMAs and tile indices are unconditional with clamped indices (a rewritten slot
 // nobody reads any more); Q.K^T of the tile behind the last one runs on stale bytes whose logits nobody consumes - a matrix segment is ONE basic block.
-// pp_flags bit 0: s_setprio 1 for waves 4-7 (the second-dispatched half loses every arbitration at equal priority; item 4 of the guide's section)
+// pp_flags bit 0: s_setprio 1 for waves 4-7 (the second-dispatched half loses every arbitration at equal priority; item 4 of the guide's section); bit 1: per-segment flips
 // ABL (bench only, sdm_bench_attn; 0 in the engine): 1 no softmax VALU, 2 no P.V MFMAs, 4 no Q.K^T MFMAs, 8 no DMAs, 32 no fragment reads
 // ------------------------------------------------------------------------------------------------
+// KE (second build of the DMA form; profiles/r06_attn_pp_dma_ablation.txt: with the DMAs and the K fragment reads inside the matrix segment that segment still
+// paid ~690 cycles per tile pair for DMA issue - a VMEM instruction blocks the issuing wave for 100-185 cycles beside MFMAs and LDS reads - and ~990 for the
+// fragment reads): KE >= 0 moves the DMAs to the head of the SOFTMAX segment (the VALU wave has ~250 cycles of slack per phase) and the ring grows to SIX slots:
+// the DMAs of tile t+4 go out in the softmax segment of tile t (slot of tile t-2: last read by B in phase 2t-1), every matrix segment still ends with the counted
+// vmcnt, so tile t+3 is complete behind the barrier closing phase 2t+3 and readable from A's softmax segment of tile t+2 (phase 2t+5) on.  KE = 1 / 2 also reads
+// the K fragments (+ bias) of the first / both 32-key halves of tile t+1 at the END of the softmax segment, next to the V^T fragments: at KE = 2 a matrix segment
+// is 24 MFMAs and nothing else.  KE = -1: the first DMA build (four slots, everything inside the matrix segment).
 #define ATTN64PP_SLOT (3 * 8192 + 256)
-#define ATTN64PP_SMEM (4 * ATTN64PP_SLOT)
-template <int ABL = 0, int BIAS = 1, int LIST = 1>
+#define ATTN64PP_SMEM (6 * ATTN64PP_SLOT)
+template <int ABL = 0, int BIAS = 1, int LIST = 1, int KE = 0>
 __global__ void __launch_bounds__(512, 2) attn_d64_pp_kernel(AttnParams p) {
   SDM_DYN_SMEM(smem);
   constexpr int SLOT = ATTN64PP_SLOT, KLO = 8192, VOFF = 16384, BOFF = 24576;
+  constexpr int R = KE < 0 ? 4 : 6, D = KE < 0 ? 3 : 4;             // ring slots; a segment of tile t requests tile t + D
   constexpr int NDMA = BIAS ? 4 : 3;                                  // DMAs a wave issues per tile
   const int tid = threadIdx.x, lane = tid & 63, wave = SDM_UNIFORM_I(tid >> 6);
   const int grp = wave >> 2;
@@ -1000,10 +1008,10 @@ __global__ void __launch_bounds__(512, 2) attn_d64_pp_kernel(AttnParams p) {
   };
   auto lds_barrier = [&]() { SDM_SCHED_FENCE(); SDM_WAIT_LGKMCNT0(); SDM_RAW_BARRIER(); SDM_SCHED_FENCE(); };
 
-  // ---- prologue: tiles 0, 1, 2 in LDS; A computes the logits of tile 0 while B waits one interval ----
-  dma(tile_at(0), 0);
-  dma(tile_at(1), 1);
-  dma(tile_at(2), 2);
+  // ---- prologue: tiles 0 .. D-1 in LDS; A computes the logits of tile 0 while B waits one interval ----
+#pragma unroll
+  for (int i = 0; i < D; ++i) dma(tile_at(i), i);
+  int tq = tile_at(D);                                                 // index of the tile the first loop segment requests
   SDM_WAIT_VMCNT0();
   lds_barrier();
   if (grp) {
@@ -1014,39 +1022,50 @@ __global__ void __launch_bounds__(512, 2) attn_d64_pp_kernel(AttnParams p) {
   f16x8 pf[2][2];
   qk(0, s);
   lds_barrier();
+  int bt = 0, b1 = 1, bD = D;                                          // slots of tiles t, t+1, t+D
   for (int t = 0; t < nwalk; ++t) {
-    const int bt = t & 3, b1 = (t + 1) & 3, b3 = (t + 3) & 3;
-    // ---- softmax segment of tile t; the V^T fragments of the same tile (in LDS since the tile before last) are read at its end, so that the matrix segment
-    //      opens with MFMAs instead of an LDS round trip ----
-    int tq;                                                            // index of the tile this iteration's matrix segment requests
+    // ---- softmax segment of tile t.  KE >= 0: it opens with the DMAs of tile t+D.  The V^T fragments of tile t (and, KE >= 1, K fragments / biases of tile
+    //      t+1) are read at its end, so that the matrix segment opens with MFMAs instead of an LDS round trip ----
+    if (p.pp_flags & 2) SDM_SETPRIO(0);                                // (A/B: per-segment priority flips - matrix segments at priority 2)
+    if (KE >= 0) dma(tq, bD);
+    int tqn;                                                           // index of the tile the NEXT request (KE >= 0) / this iteration's matrix segment (KE < 0) asks for
     {
-      int i3 = t + 3; if (i3 > nwalk - 1) i3 = nwalk - 1;
-      if (LIST) SDM_SLOAD_I32(tq, tlp + i3);                           // list walks: a scalar load that lands under the softmax (never a vector load: header)
-      else tq = i0 + i3;
+      int in_ = t + D + (KE >= 0 ? 1 : 0); if (in_ > nwalk - 1) in_ = nwalk - 1;
+      if (LIST) SDM_SLOAD_I32(tqn, tlp + in_);                         // list walks: a scalar load that lands under the softmax (never a vector load: header)
+      else tqn = i0 + in_;
     }
     softmax(s, pf);
     VFrag v0, v1;
+    KFrag k0, k1;
     load_v(bt, 0, v0);
     load_v(bt, 1, v1);
-    if (LIST) SDM_SLOAD_WAIT(tq);
+    if (KE >= 1) { load_bias(b1, s); load_k(b1, 0, k0); }
+    if (KE >= 2) load_k(b1, 1, k1);
+    if (LIST) SDM_SLOAD_WAIT(tqn);
     lds_barrier();
-    // ---- matrix segment: tile t+3 requested into the slot tile t-1 has left; P.V of tile t (operands in registers) while the K fragments / biases of tile
-    //      t+1 arrive; then Q.K^T of tile t+1.  One scheduling region per half ----
-    dma(tq, b3);
-    KFrag k0, k1;
+    // ---- matrix segment: P.V of tile t (operands in registers), then Q.K^T of tile t+1.  KE < 2: the remaining K fragments arrive under the P.V MFMAs;
+    //      KE < 0: tile t+D is requested here ----
+    if (p.pp_flags & 2) SDM_SETPRIO(2);
+    if (KE < 0) dma(tqn, bD);
     mma_v(v0, pf[0]);
     mma_v(v1, pf[1]);
-    load_bias(b1, s);
-    load_k(b1, 0, k0);
-    load_k(b1, 1, k1);
+    if (KE < 1) { load_bias(b1, s); load_k(b1, 0, k0); }
+    if (KE < 2) load_k(b1, 1, k1);
+    if (KE < 1) {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) { SDM_SCHED_GROUP(0x008, 1, 0); SDM_SCHED_GROUP(0x100, 2, 0); SDM_SCHED_GROUP(0x002, 1, 0); }
+      for (int i = 0; i < 12; ++i) { SDM_SCHED_GROUP(0x008, 1, 0); SDM_SCHED_GROUP(0x100, 2, 0); SDM_SCHED_GROUP(0x002, 1, 0); }
+    } else if (KE < 2) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { SDM_SCHED_GROUP(0x008, 1, 0); SDM_SCHED_GROUP(0x100, 1, 0); }
+    }
     SDM_SCHED_FENCE();
     mma_k(k0, s[0]);
     mma_k(k1, s[1]);
     SDM_SCHED_FENCE();
-    if (!(ABL & 8)) { if (BIAS) SDM_WAIT_VMCNT(4); else SDM_WAIT_VMCNT(3); }      // only this segment's own DMAs stay in flight: tile t+2 has landed
+    if (!(ABL & 8)) { if (BIAS) SDM_WAIT_VMCNT(4); else SDM_WAIT_VMCNT(3); }      // only the youngest batch of DMAs stays in flight
     lds_barrier();
+    tq = tqn;
+    bt = b1; b1 = b1 == R - 1 ? 0 : b1 + 1; bD = bD == R - 1 ? 0 : bD + 1;
   }
   if (!grp) lds_barrier();                                             // B's last matrix segment still reads V^T: the epilogue reuses the buffers
   SDM_WAIT_VMCNT0();                                                   // (the clamped DMAs of the last segments still write their slots)

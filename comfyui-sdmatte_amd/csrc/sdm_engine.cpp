@@ -122,7 +122,7 @@ static OptEntry g_opts[] = {
   {"attn_nw", 0, 0, "waves per d=64 attention block: 0 by launch size, 4, 8"},
   {"attn_pipe", 1, 1, "8-wave split-precision d=64 attention: two-tile software pipeline"},
   {"attn_pipe4", 1, 1, "the same pipeline for the 4-wave launches (two K / three V^T buffers)"},
-  {"attn_pp", 1, 1, "split-precision d=64 attention with fp32 output as a ping-pong of the block's wave halves (attn_d64_pp_kernel, 256 query rows per block): 0 off, 1 on, 2 on without the static priority of the younger half"},
+  {"attn_pp", 1, 1, "split-precision d=64 attention with fp32 output as a ping-pong of the block's wave halves (attn_d64_pp_kernel, 256 query rows per block): 0 off, 1 on, 2 on without the static priority of the younger half, 3 on with per-segment priority flips"},
   {"attn_ksplit", 0, 0, "key split of the d=64 split-precision attention: 0 by launch size (blocks that do not fill the chip's block slots a whole number of times), 1 off, 2 / 4 forced"},
   {"precise_mask", -1, -1, "stages in split precision (-1 = the config's own mask; per-stage attribution experiments; read at sdm_create)"},
 };
@@ -1386,7 +1386,7 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
         // 8-wave blocks with fp32 output (the engine's level-0 attentions): the two-tile software pipeline of the kernel (k_attn.h,
         // attn_d64_pipe_kernel: same arithmetic, bit-identical results, -9 % kernel time); option attn_pipe = 0 selects the plain form.
         const bool pipe8 = opt("attn_pipe") != 0, pipe4 = opt("attn_pipe4") != 0;
-        if (pp) { count_kernel("attn_d64_pp"); p.pp_flags = opt("attn_pp") == 1 ? 1 : 0; const bool pb = p.bias != nullptr;
+        if (pp) { count_kernel("attn_d64_pp"); p.pp_flags = opt("attn_pp") == 1 ? 1 : (opt("attn_pp") == 3 ? 2 : 0); const bool pb = p.bias != nullptr;
           if (p.tiles && pb) { auto kp = attn_d64_pp_kernel<0, 1, 1>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, gy, 1), dim3(512), ATTN64PP_SMEM, e->stream, p); }
           else if (pb) { auto kp = attn_d64_pp_kernel<0, 1, 0>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, gy, 1), dim3(512), ATTN64PP_SMEM, e->stream, p); }
           else { auto kp = attn_d64_pp_kernel<0, 0, 0>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk, gy, 1), dim3(512), ATTN64PP_SMEM, e->stream, p); } }
@@ -3072,9 +3072,13 @@ float sdm_bench_attn(sdm_ctx* e, int B, int heads, int Lq, int Lk, int qt, int a
     if (i == 1) (void)hipEventRecord(e0, (hipStream_t)e->stream);
     if (qt & 16) {      // bit 16: the ping-pong kernel (pair planes as the engine's self- and cross-attentions), ablate = its compile-time ABL mask
       p.pp_flags = (qt & 32) ? 0 : 1;
+      if (qt & 128) p.pp_flags |= 2;
 #define SDM_PP_ABL(A) case A: { auto kp = attn_d64_pp_kernel<A, 0, 0>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk), dim3(512), ATTN64PP_SMEM, e->stream, p); } break;
-      switch (ablate) { SDM_PP_ABL(0) SDM_PP_ABL(1) SDM_PP_ABL(6) SDM_PP_ABL(7) SDM_PP_ABL(8) SDM_PP_ABL(24) SDM_PP_ABL(32) SDM_PP_ABL(56) SDM_PP_ABL(63) default: break; }
+#define SDM_PP_KE(K, V) case V: { auto kp = attn_d64_pp_kernel<0, 0, 0, K>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk), dim3(512), ATTN64PP_SMEM, e->stream, p); } break;
+      switch (ablate) { SDM_PP_ABL(0) SDM_PP_ABL(1) SDM_PP_ABL(6) SDM_PP_ABL(7) SDM_PP_ABL(8) SDM_PP_ABL(32) SDM_PP_ABL(56) SDM_PP_ABL(63)
+                        SDM_PP_KE(-1, 100) SDM_PP_KE(2, 101) SDM_PP_KE(1, 102) default: break; }      // 100-102: the other fragment / DMA placements (KE), no ablation
 #undef SDM_PP_ABL
+#undef SDM_PP_KE
     }
     else if (prec && (qt & 8) && nw8) { auto kp = attn_d64_kernel<1, 2, 8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk), dim3(512), ATTN64P_SMEM, e->stream, p); }      // bit 8: P.V on plain fp16
     else if (prec && (qt & 8)) { auto kp = attn_d64_kernel<1, 2, 4>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk), dim3(256), ATTN64P_SMEM, e->stream, p); }

@@ -8,13 +8,15 @@ from comfyui_sdmatte_amd.engine import Engine
 from comfyui_sdmatte_amd.config import SDMatteConfig
 eng = Engine(SDMatteConfig.tiny(), 0, precision="fp16x3")
 names = {0: "full", 1: "no softmax VALU", 6: "no MFMAs", 7: "no MFMAs, no softmax (DMAs + fragment reads + barriers)", 8: "no DMAs", 24: "no DMAs (24)",
-         32: "no fragment reads", 56: "no DMAs / fragment reads (MFMAs + softmax + barriers)", 63: "barriers only"}
+         32: "no fragment reads", 56: "no DMAs / fragment reads (MFMAs + softmax + barriers)", 63: "barriers only",
+         100: "KE = -1: four slots, DMAs + K reads inside the matrix segment (first DMA build)", 101: "KE = 2: DMAs AND every K read in the softmax segment",
+         102: "KE = 1: + first K half read in the softmax segment"}
 for (B, h, Lq, Lk) in [(4, 5, 16384, 16384), (4, 10, 4096, 16384)]:
     fl = 4.0 * B * h * Lq * Lk * 64
     tiles = (Lk // 64)
-    for prio in (0, 32):
-        print(f"B={B} h={h} Lq={Lq} Lk={Lk} " + ("static priority for waves 4-7" if prio == 0 else "equal priorities"))
-        for ab in (0, 0, 1, 6, 7, 8, 32, 56, 63):
+    for prio in (0, 32, 128):
+        print(f"B={B} h={h} Lq={Lq} Lk={Lk} " + {0: "static priority for waves 4-7", 32: "equal priorities", 128: "per-segment priority flips (matrix segments at 2)"}[prio])
+        for ab in (0, 0, 100, 101, 102, 1, 6, 7, 8, 32, 56, 63):
             ms = eng.bench_attn(B, h, Lq, Lk, qt=22 | prio, ablate=ab, iters=5)
             # cycles per (tile, block) at a nominal 2.1 GHz: blocks per CU = B*h*Lq/256/256
             rounds = B * h * Lq / 256 / 256
