@@ -39,7 +39,7 @@ with open(sys.argv[5], "w", newline="") as fh:
         w.writerow([k, n, "" if b is None else f"{b:.4f}", f"{c.get('SQ_BUSY_CYCLES', 0.0) / 32.0 / n:.0f}",
                     f"{c.get('GRBM_GUI_ACTIVE', 0.0) / 8.0 / n:.0f}" if "GRBM_GUI_ACTIVE" in c else ""] + [c.get(x, 0.0) for x in counters])
 
-FAM = {"conv3x3": "conv_mfma_kernel<9", "gemm": "conv_mfma_kernel<1", "attn_d64": "attn_d64_", "attn_d512": "attn_d512_kernel"}
+FAM = {"conv3x3": ("conv_mfma_kernel<9",), "gemm": ("conv_mfma_kernel<1", "gemm_p3_kernel"), "attn_d64": ("attn_d64_",), "attn_d512": ("attn_d512_kernel",)}
 out = {"batch_per_gpu": int(sys.argv[2]), "inference_size": int(sys.argv[3]), "precision": sys.argv[4],
        "note": "matrix-pipe busy fraction per kernel family = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x SQ_BUSY_CYCLES / 32), summed over every "
                "dispatch of the family in a `bench.py --timed-only` run"}
@@ -47,7 +47,7 @@ for name, key in FAM.items():
     agg = collections.defaultdict(float)
     n = 0
     for k, c in rows.items():
-        if key in k:
+        if any(x in k for x in key):
             n += len(disp[k])
             for x, v in c.items():
                 agg[x] += v

@@ -5,9 +5,9 @@ step), so total / steps / launches-per-step is the average launch duration of a 
 usage: python tools/rocprof_stats_summary.py <kernel_stats.csv> <steps_in_run> > profiles/rNN_rocprofv3_family_summary.txt"""
 import csv, sys, collections
 
-FAMILIES = [("conv3x3 (conv_mfma_kernel<9,...>)", "conv_mfma_kernel<9"), ("gemm / 1x1 (conv_mfma_kernel<1,...>)", "conv_mfma_kernel<1"),
+FAMILIES = [("conv3x3 (conv_mfma_kernel<9,...>)", "conv_mfma_kernel<9"), ("gemm / 1x1 (conv_mfma_kernel<1,...>)", "conv_mfma_kernel<1"), ("gemm, plane-fed (gemm_p3_kernel)", "gemm_p3_kernel"),
             ("attn_d64 (incl. the pipeline kernels)", "attn_d64_"), ("attn_d512", "attn_d512_kernel"), ("transpose_v", "transpose_v_kernel"),
-            ("gn_stats / partials", "gn_"), ("layernorm", "layernorm_kernel")]
+            ("gn_stats / partials", "gn_"), ("layernorm", "layernorm_")]
 steps = int(sys.argv[2])
 agg = collections.OrderedDict((f[0], [0, 0.0]) for f in FAMILIES)
 other = [0, 0.0]
