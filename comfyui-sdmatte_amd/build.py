@@ -70,12 +70,15 @@ def build_all(verbose=False, force=False, extra_flags=(), out=None):
         if not asm:
             raise RuntimeError("device assembly not found behind -save-temps: cannot check the asynchronous loads of the F8 conv kernel")
         with open(os.path.join(tmp, asm[0])) as fh:
-            checked, problems = check_async_loads.check(fh.read())
+            asm_text = fh.read()
+            checked, problems = check_async_loads.check(asm_text)
+            c2, p2 = check_async_loads.check_scalar_loads(asm_text)      # the ping-pong attention kernels' scalar loads (tile-list entries through inline asm)
+            checked, problems = checked + c2, problems + p2
         if problems:
             sys.stderr.write("\n".join(problems) + "\n")
             raise RuntimeError("F8 conv kernel: an asynchronously loaded register is touched before its hand-over (check_async_loads.py)")
         if verbose:
-            print(f"[sdmatte] {checked} asynchronous loads of the F8 conv kernels checked")
+            print(f"[sdmatte] {checked} asynchronous loads checked (F8 conv kernels: vector loads; ping-pong attention kernels: scalar loads)")
         shutil.move(tlib, lib)
     # a kernel whose body the HOST pass rejects (e.g. inline asm that is only valid for gfx950) is dropped without a diagnostic and leaves
     # an undefined stub symbol: load the library once so that this fails here, in the build container, and not on the GPU box

@@ -181,8 +181,75 @@ def check(asm_text, verbose=False):
     return checked, problems
 
 
+# ---- second guard: scalar loads issued through inline asm (sdm_common.h SDM_SLOAD_I32: the tile-list entries of attn_d64_pp_kernel, which cannot afford a vector load
+#      beside its LDS-DMAs).  For hipcc the result exists as soon as the asm statement has executed; nothing but the operand tie of SDM_SLOAD_WAIT keeps a use - or a
+#      register shuffle (s_mov) at a block edge - behind the s_waitcnt.  Checked here for EVERY s_load_dword of the kernels named below (the compiler's own loads
+#      satisfy the rule by construction): along every path from the load, no instruction may read or overwrite a destination SGPR before an s_waitcnt that drains lgkmcnt.
+SCALAR_KERNEL_RE = re.compile(r"^(_Z18attn_d64_pp_kernelI[A-Za-z0-9_]*EEv10AttnParams):")
+_SREG = re.compile(r"\bs\[(\d+):(\d+)\]|\bs(\d+)\b")
+
+
+def _sregs(tok):
+    out = set()
+    for m in _SREG.finditer(tok):
+        if m.group(3) is not None:
+            out.add(int(m.group(3)))
+        else:
+            out |= set(range(int(m.group(1)), int(m.group(2)) + 1))
+    return out
+
+
+def check_scalar_loads(asm_text, verbose=False):
+    lines = asm_text.split("\n")
+    problems, checked = [], 0
+    keys = [m.group(1) for m in (SCALAR_KERNEL_RE.match(l) for l in lines) if m]
+    for key in keys:
+        st = [i for i, l in enumerate(lines) if l.startswith(key + ":")]
+        en = [i for i, l in enumerate(lines) if ".amdhsa_kernel " + key in l]
+        if not st or not en:
+            problems.append(f"{key}: kernel body not found in the assembly")
+            continue
+        K, labels = _parse(lines[st[0] + 1:en[0]])
+        for i, t in enumerate(K):
+            if not t.startswith(("s_load_dword", "s_buffer_load_dword")):
+                continue
+            R = _sregs(t.split(None, 1)[1].split(",")[0])
+            checked += 1
+            seen, stack, bad = set(), [i + 1], None
+            while stack and bad is None:
+                j = stack.pop()
+                while j < len(K):
+                    if j in seen:
+                        break
+                    seen.add(j)
+                    u = K[j]
+                    if u.startswith("s_endpgm") or (u.startswith("s_waitcnt") and re.search(r"lgkmcnt\(0\)", u)):
+                        break
+                    if u.startswith("s_waitcnt") and "lgkmcnt" not in u and "vmcnt" not in u and "expcnt" not in u:      # s_waitcnt <imm>: assume it drains
+                        break
+                    args = u.split(None, 1)[1] if " " in u else ""
+                    if _sregs(args) & R:
+                        bad = u
+                        break
+                    if u.startswith(("s_branch", "s_cbranch")):
+                        tgt = labels.get(_branch_target(u))
+                        if tgt is not None:
+                            stack.append(tgt)
+                        if u.startswith("s_branch"):
+                            break
+                    j += 1
+            if bad is not None:
+                problems.append(f"{key[:70]}: `{t[:60]}` -> `{bad[:60]}` touches the destination before an s_waitcnt lgkmcnt(0)")
+            elif verbose:
+                print(f"ok: {key[:40]} {t[:60]}")
+    return checked, problems
+
+
 if __name__ == "__main__":
     checked, problems = check(open(sys.argv[1]).read(), verbose="-v" in sys.argv)
+    c2, p2 = check_scalar_loads(open(sys.argv[1]).read(), verbose="-v" in sys.argv)
+    checked += c2
+    problems += p2
     for p in problems:
         print("VIOLATION:", p)
     print(f"{checked} asynchronous loads checked, {len(problems)} problem(s)")

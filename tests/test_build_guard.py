@@ -96,3 +96,21 @@ def test_guard_exit_walk_takes_both_branch_successors_and_stops_at_a_drained_cou
     counted = ["\ts_waitcnt vmcnt(2)", "\tv_mov_b32_e32 v160, v31"]
     checked, problems = G.check(_asm(lambda k: [], exit_extra=counted))
     assert problems
+
+
+def test_scalar_load_guard():
+    """inline-asm scalar loads of the ping-pong attention kernels (SDM_SLOAD_I32): the destination SGPR may not be read or rewritten before an s_waitcnt that drains
+    lgkmcnt - along every path (a register shuffle at a block edge would copy a value that has not arrived)"""
+    name = "_Z18attn_d64_pp_kernelILi0ELi1ELi1ELi0EEv10AttnParams"
+
+    def asm(between):
+        return "\n".join([name + ":", "\ts_load_dword s53, s[54:55], 0x0"] + between + ["\ts_waitcnt lgkmcnt(0)", "\ts_add_i32 s4, s53, 1", "\ts_endpgm", "\t.amdhsa_kernel " + name])
+    checked, problems = G.check_scalar_loads(asm(["\tv_add_f32_e32 v1, v2, v3", "\ts_cbranch_vccz .LBB1_2", "\tv_mul_f32_e32 v1, v1, v1", ".LBB1_2:"]))
+    assert checked == 1 and not problems, problems
+    checked, problems = G.check_scalar_loads(asm(["\ts_mov_b32 s60, s53"]))                       # the shuffle: a copy of a value still in flight
+    assert problems
+    checked, problems = G.check_scalar_loads(asm(["\ts_cbranch_vccz .LBB1_2", "\ts_branch .LBB1_3", ".LBB1_2:", "\ts_lshl_b32 s53, s53, 2", ".LBB1_3:"]))      # on one side of a branch only
+    assert problems
+    checked, problems = G.check_scalar_loads(asm(["\ts_waitcnt vmcnt(0)", "\ts_mov_b32 s60, s53"]))      # a vector-memory wait does not cover it
+    assert problems
+    assert G.check_scalar_loads("_Zother:\n\ts_load_dword s1, s[2:3], 0x0\n\ts_mov_b32 s4, s1\n\ts_endpgm\n\t.amdhsa_kernel _Zother\n") == (0, [])
