@@ -820,7 +820,7 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_pipe_kernel(AttnParams p)
 // is 24 MFMAs and nothing else.  KE = -1: the first DMA build (four slots, everything inside the matrix segment).
 #define ATTN64PP_SLOT (3 * 8192 + 256)
 #define ATTN64PP_SMEM (6 * ATTN64PP_SLOT)
-template <int ABL = 0, int BIAS = 1, int LIST = 1, int KE = 0>
+template <int ABL = 0, int BIAS = 1, int LIST = 1, int KE = 0, int DS = 1, int OB = 1>
 __global__ void __launch_bounds__(512, 2) attn_d64_pp_kernel(AttnParams p) {
   SDM_DYN_SMEM(smem);
   constexpr int SLOT = ATTN64PP_SLOT, KLO = 8192, VOFF = 16384, BOFF = 24576;
@@ -881,14 +881,19 @@ __global__ void __launch_bounds__(512, 2) attn_d64_pp_kernel(AttnParams p) {
   const unsigned int voffV = (unsigned int)(rho * p.ldvt * 2 + csrc * 16);
   const int lr = lane & 31;
   const unsigned int voffB = (unsigned int)(((lane & 32) + ((lr & 0x13) | (((lr >> 2) & 1) << 3) | (((lr >> 3) & 1) << 2))) * 4);
-  auto dma = [&](int tile, int slot) {
+  // the DMAs of one tile in issue order: V^T, [bias,] K pair plane, K_hi; `from` .. `to` selects a part of them (DS of them go out at the head of the softmax
+  // segment, the rest at the END of the matrix segment - where the wave would otherwise sit at the barrier: a DMA instruction costs the issuing wave ~100-130 cycles)
+  auto dma = [&](int tile, int slot, int from = 0, int to = 4) {
     if (ABL & 8) return;
     unsigned char* sb = smem + slot * SLOT + wave * 1024;
     const unsigned int k0 = (unsigned int)tile * 64u;
-    sdm_glds16_buf(rsK, voffK, k0 * (unsigned int)(p.ldk * 2), sb);
-    sdm_glds16_buf(rsK8, voffK, k0 * (unsigned int)(p.ldk * 2), sb + KLO);
-    sdm_glds16_buf(rsV, voffV, k0 * 2u, sb + VOFF);
-    if (BIAS) sdm_glds4_buf(rsB, voffB, k0 * 4u, smem + slot * SLOT + BOFF);      // (every wave writes the same 256 bytes: one DMA count for all waves)
+    int i = 0;
+    if (i >= from && i < to) sdm_glds16_buf(rsV, voffV, k0 * 2u, sb + VOFF);
+    ++i;
+    if (BIAS) { if (i >= from && i < to) sdm_glds4_buf(rsB, voffB, k0 * 4u, smem + slot * SLOT + BOFF); ++i; }      // (every wave writes the same 256 bytes: one DMA count for all waves)
+    if (i >= from && i < to) sdm_glds16_buf(rsK8, voffK, k0 * (unsigned int)(p.ldk * 2), sb + KLO);
+    ++i;
+    if (i >= from && i < to) sdm_glds16_buf(rsK, voffK, k0 * (unsigned int)(p.ldk * 2), sb);
   };
   // ---- fragment side: row l31 of a 32-row half, chunk (2 ks + hi) etc. at position chunk ^ ((l31 >> 1) & 7) - the XOR folds into the lane's base offset
   const int kxor = (l31 >> 1) & 7;
@@ -962,8 +967,9 @@ __global__ void __launch_bounds__(512, 2) attn_d64_pp_kernel(AttnParams p) {
   };
   // softmax of one tile: logits -> fp16 probabilities in B-operand layout; running maximum, rescale of O^T / the denominators when it moved.  Everything is
   // pinned inside the segment (the probabilities are only consumed by the NEXT segment's MFMAs: left alone, the sub / exp / pack stream sinks behind the barrier)
-  auto softmax = [&](f32x16 (&s)[2], f16x8 (&pf)[2][2]) {
+  auto softmax = [&](f32x16 (&s)[2], f16x8 (&pf)[2][2], auto&& after_max) {
     if (ABL & 1) {
+      after_max();
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -994,6 +1000,7 @@ __global__ void __launch_bounds__(512, 2) attn_d64_pp_kernel(AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
     }
+    after_max();      // the fragment reads of the coming matrix segment go out HERE: they land under the 33 exponentials instead of in front of the barrier (220 cycles)
     // (the 32 subtractions as 16 v_pk_add_f32 were measured: +7-9 % kernel time - packed fp32 shares the wide datapath with the partner wave's MFMAs,
     //  profiles/r06_attn_pp_packed_sub_ab.txt)
 #pragma unroll
@@ -1016,35 +1023,51 @@ __global__ void __launch_bounds__(512, 2) attn_d64_pp_kernel(AttnParams p) {
   int tq = tile_at(D);                                                 // index of the tile the first loop segment requests
   SDM_WAIT_VMCNT0();
   lds_barrier();
-  if (grp) {
-    if (p.pp_flags & 1) SDM_SETPRIO(1);
-    lds_barrier();
-  }
+  // OB = 1 (ONE barrier per tile and wave): half A passes its barrier behind the softmax segment, half B behind the matrix segment - the two meet once per tile
+  // period, A then runs [matrix(t), softmax(t+1)] while B runs [softmax(t), matrix(t)].  The segment trace (profiles/r06_attn_pp_segment_trace.txt) showed what two
+  // barriers per tile cost: ~150 cycles of barrier latency each, and every phase as long as its LONGER segment (softmax ~1 400 incl. DMA issue, matrix ~1 100).
+  // DMAs (all at the head of the softmax segment) and waits: the DMAs of tile t+4 go out in front of softmax(t) (slot of tile t-2: its last reader, B's matrix
+  // segment, lies two barriers back for either half); before its barrier every wave leaves only its two youngest batches in flight, so whatever a half reads behind
+  // a barrier (K of tile t+1 in matrix(t), V^T of tile t+1 in softmax(t+1)) has landed on both halves' side.
+  if (!OB) {
+    if (grp) {
+      if (p.pp_flags & 1) SDM_SETPRIO(1);
+      lds_barrier();
+    }
+  } else if (grp && (p.pp_flags & 1)) SDM_SETPRIO(1);
   f32x16 s[2];
   f16x8 pf[2][2];
   qk(0, s);
-  lds_barrier();
+  if (!OB || grp) lds_barrier();                                       // OB: B falls one half period behind here (pairs with A's barrier behind softmax(0))
+  // ABL & 64 (bench only): segment stamps of waves 0 and 4 of block 0 - [softmax done | barrier passed | matrix done | barrier passed] per tile, s_memtime at points
+  // where lgkmcnt is drained anyway - in the LDS above the ring, copied to the output buffer at the end (sdm_bench_attn prints the averages)
+  unsigned long long* trc = (unsigned long long*)(smem + R * SLOT) + (wave >> 2) * (8 * 28);
+  const bool tracing = (ABL & 64) && blockIdx.x == 0 && (wave & 3) == 0;
+  auto stamp = [&](int t, int k) { if ((ABL & 64) && tracing && t < 28 && lane == 0) trc[t * 8 + k] = __builtin_readcyclecounter(); };
   int bt = 0, b1 = 1, bD = D;                                          // slots of tiles t, t+1, t+D
   for (int t = 0; t < nwalk; ++t) {
     // ---- softmax segment of tile t.  KE >= 0: it opens with the DMAs of tile t+D.  The V^T fragments of tile t (and, KE >= 1, K fragments / biases of tile
     //      t+1) are read at its end, so that the matrix segment opens with MFMAs instead of an LDS round trip ----
     if (p.pp_flags & 2) SDM_SETPRIO(0);                                // (A/B: per-segment priority flips - matrix segments at priority 2)
-    if (KE >= 0) dma(tq, bD);
+    if (KE >= 0) dma(tq, bD, 0, OB ? NDMA : DS);
     int tqn;                                                           // index of the tile the NEXT request (KE >= 0) / this iteration's matrix segment (KE < 0) asks for
     {
       int in_ = t + D + (KE >= 0 ? 1 : 0); if (in_ > nwalk - 1) in_ = nwalk - 1;
       if (LIST) SDM_SLOAD_I32(tqn, tlp + in_);                         // list walks: a scalar load that lands under the softmax (never a vector load: header)
       else tqn = i0 + in_;
     }
-    softmax(s, pf);
+    if (ABL & 64) stamp(t, 4);                                         // (DMAs issued)
     VFrag v0, v1;
     KFrag k0, k1;
-    load_v(bt, 0, v0);
-    load_v(bt, 1, v1);
+    softmax(s, pf, [&]() { load_v(bt, 0, v0); load_v(bt, 1, v1); });
+    if (ABL & 64) stamp(t, 5);                                         // (softmax VALU done: the probabilities are pinned in front of this point)
     if (KE >= 1) { load_bias(b1, s); load_k(b1, 0, k0); }
     if (KE >= 2) load_k(b1, 1, k1);
     if (LIST) SDM_SLOAD_WAIT(tqn);
-    lds_barrier();
+    if (ABL & 64) { SDM_WAIT_LGKMCNT0(); stamp(t, 0); }
+    if (!OB) lds_barrier();
+    else if (!grp) { if (!(ABL & 8)) { if (BIAS) SDM_WAIT_VMCNT(8); else SDM_WAIT_VMCNT(6); } lds_barrier(); }
+    if (ABL & 64) stamp(t, 1);
     // ---- matrix segment: P.V of tile t (operands in registers), then Q.K^T of tile t+1.  KE < 2: the remaining K fragments arrive under the P.V MFMAs;
     //      KE < 0: tile t+D is requested here ----
     if (p.pp_flags & 2) SDM_SETPRIO(2);
@@ -1064,14 +1087,29 @@ __global__ void __launch_bounds__(512, 2) attn_d64_pp_kernel(AttnParams p) {
     mma_k(k0, s[0]);
     mma_k(k1, s[1]);
     SDM_SCHED_FENCE();
-    if (!(ABL & 8)) { if (BIAS) SDM_WAIT_VMCNT(4); else SDM_WAIT_VMCNT(3); }      // only the youngest batch of DMAs stays in flight
-    lds_barrier();
+    // tile t+2 (requested two tiles ago) must have landed; the whole batch of tile t+3 and the early part of tile t+4 may stay in flight; then the late part of
+    // tile t+4 goes out (KE >= 0) - in the time this wave would wait for its partner's softmax segment anyway
+    if (!(ABL & 8) && !OB) {
+      if (KE < 0) { if (BIAS) SDM_WAIT_VMCNT(4); else SDM_WAIT_VMCNT(3); }
+      else if (NDMA + DS == 3) SDM_WAIT_VMCNT(3); else if (NDMA + DS == 4) SDM_WAIT_VMCNT(4); else if (NDMA + DS == 5) SDM_WAIT_VMCNT(5);
+      else if (NDMA + DS == 6) SDM_WAIT_VMCNT(6); else if (NDMA + DS == 7) SDM_WAIT_VMCNT(7); else SDM_WAIT_VMCNT(8);
+    }
+    if (KE >= 0 && !OB) dma(tq, bD, DS, NDMA);
+    if (ABL & 64) { asm volatile("s_nop 0" :: "v"(s[0][0]), "v"(s[1][15])); SDM_WAIT_LGKMCNT0(); stamp(t, 2); }      // (the stamp waits for the last MFMA's result)
+    if (!OB) lds_barrier();
+    else if (grp) { if (!(ABL & 8)) { if (BIAS) SDM_WAIT_VMCNT(8); else SDM_WAIT_VMCNT(6); } lds_barrier(); }
+    if (ABL & 64) stamp(t, 3);
     tq = tqn;
     bt = b1; b1 = b1 == R - 1 ? 0 : b1 + 1; bD = bD == R - 1 ? 0 : bD + 1;
   }
   if (!grp) lds_barrier();                                             // B's last matrix segment still reads V^T: the epilogue reuses the buffers
   SDM_WAIT_VMCNT0();                                                   // (the clamped DMAs of the last segments still write their slots)
   lds_barrier();
+  if ((ABL & 64) && blockIdx.x == 0) {                                 // trace -> 3584 bytes behind the output buffer (the bench reads them back)
+    const unsigned long long* tr0 = (const unsigned long long*)(smem + R * SLOT);
+    for (int i = tid; i < 2 * 8 * 28; i += 512) ((unsigned long long*)p.part_ml)[i] = tr0[i];      // (bench: part_ml points behind the output)
+    __syncthreads();
+  }
 
   // epilogue (fp32 output): per-wave staging [32 q][64 d] at pitch 272 B -> coalesced 16-byte row stores
   constexpr int PS = 272;

@@ -3045,7 +3045,7 @@ float sdm_bench_attn(sdm_ctx* e, int B, int heads, int Lq, int Lk, int qt, int a
   const int prec = (qt & 2) ? 1 : 0, nw8 = (qt & 4) ? 1 : 0;          // qt bits: 2 = split-precision variant (hi | lo planes, fp32 output), 4 = 8-wave blocks
   void *q = nullptr, *k = nullptr, *vt = nullptr, *o = nullptr;
   if (dev_malloc(&q, (size_t)B * Lq * C * 2 * (1 + prec)) || dev_malloc(&k, (size_t)B * Lk * C * 2 * (1 + prec)) ||
-      dev_malloc(&vt, (size_t)B * heads * 64 * ldvt * 2 * (1 + prec)) || dev_malloc(&o, (size_t)B * Lq * C * (prec ? 4 : 2))) return -2.f;
+      dev_malloc(&vt, (size_t)B * heads * 64 * ldvt * 2 * (1 + prec)) || dev_malloc(&o, (size_t)B * Lq * C * (prec ? 4 : 2) + 4096)) return -2.f;
   if (prec) {
     SDM_LAUNCH(fill_random_f16_kernel, dim3(4096), dim3(256), 0, e->stream, (half_t*)q + (size_t)B * Lq * C, (long)B * Lq * C, 13u, 0.0003f);
     SDM_LAUNCH(fill_random_f16_kernel, dim3(4096), dim3(256), 0, e->stream, (half_t*)k + (size_t)B * Lk * C, (long)B * Lk * C, 17u, 0.0003f);
@@ -3072,13 +3072,17 @@ float sdm_bench_attn(sdm_ctx* e, int B, int heads, int Lq, int Lk, int qt, int a
     if (i == 1) (void)hipEventRecord(e0, (hipStream_t)e->stream);
     if (qt & 16) {      // bit 16: the ping-pong kernel (pair planes as the engine's self- and cross-attentions), ablate = its compile-time ABL mask
       p.pp_flags = (qt & 32) ? 0 : 1;
+      p.part_ml = (float*)((unsigned char*)o + (size_t)B * Lq * C * 4);      // (ablate 64: the segment trace lands behind the output)
       if (qt & 128) p.pp_flags |= 2;
-#define SDM_PP_ABL(A) case A: { auto kp = attn_d64_pp_kernel<A, 0, 0>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk), dim3(512), ATTN64PP_SMEM, e->stream, p); } break;
-#define SDM_PP_KE(K, V) case V: { auto kp = attn_d64_pp_kernel<0, 0, 0, K>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk), dim3(512), ATTN64PP_SMEM, e->stream, p); } break;
+#define SDM_PP_ABL(A) case A: { auto kp = attn_d64_pp_kernel<A, 0, 0>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk), dim3(512), ATTN64PP_SMEM + 4096, e->stream, p); } break;
+#define SDM_PP_DS(A, S, V) case V: { auto kp = attn_d64_pp_kernel<A, 0, 0, 0, S, 0>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk), dim3(512), ATTN64PP_SMEM + 4096, e->stream, p); } break;
+#define SDM_PP_KE(K, V) case V: { auto kp = attn_d64_pp_kernel<0, 0, 0, K, 1, 0>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk), dim3(512), ATTN64PP_SMEM, e->stream, p); } break;
       switch (ablate) { SDM_PP_ABL(0) SDM_PP_ABL(1) SDM_PP_ABL(6) SDM_PP_ABL(7) SDM_PP_ABL(8) SDM_PP_ABL(32) SDM_PP_ABL(56) SDM_PP_ABL(63)
-                        SDM_PP_KE(-1, 100) SDM_PP_KE(2, 101) SDM_PP_KE(1, 102) default: break; }      // 100-102: the other fragment / DMA placements (KE), no ablation
+                        SDM_PP_KE(-1, 100) SDM_PP_KE(2, 101) SDM_PP_KE(1, 102) SDM_PP_ABL(64)
+                        SDM_PP_DS(0, 0, 110) SDM_PP_DS(0, 1, 111) SDM_PP_DS(0, 2, 112) SDM_PP_DS(0, 3, 113) SDM_PP_DS(64, 0, 114) SDM_PP_DS(64, 2, 116) SDM_PP_DS(64, 3, 117) default: break; }      // 100-102: the other fragment / DMA placements (KE), no ablation
 #undef SDM_PP_ABL
 #undef SDM_PP_KE
+#undef SDM_PP_DS
     }
     else if (prec && (qt & 8) && nw8) { auto kp = attn_d64_kernel<1, 2, 8>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk), dim3(512), ATTN64P_SMEM, e->stream, p); }      // bit 8: P.V on plain fp16
     else if (prec && (qt & 8)) { auto kp = attn_d64_kernel<1, 2, 4>; SDM_SET_SMEM(kp, 160 * 1024); SDM_LAUNCH(kp, dim3(nblk), dim3(256), ATTN64P_SMEM, e->stream, p); }
@@ -3092,6 +3096,20 @@ float sdm_bench_attn(sdm_ctx* e, int B, int heads, int Lq, int Lk, int qt, int a
   float ms = 0.f;
   (void)hipEventElapsedTime(&ms, e0, e1);
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if ((qt & 16) && (ablate == 64 || (ablate >= 114 && ablate <= 117))) {      // segment stamps of waves 0 (half A) and 4 (half B) of block 0: averages over tiles 4 .. 51 of the last launch
+    std::vector<unsigned long long> tr(2 * 8 * 28);
+    (void)hipMemcpy(tr.data(), (unsigned char*)o + (size_t)B * Lq * C * 4, tr.size() * 8, hipMemcpyDeviceToHost);
+    for (int g = 0; g < 2; ++g) {
+      double dm = 0, sm = 0, vr = 0, wa = 0, mx = 0, wb = 0; int n = 0;
+      for (int t = 5; t < 27; ++t) {
+        const unsigned long long* c = &tr[(size_t)g * 224 + (size_t)t * 8];
+        const unsigned long long prev3 = tr[(size_t)g * 224 + (size_t)(t - 1) * 8 + 3];
+        dm += (double)(c[4] - prev3); sm += (double)(c[5] - c[4]); vr += (double)(c[0] - c[5]); wa += (double)(c[1] - c[0]); mx += (double)(c[2] - c[1]); wb += (double)(c[3] - c[2]); ++n;
+      }
+      fprintf(stderr, "[attn_pp trace] wave %d: DMA issue %.0f | softmax VALU %.0f | V^T reads + lgkmcnt(0) %.0f | wait at barrier %.0f | matrix segment %.0f | wait at barrier %.0f  (cycles per tile, mean of %d tiles; each stamp costs an s_memtime round trip)\n",
+              g * 4, dm / n, sm / n, vr / n, wa / n, mx / n, wb / n, n);
+    }
+  }
   dev_free(q); dev_free(k); dev_free(vt); dev_free(o);
   return ms / (float)iters;
 #endif
