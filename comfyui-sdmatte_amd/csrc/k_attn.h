@@ -785,39 +785,40 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_d64_pipe_kernel(AttnParams p)
 }
 
 // ------------------------------------------------------------------------------------------------
-// PING-PONG of the block's two wave halves (round 6; engine option attn_pp): waves 0-3 ("A", one per SIMD) and waves 4-7 ("B", their SIMD partners) run
-// the SAME instruction sequence - [softmax of tile t] barrier [P.V of tile t, Q.K^T of tile t+1] barrier - with B one barrier interval behind A, so that at
-// any time every SIMD holds one wave in its matrix segment (24 back-to-back MFMAs = 896 pipe cycles) and one wave in its softmax segment (max / sub / 33
-// v_exp_f32 / pack: ~100 VALU issues).  In attn_d64_pipe_kernel both waves of a SIMD are in the same phase (one barrier per tile): the SQ counters put the
-// matrix pipe at 0.53 busy with VALU issue active 0.48 of the time - the two pipes ran in SUM, not in MAX (profiles/r06_attn_sq_counters.txt).
-// MI355X_MICROARCH.md "Two waves per SIMD": complementary segments (matrix beside VALU / memory) are what nets.
-//   phase n:      0        1            2               3               4         ...
-//   A (0-3):    QK(0)   softmax(0)   PV(0) QK(1)     softmax(1)      PV(1) QK(2)
-//   B (4-7):     -       QK(0)       softmax(0)      PV(0) QK(1)     softmax(1)
-// Compile-time ablations of the first build (register-staged tiles; profiles/r06_attn_pp_ablation.txt): MFMAs + softmax + barriers alone take 1837 cycles per
-// tile pair - the matrix-pipe floor is 1792 - but the full kernel 3550: global loads into registers 750, LDS staging writes 370, fragment reads 520.  Hence:
-// * K, the K pair plane, V^T (and the bias row) travel by LDS-DMA - no staging registers, no ds_write, no compiler-placed vmcnt in the loop - into a ring of
-//   FOUR unpadded tile slots: the DMAs of tile t+3 are issued at the head of a wave's matrix segment of tile t (the slot of tile t-1: last read by B in phase
-//   2t+1), every matrix segment ends with a counted vmcnt that leaves only its own DMAs in flight, so a DMA has three phases to land and tile t+2 is complete,
-//   for both halves, behind the barrier that closes phase 2t+3 - A reads it from phase 2t+4 on;
+// PING-PONG of the block's two wave halves (round 6; engine option attn_pp, default for key counts that are a multiple of 64): waves 0-3 ("A", one per
+// SIMD) and waves 4-7 ("B", their SIMD partners) run the SAME instruction sequence - [softmax of tile t] [P.V of tile t, Q.K^T of tile t+1] - half a tile
+// period apart, so that every SIMD holds one wave in a matrix segment (24 back-to-back MFMAs = 896 pipe cycles) beside one in a softmax segment (max / sub /
+// 33 v_exp_f32 / pack).  In attn_d64_pipe_kernel both waves of a SIMD are in the same phase (one barrier per tile): the SQ counters put the matrix pipe at 0.53
+// busy with VALU issue active 0.48 of the time - the pipes ran in SUM, not in MAX (profiles/r06_attn_sq_counters.txt).  MI355X_MICROARCH.md "Two waves per
+// SIMD": complementary segments (matrix beside VALU / memory) are what nets.
+//     A (0-3):  QK(0) softmax(0) | PV(0) QK(1)   softmax(1) | PV(1) QK(2)   softmax(2) | ...          "|" = the ONE barrier a wave passes per tile (OB = 1):
+//     B (4-7):        QK(0)      | softmax(0)    PV(0) QK(1) | softmax(1)   PV(1) QK(2) | ...          A behind its softmax segment, B behind its matrix segment
+// How it got here (every step measured; profiles/r06_attn_pp_*.txt, NOTES.md "Round 6"):
+// * compile-time ablations of the first build (register-staged tiles, two barriers per tile): MFMAs + softmax + barriers alone took 1 837 cycles per tile pair -
+//   the pipe floor is 1 792 - but the whole kernel 3 550: global loads into registers 750, LDS staging writes 370, fragment reads 520.  Hence tiles travel by
+//   LDS-DMA - no staging registers, no ds_write, no compiler-placed vmcnt in the loop (hipcc does not count LDS-DMAs: tile-list entries come through scalar loads)
+//   - into a ring of SIX unpadded slots: the DMAs of tile t+4 go out at the head of the softmax segment of tile t (slot of tile t-2: its last reader, B's matrix
+//   segment, lies two barriers back for either half); before its barrier every wave leaves only its two youngest DMA batches in flight, so whatever a half reads
+//   behind a barrier (K of tile t+1 in its matrix segment, V^T of tile t+1 in its next softmax segment) has landed on both halves' side;
 // * images are [64 rows][8 chunks of 16 B], chunk c of row r at position c ^ ((r >> 1) & 7): the 16 lanes of a ds_read_b128 group read 16 different
-//   (row parity, position) pairs - conflict-free without padding (the DMA writes 1 KB runs: rows cannot be padded);
+//   (row parity, position) pairs - conflict-free without padding (a DMA writes 1 KB runs: rows cannot be padded); measured 0.7 % conflict cycles;
 // * K row rho of a 32-key half holds key pi(rho) (bits 2 and 3 swapped, as in attn_d512_kernel): the 8 probabilities a lane owns per 16-key step are then 8
 //   CONSECUTIVE keys and a V^T fragment is ONE ds_read_b128 (was two ds_read_b64 at a 136-byte pitch).  This permutes the k-slots of the P.V MFMAs: results
 //   equal the pipelines' up to the order of the fp32 sums inside an MFMA (not bit-identical; dense and tile-list walks of THIS kernel stay bit-identical);
-// * BIAS = 0 (no key bias: every cross-attention): accumulators start from 0, no bias row at all (8 of 40 fragment reads).  LIST = 0: dense walk.
+// * BIAS = 0 (no key bias: every cross-attention): accumulators start from 0, no bias row at all (8 of 40 fragment reads).  LIST = 0: dense walk;
+// * a segment trace (s_memtime stamps, ABL = 64) showed the SOFTMAX segment to be the long pole (~1 000-1 100 cycles of VALU issue + ~120 cycles per DMA
+//   instruction + an exposed LDS round trip for the V^T fragments, against ~1 100 for the matrix segment) with the matrix wave waiting 500-700 cycles at each of
+//   the two barriers per tile: the V^T reads now go out behind the max (they land under the exponentials) and each wave passes ONE barrier per tile (OB = 1) - the
+//   halves meet once per tile period instead of every phase being as long as its longer segment.  This form NEEDS the static s_setprio 1 of waves 4-7
+//   (attention d=64 per step: 24.2 ms with it, 29.0 ms without or with per-segment flips; the round-5 pipelines: 28.8).
+// Template parameters besides BIAS / LIST: KE / DS / OB = -1..2 / 0..3 / 0 keep the measured alternatives compilable (K fragment reads in the softmax segment;
+// DMAs split between the head of the softmax and the end of the matrix segment; two barriers per tile): all within noise of each other or slower
+// (profiles/r06_attn_pp_placements_ab.txt); KE = -1 is the first DMA build (four slots, everything inside the matrix segment).
 // Needs Lk % 64 == 0 (no masked tail rows); other launches keep the pipelines.  DMAs and tile indices are unconditional with clamped indices (a rewritten slot
 // nobody reads any more); Q.K^T of the tile behind the last one runs on stale bytes whose logits nobody consumes - a matrix segment is ONE basic block.
-// pp_flags bit 0: s_setprio 1 for waves 4-7 (the second-dispatched half loses every arbitration at equal priority; item 4 of the guide's section); bit 1: per-segment flips
-// ABL (bench only, sdm_bench_attn; 0 in the engine): 1 no softmax VALU, 2 no P.V MFMAs, 4 no Q.K^T MFMAs, 8 no DMAs, 32 no fragment reads
+// pp_flags bit 0: s_setprio 1 for waves 4-7; bit 1: per-segment priority flips (A/B).
+// ABL (bench only, sdm_bench_attn; 0 in the engine): 1 no softmax VALU, 2 no P.V MFMAs, 4 no Q.K^T MFMAs, 8 no DMAs, 32 no fragment reads, 64 segment stamps
 // ------------------------------------------------------------------------------------------------
-// KE (second build of the DMA form; profiles/r06_attn_pp_dma_ablation.txt: with the DMAs and the K fragment reads inside the matrix segment that segment still
-// paid ~690 cycles per tile pair for DMA issue - a VMEM instruction blocks the issuing wave for 100-185 cycles beside MFMAs and LDS reads - and ~990 for the
-// fragment reads): KE >= 0 moves the DMAs to the head of the SOFTMAX segment (the VALU wave has ~250 cycles of slack per phase) and the ring grows to SIX slots:
-// the DMAs of tile t+4 go out in the softmax segment of tile t (slot of tile t-2: last read by B in phase 2t-1), every matrix segment still ends with the counted
-// vmcnt, so tile t+3 is complete behind the barrier closing phase 2t+3 and readable from A's softmax segment of tile t+2 (phase 2t+5) on.  KE = 1 / 2 also reads
-// the K fragments (+ bias) of the first / both 32-key halves of tile t+1 at the END of the softmax segment, next to the V^T fragments: at KE = 2 a matrix segment
-// is 24 MFMAs and nothing else.  KE = -1: the first DMA build (four slots, everything inside the matrix segment).
 #define ATTN64PP_SLOT (3 * 8192 + 256)
 #define ATTN64PP_SMEM (6 * ATTN64PP_SLOT)
 template <int ABL = 0, int BIAS = 1, int LIST = 1, int KE = 0, int DS = 1, int OB = 1>
@@ -967,8 +968,9 @@ __global__ void __launch_bounds__(512, 2) attn_d64_pp_kernel(AttnParams p) {
   };
   // softmax of one tile: logits -> fp16 probabilities in B-operand layout; running maximum, rescale of O^T / the denominators when it moved.  Everything is
   // pinned inside the segment (the probabilities are only consumed by the NEXT segment's MFMAs: left alone, the sub / exp / pack stream sinks behind the barrier)
-  auto softmax = [&](f32x16 (&s)[2], f16x8 (&pf)[2][2], auto&& after_max) {
+  auto softmax = [&](f32x16 (&s)[2], f16x8 (&pf)[2][2], auto&& mid0, auto&& mid1, auto&& after_max) {
     if (ABL & 1) {
+      mid0(); mid1();
       after_max();
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
@@ -979,11 +981,13 @@ __global__ void __launch_bounds__(512, 2) attn_d64_pp_kernel(AttnParams p) {
       SDM_PIN_HERE_V4(pf[0][0], pf[0][1], pf[1][0], pf[1][1]);
       return;
     }
+    // the segment's remaining DMA instructions are spread over the VALU stream (mid0 behind the max, mid1 between the two halves of the exponentials): a DMA keeps the address path busy for ~120 cycles and the NEXT
+    // vector-memory instruction of the wave waits for it - VALU instructions in between do not
     float mx = SDM_NEG_BIG;
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+    for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s[0][r]), s[0][r + 1]);
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s[kt][r]), s[kt][r + 1]);
+    for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s[1][r]), s[1][r + 1]);
     {      // the other key half of this query sits in lane ^ 32: one v_permlane32_swap instead of a trip through the LDS crossbar
       unsigned int xa = __builtin_bit_cast(unsigned int, mx), xb = xa;
       sdm_permlane32_swap(xa, xb);
@@ -992,6 +996,9 @@ __global__ void __launch_bounds__(512, 2) attn_d64_pp_kernel(AttnParams p) {
     const float mnew = fmaxf(m_i, mx);
     const float alpha = sdm_exp2(m_i - mnew);
     m_i = mnew;
+    SDM_SCHED_FENCE();
+    mid0();
+    SDM_SCHED_FENCE();
     if (__any(alpha != 1.0f)) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) ls[r] *= alpha;
@@ -1004,9 +1011,12 @@ __global__ void __launch_bounds__(512, 2) attn_d64_pp_kernel(AttnParams p) {
     // (the 32 subtractions as 16 v_pk_add_f32 were measured: +7-9 % kernel time - packed fp32 shares the wide datapath with the partner wave's MFMAs,
     //  profiles/r06_attn_pp_packed_sub_ab.txt)
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+    for (int r = 0; r < 16; ++r) s[0][r] = sdm_exp2(s[0][r] - mnew);
+    SDM_SCHED_FENCE();
+    mid1();
+    SDM_SCHED_FENCE();
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[kt][r] = sdm_exp2(s[kt][r] - mnew);
+    for (int r = 0; r < 16; ++r) s[1][r] = sdm_exp2(s[1][r] - mnew);
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -1049,7 +1059,8 @@ __global__ void __launch_bounds__(512, 2) attn_d64_pp_kernel(AttnParams p) {
     // ---- softmax segment of tile t.  KE >= 0: it opens with the DMAs of tile t+D.  The V^T fragments of tile t (and, KE >= 1, K fragments / biases of tile
     //      t+1) are read at its end, so that the matrix segment opens with MFMAs instead of an LDS round trip ----
     if (p.pp_flags & 2) SDM_SETPRIO(0);                                // (A/B: per-segment priority flips - matrix segments at priority 2)
-    if (KE >= 0) dma(tq, bD, 0, OB ? NDMA : DS);
+    constexpr int NE = OB ? NDMA : DS;                                 // DMAs of this segment: the first NE - 2 at its head, the last two inside the max chain
+    if (KE >= 0) dma(tq, bD, 0, NE >= 2 ? NE - 2 : NE);
     int tqn;                                                           // index of the tile the NEXT request (KE >= 0) / this iteration's matrix segment (KE < 0) asks for
     {
       int in_ = t + D + (KE >= 0 ? 1 : 0); if (in_ > nwalk - 1) in_ = nwalk - 1;
@@ -1059,7 +1070,8 @@ __global__ void __launch_bounds__(512, 2) attn_d64_pp_kernel(AttnParams p) {
     if (ABL & 64) stamp(t, 4);                                         // (DMAs issued)
     VFrag v0, v1;
     KFrag k0, k1;
-    softmax(s, pf, [&]() { load_v(bt, 0, v0); load_v(bt, 1, v1); });
+    softmax(s, pf, [&]() { if (KE >= 0 && NE >= 2) dma(tq, bD, NE - 2, NE - 1); }, [&]() { if (KE >= 0 && NE >= 2) dma(tq, bD, NE - 1, NE); },
+            [&]() { load_v(bt, 0, v0); load_v(bt, 1, v1); });
     if (ABL & 64) stamp(t, 5);                                         // (softmax VALU done: the probabilities are pinned in front of this point)
     if (KE >= 1) { load_bias(b1, s); load_k(b1, 0, k0); }
     if (KE >= 2) load_k(b1, 1, k1);

@@ -123,6 +123,7 @@ static OptEntry g_opts[] = {
   {"attn_pipe", 1, 1, "8-wave split-precision d=64 attention: two-tile software pipeline"},
   {"attn_pipe4", 1, 1, "the same pipeline for the 4-wave launches (two K / three V^T buffers)"},
   {"attn_pp", 1, 1, "split-precision d=64 attention with fp32 output as a ping-pong of the block's wave halves (attn_d64_pp_kernel, 256 query rows per block): 0 off, 1 on, 2 on without the static priority of the younger half, 3 on with per-segment priority flips"},
+  {"attn_pp_min_blocks", 128, 128, "attn_pp: launches with fewer 256-row blocks than this keep the 4-wave pipelines (0 in tests: the ping-pong kernel at any size)"},
   {"attn_ksplit", 0, 0, "key split of the d=64 split-precision attention: 0 by launch size (blocks that do not fill the chip's block slots a whole number of times), 1 off, 2 / 4 forced"},
   {"precise_mask", -1, -1, "stages in split precision (-1 = the config's own mask; per-stage attribution experiments; read at sdm_create)"},
 };
@@ -1305,7 +1306,9 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
   T part_o, part_ml;
   if (D == 64 && ap.prec && ap.out_f32 && !(ap.prec == 1 && opt("attn_pv_split"))) {
     const int force_nw = opt("attn_nw");
-    const bool pp = ap.prec == 2 && opt("attn_pp") != 0 && !force_nw && Lk % 64 == 0;      // ping-pong kernel: always 256-row blocks, one per CU
+    // ping-pong kernel: always 256-row blocks, one per CU; launches of fewer than 128 such blocks (the 16^2 level: 80) keep the 4-wave pipelines, whose 128-row
+    // blocks spread over twice as many CUs (measured 0.63 vs 0.79 ms at B = 4, profiles/r06_attn_pp_lab.txt)
+    const bool pp = ap.prec == 2 && opt("attn_pp") != 0 && !force_nw && Lk % 64 == 0 && (long)B * heads * sdm_cdiv(Lq, 256) >= opt("attn_pp_min_blocks");
     const bool nw8 = pp || (force_nw ? (force_nw == 8) : ((long)B * heads * sdm_cdiv(Lq, 256) >= 1024));
     const long blocks = (long)B * heads * 8 * sdm_cdiv(sdm_cdiv(Lq, nw8 ? 256 : 128), 8), slots = (long)device_cus() * (nw8 ? 1 : 2);
     const int o = opt("attn_ksplit");
@@ -1376,7 +1379,8 @@ static int op_attention_raw(sdm_ctx* e, const half_t* q, int ldq, const half_t* 
       // where they measured faster: the split-precision variant with >= 4 such blocks per CU (B=4 h=5 L=16384: 4.01 vs 4.25 ms;
       // h=10 Lq=4096: 2.39 vs 2.24 ms, i.e. slower; the fp16 variant is neutral to -10 %) - profiles/r02_ablate_attn_nw8.txt
       const int force_nw = opt("attn_nw");                          // A/B / test option: 4 or 8
-      const bool pp = ap.prec == 2 && ap.out_f32 && opt("attn_pp") != 0 && !force_nw && Lk % 64 == 0;      // (LDS-DMA tiles: no masked tail rows)
+      const bool pp = ap.prec == 2 && ap.out_f32 && opt("attn_pp") != 0 && !force_nw && Lk % 64 == 0 &&      // (LDS-DMA tiles: no masked tail rows)
+                      (long)B * heads * sdm_cdiv(Lq, 256) >= opt("attn_pp_min_blocks");
       const bool nw8 = pp || (force_nw ? (force_nw == 8) : (ap.prec && (long)B * heads * sdm_cdiv(Lq, 256) >= 1024));
       const int qrows = nw8 ? 256 : 128;
       p.batch = B; p.heads = heads; p.nq_blocks = sdm_cdiv(Lq, qrows); p.q_chunks = 8;     // B*heads*8 units: always a multiple of 8

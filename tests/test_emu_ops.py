@@ -253,6 +253,7 @@ def test_attention_d64_split_precision(emu_engine, engine_option):
             # order inside the MFMAs -> equal to the pipelines to fp32 rounding, not bit for bit
             engine_option(emu_engine, "attn_nw", 0)
             engine_option(emu_engine, "attn_pp", 1)
+            engine_option(emu_engine, "attn_pp_min_blocks", 0)      # (the engine keeps launches of < 128 blocks on the pipelines)
             emu_engine.lib.kernel_counts(reset=True)
             rpp = emu_engine.op_attention_split(q, kk, vv, 2, bias=bb)
             assert emu_engine.lib.kernel_counts().get("attn_d64_pp", 0) == (1 if lk % 64 == 0 else 0)
@@ -278,6 +279,7 @@ def test_attention_d64_skips_underflowing_key_tiles(emu_engine, engine_option):
     assert torch.equal(sparse, dense)
     # the same property of the ping-pong kernel (split-precision operands; tile-list walk through scalar loads, dense walk by arithmetic), with and without a key split
     engine_option(emu_engine, "attn_pp", 1)
+    engine_option(emu_engine, "attn_pp_min_blocks", 0)
     for ns in (1, 2):
         engine_option(emu_engine, "attn_ksplit", ns)
         engine_option(emu_engine, "attn_dense", 0)

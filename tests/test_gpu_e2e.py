@@ -100,7 +100,7 @@ def test_e2e_tiny_node_sizes_640_896(pkg, S):
     m.engine.close()
 
 
-@pytest.mark.parametrize("nw", [8, 4])
+@pytest.mark.parametrize("nw", [0, 8, 4])
 def test_e2e_tiny_through_each_attention_pipeline_kernel(pkg, engine_option, nw):
     """End to end against the oracle with every d=64 attention launch forced onto one of the two shipped pipeline kernels (8-wave: what
     the level-0 attentions of the timed B=4 1024^2 step run; 4-wave: everything else), trimap bias and tile lists included."""
@@ -108,6 +108,8 @@ def test_e2e_tiny_through_each_attention_pipeline_kernel(pkg, engine_option, nw)
     from comfyui_sdmatte_amd import engine as E
     lib = E.load_library()
     engine_option(lib, "attn_nw", nw)
+    if nw == 0:
+        engine_option(lib, "attn_pp_min_blocks", 0)      # nw = 0: the ping-pong kernel (round 6) at this tiny size too (the engine keeps launches of < 128 blocks on the pipelines)
     lib.kernel_counts(reset=True)
     m, w, img, tri, data, ref, out, d = _run(pkg, SDMatteConfig.tiny(), 256, 2)
     counts = lib.kernel_counts()
@@ -115,7 +117,8 @@ def test_e2e_tiny_through_each_attention_pipeline_kernel(pkg, engine_option, nw)
     assert d.max().item() <= TOL
     # (the cross-attentions keep fp16 hi | lo planes for K | V - their producer is a folded 3x3 conv - and run attn_d64<prec2,*>; every
     # self-attention, i.e. everything with fp8 pair planes, a trimap bias and tile lists, must have gone through the pipeline kernel)
-    assert counts.get(f"attn_d64_pipe<{nw}>", 0) > 0 and not any(c for n, c in counts.items() if n.startswith("attn_d64<prec3")), counts
+    kern = f"attn_d64_pipe<{nw}>" if nw else "attn_d64_pp"
+    assert counts.get(kern, 0) > 0 and not any(c for n, c in counts.items() if n.startswith("attn_d64<prec3")), counts
     m.engine.close()
 
 

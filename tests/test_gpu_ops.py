@@ -289,6 +289,7 @@ def test_attention_pipeline_kernels_with_trimap_bias_and_skipped_tiles(eng, engi
     import numpy as np
     engine_option(eng, "attn_nw", nw)
     engine_option(eng, "attn_pp", 1 if nw == 0 else 0)
+    engine_option(eng, "attn_pp_min_blocks", 0)      # (the engine keeps launches of < 128 blocks on the pipelines)
     eng.lib.kernel_counts(reset=True)
     lk = (333, 1500, 40) if nw else (320, 1536, 64)      # (the ping-pong kernel takes whole 64-key tiles by LDS-DMA: ragged key counts stay on the pipelines)
     e_blocks = S.check_attention(eng, DEV, 2, 5, 700, lk[0], 64, use_bias=True, split=True, blocks=True, seed=11, atol=1e-3)     # 5-6 key tiles, ragged queries

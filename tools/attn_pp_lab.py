@@ -15,6 +15,7 @@ from comfyui_sdmatte_amd.config import SDMatteConfig
 eng = Engine(SDMatteConfig.tiny(), 0, precision="fp16x3")
 g = torch.Generator(device="cuda").manual_seed(3)
 ok = True
+eng.lib.set_option("attn_pp_min_blocks", 0)      # consistency at every size; the timings below use the engine's own threshold
 for (B, h, Lq, Lk) in ((2, 5, 16384, 16384), (1, 10, 1000, 4096 + 64), (2, 20, 256, 16384), (1, 10, 4096, 4096), (1, 2, 300, 64), (1, 2, 300, 192)):
     q = torch.randn(B, Lq, h * 64, generator=g, device="cuda") * 1.5
     k = torch.randn(B, Lk, h * 64, generator=g, device="cuda") * 1.5
@@ -36,6 +37,7 @@ for (B, h, Lq, Lk) in ((2, 5, 16384, 16384), (1, 10, 1000, 4096 + 64), (2, 20, 2
             ok &= same
             print(f"B={B} h={h} Lq={Lq} Lk={Lk} {name:12s} attn_pp={mode}: 4 runs identical, list == dense, max|d| vs pipelines {md:.2e}: {same}", flush=True)
 print("ping-pong kernel consistent:", ok)
+eng.lib.set_option("attn_pp_min_blocks", 128)
 
 
 def timed(fn, n=10):
