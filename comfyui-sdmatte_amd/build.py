@@ -73,12 +73,13 @@ def build_all(verbose=False, force=False, extra_flags=(), out=None):
             asm_text = fh.read()
             checked, problems = check_async_loads.check(asm_text)
             c2, p2 = check_async_loads.check_scalar_loads(asm_text)      # the ping-pong attention kernels' scalar loads (tile-list entries through inline asm)
-            checked, problems = checked + c2, problems + p2
+            c3, p3 = check_async_loads.check_dma_loops(asm_text)         # ... and nothing but LDS-DMAs on vmcnt inside their loops (counted waits)
+            checked, problems = checked + c2 + c3, problems + p2 + p3
         if problems:
             sys.stderr.write("\n".join(problems) + "\n")
-            raise RuntimeError("F8 conv kernel: an asynchronously loaded register is touched before its hand-over (check_async_loads.py)")
+            raise RuntimeError("a build-time guard of the asynchronous loads failed (check_async_loads.py): see the lines above")
         if verbose:
-            print(f"[sdmatte] {checked} asynchronous loads checked (F8 conv kernels: vector loads; ping-pong attention kernels: scalar loads)")
+            print(f"[sdmatte] {checked} asynchronous loads / DMA loops checked (F8 conv kernels: vector loads; ping-pong attention kernels: scalar loads, LDS-DMA loops)")
         shutil.move(tlib, lib)
     # a kernel whose body the HOST pass rejects (e.g. inline asm that is only valid for gfx950) is dropped without a diagnostic and leaves
     # an undefined stub symbol: load the library once so that this fails here, in the build container, and not on the GPU box

@@ -245,8 +245,47 @@ def check_scalar_loads(asm_text, verbose=False):
     return checked, problems
 
 
+# ---- third guard: the ping-pong attention kernels wait for their LDS-DMAs with COUNTED vmcnt immediates (k_attn.h: "only the two youngest batches stay in flight").
+#      Those counts hold only while the DMAs are the loop's ONLY vector-memory instructions: a register spill (scratch_*), a vector load hipcc substitutes for a scalar
+#      one, or a store inside the loop would shift them - silently, towards too lenient.  Every loop (backward branch) of those kernels that issues an LDS-DMA may
+#      contain no other buffer_ / global_ / scratch_ / flat_ instruction.
+def check_dma_loops(asm_text, verbose=False):
+    lines = asm_text.split("\n")
+    problems, checked = [], 0
+    keys = [m.group(1) for m in (SCALAR_KERNEL_RE.match(l) for l in lines) if m]
+    for key in keys:
+        st = [i for i, l in enumerate(lines) if l.startswith(key + ":")]
+        en = [i for i, l in enumerate(lines) if ".amdhsa_kernel " + key in l]
+        if not st or not en:
+            problems.append(f"{key}: kernel body not found in the assembly")
+            continue
+        K, labels = _parse(lines[st[0] + 1:en[0]])
+        loops = 0
+        for j, t in enumerate(K):
+            if not t.startswith(("s_branch", "s_cbranch")):
+                continue
+            tgt = labels.get(_branch_target(t))
+            if tgt is None or tgt > j:
+                continue
+            body = K[tgt:j + 1]
+            if not any(u.startswith("buffer_load") and " lds" in u for u in body):
+                continue
+            loops += 1
+            for u in body:
+                if u.startswith(("buffer_", "global_", "scratch_", "flat_")) and not (u.startswith("buffer_load") and " lds" in u) and not u.startswith("buffer_inv") and not u.startswith("buffer_wbl2"):
+                    problems.append(f"{key[:70]}: `{u[:60]}` inside a loop that waits for its LDS-DMAs with counted vmcnt")
+            checked += 1
+        abl = re.search(r"kernelILi(\d+)E", key)
+        if loops == 0 and not (abl and int(abl.group(1)) & 8):      # (ABL & 8: the bench-only ablations without DMAs)
+            problems.append(f"{key[:70]}: no loop with LDS-DMAs found (kernel restructured? update check_async_loads.py)")
+    return checked, problems
+
+
 if __name__ == "__main__":
     checked, problems = check(open(sys.argv[1]).read(), verbose="-v" in sys.argv)
+    c3, p3 = check_dma_loops(open(sys.argv[1]).read())
+    checked += c3
+    problems += p3
     c2, p2 = check_scalar_loads(open(sys.argv[1]).read(), verbose="-v" in sys.argv)
     checked += c2
     problems += p2

@@ -114,3 +114,18 @@ def test_scalar_load_guard():
     checked, problems = G.check_scalar_loads(asm(["\ts_waitcnt vmcnt(0)", "\ts_mov_b32 s60, s53"]))      # a vector-memory wait does not cover it
     assert problems
     assert G.check_scalar_loads("_Zother:\n\ts_load_dword s1, s[2:3], 0x0\n\ts_mov_b32 s4, s1\n\ts_endpgm\n\t.amdhsa_kernel _Zother\n") == (0, [])
+
+
+def test_dma_loop_guard():
+    """the ping-pong attention kernels count their LDS-DMAs on vmcnt by hand: any other vector-memory instruction inside such a loop (a spill, a substituted vector load) breaks the counts"""
+    name = "_Z18attn_d64_pp_kernelILi0ELi0ELi0ELi0ELi1ELi1EEv10AttnParams"
+
+    def asm(extra):
+        return "\n".join([name + ":", ".LBB9_1:", "\tbuffer_load_dwordx4 v1, s[4:7], s8 offen lds", "\tv_exp_f32_e32 v2, v3"] + extra +
+                         ["\ts_waitcnt vmcnt(6)", "\ts_barrier", "\ts_cbranch_scc0 .LBB9_1", "\tglobal_store_dwordx4 v[4:5], v[6:9], off", "\ts_endpgm", "\t.amdhsa_kernel " + name])
+    assert G.check_dma_loops(asm([])) == (1, [])                                       # (the store behind the loop is none of its business)
+    for bad in ("\tscratch_store_dword off, v9, s32", "\tglobal_load_dword v9, v10, s[2:3]", "\tbuffer_load_dwordx4 v[9:12], v13, s[4:7], 0 offen"):
+        checked, problems = G.check_dma_loops(asm([bad]))
+        assert problems, bad
+    checked, problems = G.check_dma_loops(asm([]).replace(" lds", ""))                  # no DMA loop at all: the kernel was restructured
+    assert problems
