@@ -275,11 +275,11 @@ class SDMatteApply:
                 "ckpt_name": (list(MODEL_URLS.keys()), ),
                 "image": ("IMAGE", {"tooltip": "image to matte"}),
                 "trimap": ("MASK", {"tooltip": "trimap: white = foreground, black = background, gray = unknown"}),
-                "inference_size": ([512, 640, 768, 896, 1024], {"default": 1024, "tooltip": "inference resolution"}),
-                "is_transparent": ("BOOLEAN", {"default": False, "tooltip": "input depicts a transparent object"}),
-                "output_mode": (["alpha_only", "matted_rgba", "matted_rgb"], {"default": "alpha_only"}),
-                "mask_refine": ("BOOLEAN", {"default": True, "tooltip": "constrain the alpha with the trimap"}),
-                "trimap_constraint": ("FLOAT", {"default": 0.8, "min": 0.1, "max": 1.0, "step": 0.1}),
+                "inference_size": ([512, 640, 768, 896, 1024], {"default": 1024, "tooltip": "inference resolution: higher = better and slower (1024 best quality, 768 balanced)"}),
+                "is_transparent": ("BOOLEAN", {"default": False, "tooltip": "enable when the source image has a transparent background / depicts a transparent object"}),
+                "output_mode": (["alpha_only", "matted_rgba", "matted_rgb"], {"default": "alpha_only", "tooltip": "alpha_only = mask only; matted_rgba = cut-out on a transparent background; matted_rgb = cut-out on black"}),
+                "mask_refine": ("BOOLEAN", {"default": True, "tooltip": "refine the mask with the trimap: filters unwanted regions, less background interference"}),
+                "trimap_constraint": ("FLOAT", {"default": 0.8, "min": 0.1, "max": 1.0, "step": 0.1, "tooltip": "strength of the trimap constraint (0.1-1.0): higher = stricter; 0.8 balanced, 0.9 strict, 0.6 permissive"}),
             },
             "optional": {
                 "force_cpu": ("BOOLEAN", {"default": False}),
